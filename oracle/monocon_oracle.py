@@ -1,0 +1,482 @@
+"""CPU oracle for the MonoCon hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A from-scratch, functional (flat ``state_dict`` in, tensors out) restatement of the
+reference's algorithm for the path SURVEY.md §8 scopes: DLA-34 -> DLAUp -> dense
+heads, target generation, the ten losses, heat-map decode, grad-clip + AdamW +
+cyclic schedule.  It issues plain ``torch`` CPU ops (fp32 by default; pass a
+``.double()`` state dict / input for an fp64 run).
+
+Pinning: ``tests/golden/make_golden.py`` imports the real reference from
+``/root/reference`` *in the build container only*, loads the same synthetic
+parameters, and stores its outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` holds this file to those vectors.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module -- and only as the checker / the timed CPU baseline.  Nothing
+under ``monocon-pytorch_amd/`` imports it.
+
+Each function cites the reference lines it follows (paths relative to the
+reference repository root).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+PI = math.pi
+EPS = 1e-12
+BN_EPS, BN_MOM = 1e-5, 0.1
+ABN_EPS, ABN_MOM, ABN_EPS_VAR = 1e-3, 0.03, 1e-3
+
+HEAD_BRANCHES = OrderedDict([
+    ("heatmap_head", "center_heatmap_pred"), ("wh_head", "wh_pred"),
+    ("offset_head", "offset_pred"), ("center2kpt_offset_head", "center2kpt_offset_pred"),
+    ("kpt_heatmap_head", "kpt_heatmap_pred"), ("kpt_heatmap_offset_head", "kpt_heatmap_offset_pred"),
+    ("dim_head", "dim_pred"), ("depth_head", "depth_pred"),
+])
+PRED_ORDER = ("center_heatmap_pred", "kpt_heatmap_pred", "wh_pred", "offset_pred",
+              "kpt_heatmap_offset_pred", "center2kpt_offset_pred", "dim_pred", "depth_pred",
+              "alpha_cls_pred", "alpha_offset_pred")
+LOSS_ORDER = ("loss_center_heatmap", "loss_wh", "loss_offset", "loss_dim",
+              "loss_center2kpt_offset", "loss_kpt_heatmap", "loss_kpt_heatmap_offset",
+              "loss_alpha_cls", "loss_alpha_reg", "loss_depth")
+
+
+# ------------------------------------------------------------------ primitive layers
+class _Ctx:
+    """Carries the flat state dict, the train/eval switch and (train mode) the
+    updated BatchNorm buffers, so the functional code can mirror nn.BatchNorm2d's
+    running-statistics side effect without mutating the caller's tensors."""
+
+    def __init__(self, sd, train):
+        self.sd, self.train = sd, train
+        self.new_buffers = {}
+
+    def bn(self, x, name, eps=BN_EPS, mom=BN_MOM, affine=True):
+        sd = self.sd
+        w = sd[name + ".weight"] if affine else None
+        b = sd[name + ".bias"] if affine else None
+        if not self.train:
+            return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], w, b, False, mom, eps)
+        rm = sd[name + ".running_mean"].detach().clone()
+        rv = sd[name + ".running_var"].detach().clone()
+        y = F.batch_norm(x, rm, rv, w, b, True, mom, eps)
+        self.new_buffers[name + ".running_mean"] = rm
+        self.new_buffers[name + ".running_var"] = rv
+        self.new_buffers[name + ".num_batches_tracked"] = sd[name + ".num_batches_tracked"] + 1
+        return y
+
+    def conv(self, x, name, stride=1, pad=0):
+        return F.conv2d(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"), stride, pad)
+
+    def cbr(self, x, conv, bn, stride=1, pad=1, relu=True):
+        y = self.bn(self.conv(x, conv, stride, pad), bn)
+        return F.relu(y) if relu else y
+
+
+def _basic_block(cx, x, name, stride, residual=None):
+    """reference model/backbone/dla.py:34-51"""
+    if residual is None:
+        residual = x
+    y = cx.cbr(x, name + ".conv1", name + ".bn1", stride)
+    y = cx.bn(cx.conv(y, name + ".conv2", 1, 1), name + ".bn2")
+    return F.relu(y + residual)
+
+
+def _tree(cx, x, name, levels, cin, cout, stride, level_root, children=None):
+    """reference model/backbone/dla.py:135-205.  tree1 inherits the stride, tree2 is
+    stride 1 (dla.py:157-167).  Note the nested tree ignores the residual it is handed
+    and recomputes its own (dla.py:193-194); the outer ``project`` is still *executed*
+    by the reference, so in train mode its BN running statistics tick -- reproduced."""
+    children = [] if children is None else children
+    bottom = F.max_pool2d(x, stride, stride) if stride > 1 else x
+    if cin != cout:
+        residual = cx.bn(cx.conv(bottom, name + ".project.0"), name + ".project.1")
+    else:
+        residual = bottom
+    if level_root:
+        children.append(bottom)
+    if levels == 1:
+        x1 = _basic_block(cx, x, name + ".tree1", stride, residual)
+        x2 = _basic_block(cx, x1, name + ".tree2", 1)
+        cat = torch.cat([x2, x1] + children, 1)
+        return F.relu(cx.bn(cx.conv(cat, name + ".root.conv"), name + ".root.bn"))   # dla.py:124-132
+    x1 = _tree(cx, x, name + ".tree1", levels - 1, cin, cout, stride, False)
+    children.append(x1)
+    return _tree(cx, x1, name + ".tree2", levels - 1, cout, cout, 1, False, children)
+
+
+def backbone(cx, img):
+    """reference model/backbone/dla.py:273-278; returns the six level outputs."""
+    x = cx.cbr(img, "backbone.base_layer.0", "backbone.base_layer.1", 1, 3)
+    l0 = cx.cbr(x, "backbone.level0.0", "backbone.level0.1", 1)
+    l1 = cx.cbr(l0, "backbone.level1.0", "backbone.level1.1", 2)
+    l2 = _tree(cx, l1, "backbone.level2", 1, 32, 64, 2, False)
+    l3 = _tree(cx, l2, "backbone.level3", 2, 64, 128, 2, True)
+    l4 = _tree(cx, l3, "backbone.level4", 2, 128, 256, 2, True)
+    l5 = _tree(cx, l4, "backbone.level5", 1, 256, 512, 2, True)
+    return [l0, l1, l2, l3, l4, l5]
+
+
+def _ida(cx, name, layers):
+    """reference model/backbone/dla_neck.py:94-106: proj 3x3 -> depthwise deconv x2 ->
+    node 3x3 over cat([previous, upsampled])."""
+    for i in range(1, len(layers)):
+        p = cx.cbr(layers[i], "%s.proj_%d.conv" % (name, i), "%s.proj_%d.bn1" % (name, i))
+        w = cx.sd["%s.up_%d.weight" % (name, i)]
+        u = F.conv_transpose2d(p, w, None, stride=2, padding=1, groups=w.shape[0])
+        layers[i] = cx.cbr(torch.cat([layers[i - 1], u], 1),
+                           "%s.node_%d.conv" % (name, i), "%s.node_%d.bn1" % (name, i))
+    return layers
+
+
+def neck(cx, levels):
+    """reference model/backbone/dla_neck.py:136-143 with start_level=2."""
+    layers = list(levels[2:])
+    for i in range(len(layers) - 1):
+        layers[-i - 2:] = _ida(cx, "neck.ida_%d" % i, layers[-i - 2:])
+    return layers[-1]
+
+
+def _attn_bn(cx, x, name):
+    """reference model/norm/attentive_norm.py:79-91,154-164."""
+    sd = cx.sd
+    o = cx.bn(x, name, ABN_EPS, ABN_MOM, affine=False)
+    var, mean = torch.var_mean(x, dim=(2, 3), keepdim=True)            # unbiased
+    s = mean * (var + ABN_EPS_VAR).rsqrt()
+    a = F.conv2d(s, sd[name + ".attn_weights.attention.0.weight"])
+    a = cx.bn(a, name + ".attn_weights.attention.1")
+    y = (F.relu6(a + 3.0) / 6.0).view(x.shape[0], -1)                   # (B, 10)
+    g = (y @ sd[name + ".weight_"])[:, :, None, None]
+    b = (y @ sd[name + ".bias_"])[:, :, None, None]
+    return g * o + b
+
+
+def head_predictions(cx, feat):
+    """reference model/dense_heads/monocon_heads.py:165-200."""
+    raw = {}
+    for br, key in HEAD_BRANCHES.items():
+        h = cx.conv(feat, "head.%s.0" % br, 1, 1)
+        h = F.relu(_attn_bn(cx, h, "head.%s.1" % br))
+        raw[key] = cx.conv(h, "head.%s.3" % br)
+    h = F.relu(_attn_bn(cx, cx.conv(feat, "head.dir_feat.0", 1, 1), "head.dir_feat.1"))
+    raw["alpha_cls_pred"] = cx.conv(h, "head.dir_cls.0")
+    raw["alpha_offset_pred"] = cx.conv(h, "head.dir_reg.0")
+    for k in ("center_heatmap_pred", "kpt_heatmap_pred"):
+        raw[k] = torch.clamp(torch.sigmoid(raw[k]), 1e-4, 1.0 - 1e-4)
+    d = raw["depth_pred"]
+    d0 = 1.0 / (torch.sigmoid(d[:, 0:1]) + EPS) - 1.0
+    raw["depth_pred"] = torch.cat([d0, d[:, 1:2]], 1)
+    return OrderedDict((k, raw[k]) for k in PRED_ORDER)
+
+
+def forward(sd, img, train=False, return_levels=False):
+    """Detector forward (reference model/detector/monocon_detector.py:53-66,85-87).
+    Returns (pred_dict, feat[, levels], new_buffers)."""
+    cx = _Ctx(sd, train)
+    levels = backbone(cx, img)
+    feat = neck(cx, levels)
+    preds = head_predictions(cx, feat)
+    if return_levels:
+        return preds, feat, levels, cx.new_buffers
+    return preds, feat, cx.new_buffers
+
+
+# ------------------------------------------------------------------ targets
+def gaussian_radius(h, w, min_overlap=0.3):
+    """reference utils/tensor_ops.py:77-99 (python-float arithmetic on fp32 inputs)."""
+    h, w = float(h), float(w)
+    b1 = h + w
+    c1 = w * h * (1 - min_overlap) / (1 + min_overlap)
+    r1 = (b1 - math.sqrt(b1 * b1 - 4 * c1)) / 2
+    b2 = 2 * (h + w)
+    c2 = (1 - min_overlap) * w * h
+    r2 = (b2 - math.sqrt(b2 * b2 - 16 * c2)) / 8
+    a3 = 4 * min_overlap
+    b3 = -2 * min_overlap * (h + w)
+    c3 = (min_overlap - 1) * w * h
+    r3 = (b3 + math.sqrt(b3 * b3 - 4 * a3 * c3)) / (2 * a3)
+    return min(r1, r2, r3)
+
+
+def _splat(canvas, cx_, cy_, radius):
+    """reference utils/tensor_ops.py:62-125: max-splat of exp(-(x^2+y^2)/(2 sigma^2)),
+    sigma = (2r+1)/6, entries below eps*max zeroed, clipped at the canvas border."""
+    H, W = canvas.shape
+    r = radius
+    sigma = (2 * r + 1) / 6
+    ax = torch.arange(-r, r + 1, dtype=torch.float32)
+    g = (-(ax[None, :] * ax[None, :] + ax[:, None] * ax[:, None]) / (2 * sigma * sigma)).exp()
+    g[g < torch.finfo(g.dtype).eps * g.max()] = 0
+    left, right = min(cx_, r), min(W - cx_, r + 1)
+    top, bottom = min(cy_, r), min(H - cy_, r + 1)
+    dst = canvas[cy_ - top:cy_ + bottom, cx_ - left:cx_ + right]
+    src = g[r - top:r + bottom, r - left:r + right]
+    torch.max(dst, src, out=dst)
+
+
+def angle_to_bin(alpha, nbins=12):
+    """reference utils/target_generator.py:141-149.  ``alpha`` is an fp32 tensor scalar
+    in the reference, so the modulo / add happen in fp32 tensor arithmetic."""
+    per = 2 * PI / float(nbins)
+    a = alpha % (2 * PI)
+    shifted = (a + per / 2) % (2 * PI)
+    cid = int(shifted / per)
+    return cid, shifted - (cid * per + per / 2)
+
+
+def make_targets(label, pad_hw, feat_shape, num_classes=3, max_objs=30, num_kpt=9, nbins=12):
+    """reference utils/target_generator.py:30-177.  ``label``: dict of fp32 CPU tensors."""
+    B, _, fh, fw = feat_shape
+    ph, pw = pad_hw
+    hr, wr = fh / ph, fw / pw
+    z = torch.zeros
+    T = OrderedDict(
+        center_heatmap_target=z(B, num_classes, fh, fw), wh_target=z(B, max_objs, 2),
+        offset_target=z(B, max_objs, 2), dim_target=z(B, max_objs, 3),
+        alpha_cls_target=z(B, max_objs, 1), alpha_offset_target=z(B, max_objs, 1),
+        depth_target=z(B, max_objs, 1), center2kpt_offset_target=z(B, max_objs, num_kpt * 2),
+        kpt_heatmap_target=z(B, num_kpt, fh, fw), kpt_heatmap_offset_target=z(B, max_objs, num_kpt * 2),
+        indices=z(B, max_objs, dtype=torch.long), indices_kpt=z(B, max_objs, num_kpt, dtype=torch.long),
+        mask_target=z(B, max_objs), mask_center2kpt_offset=z(B, max_objs, num_kpt * 2),
+        mask_kpt_heatmap_offset=z(B, max_objs, num_kpt * 2))
+    for b in range(B):
+        m = label["mask"][b].bool()
+        boxes = label["gt_bboxes"][b][m]
+        if len(boxes) < 1:
+            continue
+        cls = label["gt_labels"][b][m].long()
+        ctx = (boxes[:, 0] + boxes[:, 2]) * wr / 2.0
+        cty = (boxes[:, 1] + boxes[:, 3]) * hr / 2.0
+        kp = label["gt_kpts_2d"][b][m].reshape(-1, num_kpt, 2).clone()
+        kp[:, :, 0] = kp[:, :, 0] * wr
+        kp[:, :, 1] = kp[:, :, 1] * hr
+        kvis = label["gt_kpts_valid_mask"][b][m]
+        b3d = label["gt_bboxes_3d"][b][m]
+        dep = label["depths"][b][m]
+        for o in range(len(boxes)):
+            xi, yi = int(ctx[o].int()), int(cty[o].int())                 # truncation toward zero
+            bh = (boxes[o, 3] - boxes[o, 1]) * hr
+            bw = (boxes[o, 2] - boxes[o, 0]) * wr
+            rad = max(0, int(gaussian_radius(bh, bw)))
+            _splat(T["center_heatmap_target"][b, cls[o]], xi, yi, rad)
+            T["indices"][b, o] = yi * fw + xi
+            T["wh_target"][b, o] = torch.stack([bw, bh])
+            T["offset_target"][b, o] = torch.stack([ctx[o] - xi, cty[o] - yi])
+            T["dim_target"][b, o] = b3d[o, 3:6]
+            T["depth_target"][b, o] = dep[o]
+            cid, res = angle_to_bin(b3d[o, 6], nbins)
+            T["alpha_cls_target"][b, o] = cid
+            T["alpha_offset_target"][b, o] = res
+            T["mask_target"][b, o] = 1
+            for k in range(num_kpt):
+                if kvis[o, k] < 1:
+                    continue
+                kx, ky = kp[o, k, 0], kp[o, k, 1]
+                kxi, kyi = int(kx.int()), int(ky.int())
+                T["center2kpt_offset_target"][b, o, 2 * k] = kx - xi
+                T["center2kpt_offset_target"][b, o, 2 * k + 1] = ky - yi
+                T["mask_center2kpt_offset"][b, o, 2 * k:2 * k + 2] = 1
+                if not (0 <= kxi < fw and 0 <= kyi < fh):
+                    continue
+                _splat(T["kpt_heatmap_target"][b, k], kxi, kyi, rad)
+                T["indices_kpt"][b, o, k] = kyi * fw + kxi
+                T["kpt_heatmap_offset_target"][b, o, 2 * k] = kx - kxi
+                T["kpt_heatmap_offset_target"][b, o, 2 * k + 1] = ky - kyi
+                T["mask_kpt_heatmap_offset"][b, o, 2 * k:2 * k + 2] = 1
+    T["indices_kpt"] = T["indices_kpt"].reshape(B, -1)
+    T["mask_target"] = T["mask_target"].bool()
+    return T
+
+
+# ------------------------------------------------------------------ losses
+def _gather(feat, ind):
+    """reference utils/tensor_ops.py:34-59: (B,C,H,W) x (B,K) -> (B,K,C)."""
+    B, C = feat.shape[:2]
+    f = feat.permute(0, 2, 3, 1).reshape(B, -1, C)
+    return f.gather(1, ind[:, :, None].expand(-1, -1, C))
+
+
+def gaussian_focal(p, t):
+    """reference losses/focal_loss.py:21-44."""
+    pos = (t == 1).to(p.dtype)
+    neg = (t < 1).to(p.dtype)
+    npos = pos.sum()
+    pl = (torch.log(p + EPS) * (1 - p) ** 2 * pos).sum()
+    nl = (torch.log(1 - p + EPS) * p ** 2 * (1 - t) ** 4 * neg).sum()
+    return -nl if npos == 0 else -(pl + nl) / npos
+
+
+def _l1(p, t, avg=None):
+    """reference losses/l1_loss.py:13-39 + losses/utils.py:20-34."""
+    assert p.shape == t.shape and t.numel() > 0
+    d = (p - t).abs()
+    return d.mean() if avg is None else d.sum() / avg
+
+
+def losses(pred, T, max_objs=30, num_kpt=9, nbins=12):
+    """reference model/dense_heads/monocon_heads.py:203-310 (loss weights :98-111)."""
+    ind, indk, m = T["indices"], T["indices_kpt"], T["mask_target"]
+    B = ind.shape[0]
+    g = lambda k: _gather(pred[k], ind)[m]
+    out = OrderedDict()
+    out["loss_center_heatmap"] = gaussian_focal(pred["center_heatmap_pred"], T["center_heatmap_target"])
+    out["loss_wh"] = 0.1 * _l1(g("wh_pred"), T["wh_target"][m])
+    out["loss_offset"] = _l1(g("offset_pred"), T["offset_target"][m])
+    dp, dt = g("dim_pred"), T["dim_target"][m]
+    dl = (dp - dt).abs() / dp.detach()                                   # losses/dim_loss.py:13-25
+    with torch.no_grad():
+        comp = F.l1_loss(dp, dt) / dl.mean()
+    out["loss_dim"] = (dl * comp).mean()
+    mk = T["mask_center2kpt_offset"][m]
+    out["loss_center2kpt_offset"] = _l1(g("center2kpt_offset_pred") * mk, T["center2kpt_offset_target"][m],
+                                        mk.sum() + EPS)
+    out["loss_kpt_heatmap"] = gaussian_focal(pred["kpt_heatmap_pred"], T["kpt_heatmap_target"])
+    kho = _gather(pred["kpt_heatmap_offset_pred"], indk).reshape(B, max_objs, num_kpt * 2)[m]
+    mkh = T["mask_kpt_heatmap_offset"][m]
+    out["loss_kpt_heatmap_offset"] = _l1(kho, T["kpt_heatmap_offset_target"][m], mkh.sum() + EPS)
+    acls = T["alpha_cls_target"][m].long()
+    onehot = torch.zeros(len(acls), nbins, dtype=torch.long).scatter_(1, acls.view(-1, 1), 1)
+    if m.sum() > 0:
+        out["loss_alpha_cls"] = F.binary_cross_entropy_with_logits(g("alpha_cls_pred"), onehot.to(dp.dtype))
+    else:
+        out["loss_alpha_cls"] = 0.0
+    areg = (g("alpha_offset_pred") * onehot).sum(1, keepdim=True)
+    out["loss_alpha_reg"] = _l1(areg, T["alpha_offset_target"][m])
+    dd = g("depth_pred")
+    d, s, t = dd[:, 0], dd[:, 1], T["depth_target"][m].flatten()         # losses/depth_loss.py:10-21
+    out["loss_depth"] = (1.4142 * torch.exp(-s) * (d - t).abs() + s).mean()
+    return OrderedDict((k, out[k]) for k in LOSS_ORDER)
+
+
+# ------------------------------------------------------------------ decode
+def local_max_keep(heat, kernel=3):
+    """reference utils/tensor_ops.py:17-21; returns (heat*keep, keep mask)."""
+    hmax = F.max_pool2d(heat, kernel, 1, (kernel - 1) // 2)
+    keep = hmax == heat
+    return heat * keep.to(heat.dtype), keep
+
+
+def canonical_topk(flat, k):
+    """top-k with the canonical tie order (score desc, flat index asc).  torch.topk's
+    own tie order on CPU is arbitrary, so the oracle defines the order
+    the HIP kernel must reproduce; on tie-free inputs it equals torch.topk."""
+    B, N = flat.shape
+    order = torch.argsort(flat, dim=1, descending=True, stable=True)[:, :k]
+    return flat.gather(1, order), order
+
+
+def decode(pred, P2, pad_hw, topk=30, thres=0.4, kernel=3, nbins=12):
+    """reference model/dense_heads/monocon_heads.py:399-482 (+ :379-396, :485-558).
+    ``P2``: (B,3,4) float32.  Returns a dict of dense (B,K,...) tensors plus the keep
+    masks; ragged per-image lists are produced from ``box_mask`` by the caller."""
+    heat = pred["center_heatmap_pred"]
+    B, C, H, W = heat.shape
+    ph, pw = pad_hw
+    filt, keep = local_max_keep(heat, kernel)
+    scores, flat = canonical_topk(filt.reshape(B, -1), topk)
+    cls = flat // (H * W)
+    ind = flat % (H * W)
+    ys = (ind // W).to(heat.dtype)
+    xs = (ind % W).to(heat.dtype)
+    wh = _gather(pred["wh_pred"], ind)
+    off = _gather(pred["offset_pred"], ind)
+    tx, ty = xs + off[..., 0], ys + off[..., 1]
+    sx, sy = pw / W, ph / H
+    box2d = torch.stack([(tx - wh[..., 0] / 2) * sx, (ty - wh[..., 1] / 2) * sy,
+                         (tx + wh[..., 0] / 2) * sx, (ty + wh[..., 1] / 2) * sy], 2)
+    acls = _gather(pred["alpha_cls_pred"], ind)
+    aoff = _gather(pred["alpha_offset_pred"], ind)
+    abin = acls.argmax(-1, keepdim=True)
+    alpha = abin * (2 * PI / nbins) + aoff.gather(2, abin)
+    alpha = torch.where(alpha > PI, alpha - 2 * PI, alpha)
+    alpha = torch.where(alpha < -PI, alpha + 2 * PI, alpha)
+    dep = _gather(pred["depth_pred"], ind)
+    sigma = torch.exp(-dep[..., 1])
+    score = scores * sigma
+    c2k = _gather(pred["center2kpt_offset_pred"], ind)[..., -2:]
+    u = (c2k[..., 0:1] + xs[..., None]) * sx
+    v = (c2k[..., 1:2] + ys[..., None]) * sy
+    P2 = torch.as_tensor(P2, dtype=heat.dtype)
+    roty = alpha + torch.atan2(u - P2[:, 0:1, 2:3], torch.zeros_like(u) + P2[:, 0:1, 0:1])
+    while (roty > PI).any():
+        roty = torch.where(roty > PI, roty - 2 * PI, roty)
+    while (roty < -PI).any():
+        roty = torch.where(roty < -PI, roty + 2 * PI, roty)
+    z = dep[..., 0:1]
+    homo = torch.cat([u * z, v * z, z, torch.ones_like(z)], -1)          # (B,K,4)
+    xyz = []
+    for b in range(B):
+        view = torch.eye(4, dtype=torch.float32)
+        view[:3, :4] = P2[b].float()
+        inv_t = torch.inverse(view).transpose(0, 1).to(heat.dtype)
+        xyz.append((homo[b] @ inv_t)[:, :3])
+    xyz = torch.stack(xyz)
+    dim = _gather(pred["dim_pred"], ind)
+    box3d = torch.cat([xyz, dim, roty], -1)
+    box_mask = score > thres
+    box3d_shift = box3d.clone()
+    box3d_shift[..., 1] += 0.5 * box3d[..., 4]                          # monocon_heads.py:313-329
+    return dict(keep=keep, scores=scores, flat_index=flat, cls=cls, ind=ind, ys=ys, xs=xs,
+                box2d=torch.cat([box2d, score[..., None]], -1), box3d=box3d, box3d_shift=box3d_shift,
+                box_mask=box_mask)
+
+
+def p2_inverse(P2):
+    """inverse of the 4x4 view-padded projection, as monocon_heads.py:544-546 builds it."""
+    out = []
+    for p in np.asarray(P2, np.float32):
+        view = torch.eye(4, dtype=torch.float32)
+        view[:3, :4] = torch.from_numpy(p)
+        out.append(torch.inverse(view))
+    return torch.stack(out)
+
+
+# ------------------------------------------------------------------ solver
+def cyclic_values(step_count, total_steps, base_lr=2.25e-4, base_mom=0.95,
+                  lr_ratio=(10, 1e-4), mom_ratio=(0.85 / 0.95, 1.0), period_up=0.4):
+    """reference solver/cyclic_scheduler.py:36-76; ``step_count`` is the scheduler's
+    ``_step_count`` (1 right after construction)."""
+    up = int(total_steps * period_up)
+    ann = lambda s, e, f: e + 0.5 * (s - e) * (math.cos(math.pi * f) + 1)
+    if step_count < up:
+        f = step_count / up
+        return ann(base_lr, base_lr * lr_ratio[0], f), ann(base_mom, base_mom * mom_ratio[0], f)
+    f = (step_count - up) / (total_steps - up)
+    return (ann(base_lr * lr_ratio[0], base_lr * lr_ratio[1], f),
+            ann(base_mom * mom_ratio[0], base_mom * mom_ratio[1], f))
+
+
+def grad_total_norm(grads):
+    """L2 norm over all gradients (torch.nn.utils.clip_grad_norm_, norm_type=2)."""
+    return torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+
+
+def clip_and_adamw(params, grads, m, v, step, lr, beta1, beta2=0.99, eps=1e-8, wd=1e-5, max_norm=35.0,
+                   total_norm=None):
+    """reference engine/monocon_engine.py:94-102: clip_grad_norm_(35, L2) then
+    torch.optim.AdamW (decoupled weight decay, bias-corrected moments).  Operates in
+    place on lists of tensors; returns the total norm.  ``total_norm`` may be supplied
+    when ``grads`` is only a subset of the model's gradients."""
+    total = grad_total_norm(grads) if total_norm is None else torch.as_tensor(total_norm, dtype=torch.float32)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for p, g, m_, v_ in zip(params, grads, m, v):
+        g = g * coef
+        p.mul_(1 - lr * wd)
+        m_.mul_(beta1).add_(g, alpha=1 - beta1)
+        v_.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+        denom = (v_.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m_, denom, value=-lr / bc1)
+    return total
+
+
+# ------------------------------------------------------------------ whole train step
+def train_forward(sd, batch):
+    """One training forward: (pred, target, loss_dict, new_buffers).  ``sd`` tensors that
+    require grad receive gradients from ``sum(loss_dict.values()).backward()``."""
+    preds, feat, newbuf = forward(sd, batch["img"], train=True)
+    T = make_targets(batch["label"], batch["img_metas"]["pad_shape"][0], tuple(feat.shape))
+    L = losses(preds, T)
+    return preds, T, L, newbuf

@@ -1,0 +1,38 @@
+"""pytest wiring: path set-up, the ``gpu`` marker and shared fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "monocon-pytorch_amd")
+for p in (PKG, REPO):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+GOLDEN_SEED = 7
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden_sd():
+    """Synthetic parameters (seed 7) with the calibrated BN statistics fixture."""
+    from hipmonocon import synth
+    stats = load_golden("bn_calib_seed%d.npz" % GOLDEN_SEED)
+    return synth.make_state_dict(GOLDEN_SEED, bn_stats={k: stats[k] for k in stats.files})
+
+
+def rel_err(a, b):
+    """norm-wise error used throughout: max|a-b| / max|b|."""
+    import torch
+    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).double()
+    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing here
+travels as code the tests execute: the tests read the .npz files this script
+writes.  Inputs and parameters come from hipmonocon.synth (bit-reproducible from a
+seed), so only reference OUTPUTS are stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")                       # reference packages win name lookups
+sys.path.append(os.path.join(REPO, "monocon-pytorch_amd"))  # only ``hipmonocon`` is taken from here
+
+import numpy as np
+import torch
+import torch.optim as optim
+from torch.nn.utils import clip_grad_norm_
+
+from model import MonoConDetector                           # noqa: E402  (reference)
+from solver import CyclicScheduler                          # noqa: E402  (reference)
+from utils.target_generator import TargetGenerator          # noqa: E402  (reference)
+from hipmonocon import synth, netspec                       # noqa: E402  (this repo)
+
+SEED = 7
+torch.set_num_threads(8)
+META = {"torch": torch.__version__, "threads": torch.get_num_threads(), "seed": SEED}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def ref_model(sd, test_config=None, train=False, double=False):
+    m = MonoConDetector(34, pretrained_backbone=False, test_config=test_config)
+    m.load_state_dict(sd, strict=True)
+    if double:
+        m = m.double()
+    return m.train() if train else m.eval()
+
+
+def calibrate(seed):
+    """One train-mode pass with momentum 1.0 so running stats == batch stats
+    (raw random-init eval statistics make activations blow up)."""
+    sd = synth.make_state_dict(seed)
+    m = ref_model(sd, train=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.momentum = 1.0
+    batch = synth.make_batch(seed + 100, 4, 128, 256, with_labels=False)
+    with torch.no_grad():
+        feat = m.neck(m.backbone(batch["img"]))[0]
+        m.head._get_predictions(feat)
+    out = {k: v for k, v in m.state_dict().items()
+           if k.endswith("running_mean") or k.endswith("running_var")}
+    return out
+
+
+def strided(t, step=97):
+    return t.detach().reshape(-1)[::step].clone()
+
+
+def main():
+    # ---------------------------------------------------------------- (0) BN calibration
+    stats = calibrate(SEED)
+    save("bn_calib_seed%d.npz" % SEED, **stats)
+    sd = synth.make_state_dict(SEED, bn_stats={k: v.numpy() for k, v in stats.items()})
+
+    # ---------------------------------------------------------------- (1) small-res eval forward
+    b = synth.make_batch(SEED + 1, 2, 64, 128, with_labels=False)
+    m = ref_model(sd)
+    with torch.no_grad():
+        levels = m.backbone(b["img"])
+        feat = m.neck(levels)[0]
+        pred = m.head.forward_test(feat)
+    m64 = ref_model(sd, double=True)
+    with torch.no_grad():
+        pred64 = m64({"img": b["img"].double()})
+    out = {"feat": feat}
+    for i, l in enumerate(levels):
+        out["level%d_sample" % i] = strided(l, 13)
+        out["level%d_absmax" % i] = l.abs().max()
+    for k, v in pred.items():
+        out[k] = v
+        out["f64." + k] = pred64[k]
+    save("fwd_small_eval.npz", **out)
+
+    # ---------------------------------------------------------------- (2) full-res eval forward
+    b = synth.make_batch(SEED + 2, 2, 384, 1280, with_labels=False)
+    with torch.no_grad():
+        pred = m({"img": b["img"]})
+        pred64 = m64({"img": b["img"].double()})
+    out = {}
+    for k, v in pred.items():
+        out[k + ".sample"] = strided(v)
+        out[k + ".f64sample"] = strided(pred64[k])
+        out[k + ".sum"] = v.double().sum()
+        out[k + ".absmax"] = v.abs().max()
+    save("fwd_full_eval.npz", **out)
+
+    # ---------------------------------------------------------------- (3) target generator
+    lab = synth.make_labels(SEED + 3, 3, 384, 1280)
+    # hand-made edge cases on image 2: border-clipped splat, radius 0, out-of-map keypoints
+    lab["gt_bboxes"][2, 0] = [0.0, 100.0, 30.0, 380.0]       # hugging the left border
+    lab["gt_bboxes"][2, 1] = [1270.0, 370.0, 1279.0, 383.0]  # tiny box in the corner -> radius 0
+    lab["gt_kpts_2d"][2, 0, 0:4] = [-20.0, 50.0, 1300.0, 400.0]
+    lab["gt_kpts_valid_mask"][2, 0, 0:2] = 1
+    lab["mask"][2, 0:2] = 1
+    lab_t = {k: torch.from_numpy(v.copy()) for k, v in lab.items()}
+    tg = TargetGenerator()
+    data = {"img": torch.zeros(3, 3, 384, 1280), "img_metas": {"pad_shape": [(384, 1280)] * 3}, "label": lab_t}
+    T = tg(data, feat_shape=(3, 64, 96, 320))
+    save("targets.npz", **{"in." + k: v for k, v in lab.items()}, **T)
+
+    # ---------------------------------------------------------------- (4) train forward/backward
+    hb, wb = 192, 384
+    b = synth.make_batch(SEED + 4, 2, hb, wb)
+    mt = ref_model(sd, train=True)
+    pred, loss = mt(b)
+    total = sum(v for v in loss.values())
+    total.backward()
+    out = {"total": total}
+    for k, v in loss.items():
+        out[k] = v if torch.is_tensor(v) else torch.tensor(float(v))
+    dead = []
+    for n, p in mt.named_parameters():
+        if p.grad is None:
+            dead.append(n)
+            continue
+        out["gnorm." + n] = p.grad.double().norm()
+        out["gsample." + n] = strided(p.grad, 101)
+    out["dead"] = np.array(dead)
+    newsd = mt.state_dict()
+    for k in newsd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["buf." + k] = newsd[k]
+    for k, v in pred.items():
+        out["pred." + k + ".sample"] = strided(v, 31)
+    save("train_step.npz", **out)
+    assert sorted(dead) == sorted(netspec.DEAD_PARAMS), dead
+
+    # ---------------------------------------------------------------- (6) clip + AdamW + cyclic scheduler
+    names = ["backbone.level2.tree1.conv1.weight", "neck.ida_2.up_3.weight", "head.wh_head.3.bias",
+             "head.dim_head.1.weight_", "backbone.base_layer.1.weight"]
+    opt = optim.AdamW(mt.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99))
+    sch = CyclicScheduler(opt, total_steps=1000, target_lr_ratio=(10, 1e-4),
+                          target_momentum_ratio=(0.85 / 0.95, 1.0), period_up=0.4)
+    sched = []
+    out = {}
+    pd = dict(mt.named_parameters())
+    for step in range(3):
+        if step > 0:
+            opt.zero_grad()
+            bb = synth.make_batch(SEED + 4 + step, 2, hb, wb)
+            _, loss = mt(bb)
+            sum(v for v in loss.values()).backward()
+        for n in names:                                   # pre-clip gradients of the sampled tensors
+            out["grad%d.%s" % (step, n)] = pd[n].grad.detach().clone()
+        norm = clip_grad_norm_(mt.parameters(), max_norm=35, norm_type=2.0)
+        lr_used, b1_used = opt.param_groups[0]["lr"], opt.param_groups[0]["betas"][0]
+        opt.step()
+        sch.step()
+        sched.append([lr_used, b1_used, float(norm)])
+        for n in names:
+            out["step%d.%s" % (step, n)] = pd[n].detach().clone()
+    for extra in range(3, 12):
+        sched.append([opt.param_groups[0]["lr"], opt.param_groups[0]["betas"][0], 0.0])
+        opt.step(); sch.step()
+    out["sched"] = np.array(sched, dtype=np.float64)
+    save("adamw.npz", **out)
+
+    # ---------------------------------------------------------------- (5) decode
+    for K in (30, 100):
+        seed = SEED + 50
+        while True:
+            d = synth.make_decode_inputs(seed, 4, 96, 320, topk=K)
+            heat = torch.from_numpy(d["center_heatmap_pred"])
+            hmax = torch.nn.functional.max_pool2d(heat, 3, 1, 1)
+            filt = (heat * (hmax == heat).float()).view(4, -1)
+            top = torch.topk(filt, K + 1)[0]
+            if (top[:, 1:] < top[:, :-1]).all():
+                break
+            seed += 1
+        mdec = ref_model(sd, test_config={"topk": K, "local_maximum_kernel": 3, "max_per_img": 30,
+                                          "test_thres": 0.4})
+        pd_ = {k: torch.from_numpy(v.copy()) for k, v in d.items()}
+        data = {"img_metas": {"pad_shape": [(384, 1280)] * 4}, "calib": [synth.SynthCalib() for _ in range(4)]}
+        # dense intermediates through the reference's own helpers
+        from utils.tensor_ops import get_local_maximum, get_topk_from_heatmap
+        filt_ref = get_local_maximum(pd_["center_heatmap_pred"], kernel=3)
+        sc, ind, cls, ys, xs = get_topk_from_heatmap(filt_ref, k=K)
+        b2d, b3d, labs = mdec.head._get_bboxes(data, {k: v.clone() for k, v in pd_.items()})
+        out = {"seed": seed, "keep_packed": np.packbits((filt_ref > 0).numpy()),
+               "scores": sc, "ind": ind, "cls": cls, "ys": ys, "xs": xs}
+        for i in range(4):
+            out["box2d.%d" % i] = b2d[i]
+            out["box3d.%d" % i] = b3d[i]
+            out["label.%d" % i] = labs[i]
+        save("decode_k%d.npz" % K, **out)
+
+    json.dump(META, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

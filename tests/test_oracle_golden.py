@@ -1,0 +1,148 @@
+"""Pin the CPU oracle (oracle/monocon_oracle.py) to the golden vectors produced by the
+real reference (tests/golden/make_golden.py).  CPU-only; runs everywhere."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, GOLDEN_SEED
+from hipmonocon import synth, netspec
+from oracle import monocon_oracle as O
+
+TOL = 1e-4   # north_star: fp32 within 1e-4 relative (norm-wise)
+
+
+def test_small_eval_forward(golden_sd):
+    g = load_golden("fwd_small_eval.npz")
+    img = synth.make_batch(GOLDEN_SEED + 1, 2, 64, 128, with_labels=False)["img"]
+    with torch.no_grad():
+        preds, feat, levels, _ = O.forward(golden_sd, img, train=False, return_levels=True)
+    assert rel_err(feat, g["feat"]) < 2e-5
+    for i, l in enumerate(levels):
+        assert rel_err(l.reshape(-1)[::13], g["level%d_sample" % i]) < 2e-5
+    for k, v in preds.items():
+        assert tuple(v.shape) == g[k].shape
+        assert rel_err(v, g[k]) < 2e-5, k
+        assert rel_err(v, g["f64." + k]) < TOL, k
+
+
+def test_small_eval_forward_fp64(golden_sd):
+    g = load_golden("fwd_small_eval.npz")
+    img = synth.make_batch(GOLDEN_SEED + 1, 2, 64, 128, with_labels=False)["img"].double()
+    sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in golden_sd.items()}
+    with torch.no_grad():
+        preds, _, _ = O.forward(sd64, img)
+    for k, v in preds.items():
+        assert rel_err(v, g["f64." + k]) < 1e-9, k
+
+
+def test_full_res_eval_forward(golden_sd):
+    g = load_golden("fwd_full_eval.npz")
+    img = synth.make_batch(GOLDEN_SEED + 2, 2, 384, 1280, with_labels=False)["img"]
+    with torch.no_grad():
+        preds, _, _ = O.forward(golden_sd, img)
+    for k, v in preds.items():
+        assert rel_err(v.reshape(-1)[::97], g[k + ".sample"]) < 5e-5, k
+        assert rel_err(v.reshape(-1)[::97], g[k + ".f64sample"]) < TOL, k
+        assert abs(float(v.double().sum()) - float(g[k + ".sum"])) <= 1e-5 * abs(float(g[k + ".sum"])) + 1e-2
+
+
+def test_targets_exact():
+    g = load_golden("targets.npz")
+    label = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in.")}
+    T = O.make_targets(label, (384, 1280), (3, 64, 96, 320))
+    for k, v in T.items():
+        ref = g[k]
+        assert tuple(v.shape) == ref.shape, k
+        if v.dtype in (torch.long, torch.bool):
+            assert np.array_equal(v.numpy(), ref), k
+        else:
+            assert np.array_equal(v.numpy(), ref), k     # same fp32 op sequence -> bit equal
+
+
+def test_train_step_losses_and_grads(golden_sd):
+    g = load_golden("train_step.npz")
+    batch = synth.make_batch(GOLDEN_SEED + 4, 2, 192, 384)
+    sd = {k: v.clone() for k, v in golden_sd.items()}
+    roles = netspec.state_shapes()
+    for k, v in sd.items():
+        if roles[k][2] == "param":
+            v.requires_grad_(True)
+    preds, T, L, newbuf = O.train_forward(sd, batch)
+    total = sum(v for v in L.values())
+    total.backward()
+    assert rel_err(total.detach(), g["total"]) < 2e-5
+    for k, v in L.items():
+        assert rel_err(torch.as_tensor(v).detach(), g[k]) < 2e-5, k
+    dead = set(g["dead"].tolist())
+    assert dead == set(netspec.DEAD_PARAMS)
+    for k, v in sd.items():
+        if roles[k][2] != "param":
+            continue
+        if k in dead:
+            assert v.grad is None
+            continue
+        gn = float(v.grad.double().norm())
+        assert abs(gn - float(g["gnorm." + k])) <= 2e-3 * float(g["gnorm." + k]) + 1e-7, k
+        assert rel_err(v.grad.reshape(-1)[::101], g["gsample." + k]) < 5e-3, k
+    for k, v in newbuf.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        assert rel_err(v, g["buf." + k]) < 1e-4, k
+
+
+def test_cyclic_schedule_and_adamw(golden_sd):
+    g = load_golden("adamw.npz")
+    sched = g["sched"]
+    for i in range(len(sched)):
+        # _LRScheduler.__init__ already runs one step(), so the values the optimizer uses
+        # at training step i (0-based) come from _step_count == i + 1 (SURVEY §8a quirk ix)
+        lr, b1 = O.cyclic_values(i + 1, 1000)
+        assert abs(lr - sched[i, 0]) < 1e-12 and abs(b1 - sched[i, 1]) < 1e-12, (i, lr, sched[i])
+
+
+def test_adamw_three_steps(golden_sd):
+    """Optimizer arithmetic on the reference's own (pre-clip) gradients.  A chained
+    re-derivation of steps 1..2 from the oracle's gradients is ill-conditioned (the
+    first AdamW step moves every weight by ~lr whatever its gradient), so each step is
+    pinned from the reference's recorded gradient, norm, lr and beta1."""
+    g = load_golden("adamw.npz")
+    names = [k[len("step0."):] for k in g.files if k.startswith("step0.")]
+    P = {n: golden_sd[n].clone() for n in names}
+    M = {n: torch.zeros_like(P[n]) for n in names}
+    V = {n: torch.zeros_like(P[n]) for n in names}
+    for step in range(3):
+        lr, b1, norm = g["sched"][step]
+        assert (lr, b1) == pytest.approx(O.cyclic_values(step + 1, 1000), rel=1e-12)
+        grads = [torch.from_numpy(g["grad%d.%s" % (step, n)]) for n in names]
+        O.clip_and_adamw([P[n] for n in names], grads, [M[n] for n in names], [V[n] for n in names],
+                         step + 1, lr, b1, total_norm=norm)
+        for n in names:
+            assert rel_err(P[n], g["step%d.%s" % (step, n)]) < 1e-6, (step, n)
+
+
+def test_total_norm_matches_reference(golden_sd):
+    g = load_golden("train_step.npz")
+    a = load_golden("adamw.npz")
+    tot = np.sqrt(sum(float(g[k]) ** 2 for k in g.files if k.startswith("gnorm.")))
+    assert abs(tot - a["sched"][0, 2]) < 1e-5 * tot
+
+
+@pytest.mark.parametrize("K", [30, 100])
+def test_decode(K):
+    g = load_golden("decode_k%d.npz" % K)
+    d = synth.make_decode_inputs(int(g["seed"]), 4, 96, 320, topk=K)
+    pred = {k: torch.from_numpy(v) for k, v in d.items()}
+    P2 = np.stack([synth.KITTI_P2] * 4)
+    R = O.decode(pred, P2, (384, 1280), topk=K, thres=0.4)
+    assert np.array_equal(np.packbits(R["keep"].numpy()), g["keep_packed"])
+    assert np.array_equal(R["ind"].numpy(), g["ind"])
+    assert np.array_equal(R["cls"].numpy(), g["cls"])
+    assert np.array_equal(R["scores"].numpy(), g["scores"])
+    assert np.array_equal(R["ys"].numpy(), g["ys"].astype(np.float32))
+    assert np.array_equal(R["xs"].numpy(), g["xs"])
+    for i in range(4):
+        mk = R["box_mask"][i]
+        assert int(mk.sum()) == g["box2d.%d" % i].shape[0]
+        assert rel_err(R["box2d"][i][mk], g["box2d.%d" % i]) < 1e-6
+        assert rel_err(R["box3d_shift"][i][mk], g["box3d.%d" % i]) < 1e-5
+        assert np.array_equal(R["cls"][i][mk].numpy(), g["label.%d" % i])
