@@ -1,0 +1,133 @@
+/*
+ * monocon_hip.h -- C-ABI of libmonocon_hip.so, the MI355X (gfx950) implementation of the
+ * MonoCon hot path (DLA-34 -> DLAUp -> attentive-norm dense heads -> decode).
+ *
+ * The reference (2gunsu/monocon-pytorch) is pure Python over torch.nn and defines no FFI;
+ * these entry points are what a ctypes binding for its hot path binds instead of the
+ * torch.nn modules.  Each entry cites the reference code it replaces (paths relative to
+ * the reference repository root).  Conventions:
+ *   - plain C types only: raw device pointers, sizes, a hipStream_t passed as void*;
+ *   - every function returns 0 on success, <0 on error (text via mc_last_error);
+ *   - all work is enqueued asynchronously on the given stream; no hidden device sync;
+ *   - the caller owns every tensor it passes and keeps it alive until the stream reaches
+ *     the op; the handle owns its workspace, packed weights and plan cache;
+ *   - external tensors use the reference's layouts (NCHW fp32 images / prediction maps,
+ *     OIHW fp32 weights); NHWC is internal.
+ * One handle per process per GPU; not thread-safe.
+ */
+#ifndef MONOCON_HIP_H
+#define MONOCON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mc_handle mc_handle;
+
+enum { MC_F32 = 0, MC_I64 = 1 };
+
+/* One named tensor of the model's state_dict (names = the reference's state_dict keys,
+ * e.g. "backbone.level2.tree1.conv1.weight"; "<key>#grad" binds the gradient buffer). */
+typedef struct mc_tensor_desc {
+    const char *name;
+    void *ptr;          /* device pointer */
+    int64_t numel;
+    int32_t dtype;      /* MC_F32 | MC_I64 */
+} mc_tensor_desc;
+
+/* Order of the ten prediction maps == reference pred_dict order
+ * (model/dense_heads/monocon_heads.py:190-200); channels 3,9,2,2,2,18,3,2,12,12. */
+enum {
+    MC_PRED_CENTER_HEATMAP = 0, MC_PRED_KPT_HEATMAP, MC_PRED_WH, MC_PRED_OFFSET,
+    MC_PRED_KPT_HEATMAP_OFFSET, MC_PRED_CENTER2KPT_OFFSET, MC_PRED_DIM, MC_PRED_DEPTH,
+    MC_PRED_ALPHA_CLS, MC_PRED_ALPHA_OFFSET, MC_NUM_PREDS
+};
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int mc_create(int device, mc_handle **out);
+int mc_destroy(mc_handle *h);
+const char *mc_last_error(mc_handle *h);      /* h may be NULL: last create() error */
+int mc_version(void);
+
+/* ---- parameters -------------------------------------------------------------------- */
+/* Replaces nn.Module parameter ownership: MonoConDetector.state_dict()/load_state_dict()
+ * (model/detector/monocon_detector.py:80-82, engine/base_engine.py:178,208).  Binds the
+ * caller-owned master tensors (all 449 keys must be present). */
+int mc_bind_params(mc_handle *h, const mc_tensor_desc *descs, int n);
+/* Re-derive the device-side packed weights (OIHW -> K-major MFMA panels) and, for eval
+ * mode, the folded BatchNorm scale/shift.  Call after binding and after any parameter
+ * update.  train_mode=0: BN folded from running statistics (model.eval()). */
+int mc_pack_params(mc_handle *h, int train_mode, void *stream);
+
+/* ---- inference forward -------------------------------------------------------------
+ * Replaces MonoConDetector.forward in eval mode: neck(backbone(img))[0] then
+ * MonoConDenseHeads.forward_test (model/detector/monocon_detector.py:53-66,85-87;
+ * model/backbone/dla.py:273-278; model/backbone/dla_neck.py:136-143;
+ * model/dense_heads/monocon_heads.py:165-200; model/norm/attentive_norm.py:154-164).
+ * img: (B,3,H,W) fp32 NCHW, H and W multiples of 32.  preds[i]: (B,C_i,H/4,W/4) fp32 NCHW.
+ * feat_nchw (optional, may be NULL): (B,64,H/4,W/4) copy of the neck output. */
+int mc_forward_infer(mc_handle *h, const float *img, int B, int H, int W,
+                     float *const preds[MC_NUM_PREDS], float *feat_nchw, void *stream);
+
+/* ---- decode -------------------------------------------------------------------------
+ * Replaces MonoConDenseHeads.decode_heatmap + _get_bboxes origin shift
+ * (model/dense_heads/monocon_heads.py:313-329,379-558) and utils/tensor_ops.py:17-31
+ * (get_local_maximum, get_topk_from_heatmap).  3x3 local-maximum filter, per-image top-K
+ * over the flattened C*H*W map (ties: score desc, flat index asc), gathers, box assembly.
+ * preds: the ten NCHW maps (only those the reference reads are touched); P2: (B,3,4);
+ * P2inv: (B,4,4) inverse of the view-padded projection (monocon_heads.py:544-546).
+ * Outputs (all dense, caller-allocated):
+ *   scores (B,K) f32 raw heat-map peaks; flat_index (B,K) i64 into C*H*W; cls (B,K) i64;
+ *   box2d (B,K,5) = x1,y1,x2,y2,score*sigma; box3d (B,K,7) = x,y+h/2,z,dim(3),rot_y;
+ *   keep_localmax (B,C,H,W) u8 or NULL; keep_thr (B,K) u8 = box2d[...,4] > thr. */
+int mc_decode(mc_handle *h, const float *const preds[MC_NUM_PREDS], const float *P2,
+              const float *P2inv, int B, int C, int H, int W, int K, float thr,
+              float pad_h, float pad_w, float *scores, int64_t *flat_index, int64_t *cls,
+              float *box2d, float *box3d, uint8_t *keep_localmax, uint8_t *keep_thr,
+              void *stream);
+
+/* ---- op-level entry points (unit parity tests; same kernels the forward uses) -------
+ * Fused convolution, NHWC fp32: out = act(conv(cat(src...)) * scale + bias + residual).
+ * Replaces nn.Conv2d + nn.BatchNorm2d(eval) + ReLU (+ torch.cat, + residual add) of
+ * BasicBlock / Root / Conv2dBlock (model/backbone/dla.py:34-51,124-132,
+ * model/backbone/dla_neck.py:34-38).  weight: OIHW fp32 (O, sum C_i, k, k), k in {1,3},
+ * stride in {1,2}, pad = k/2; scale/bias/residual may be NULL. */
+int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[], int nsrc,
+               int B, int Hin, int Win, const float *weight_oihw, int Cout, int ksize,
+               int stride, const float *scale, const float *bias, const float *residual,
+               int relu, float *out, void *stream);
+/* 7x7 stem: NCHW (B,3,H,W) in -> NHWC (B,H,W,16) out (model/backbone/dla.py:231-234). */
+int mc_op_stem(mc_handle *h, const float *img_nchw, int B, int H, int W,
+               const float *weight_oihw, const float *scale, const float *bias, float *out,
+               void *stream);
+/* 2x2/2 max-pool, NHWC (model/backbone/dla.py:178-179). */
+int mc_op_maxpool2(mc_handle *h, const float *in, int B, int H, int W, int C, float *out,
+                   void *stream);
+/* depthwise ConvTranspose2d k=4,s=2,p=1, NHWC; weight (C,1,4,4)
+ * (model/backbone/dla_neck.py:58-65). */
+int mc_op_deconv4x4(mc_handle *h, const float *in, int B, int H, int W, int C,
+                    const float *weight, float *out, void *stream);
+/* layout helpers */
+int mc_op_nchw_to_nhwc(mc_handle *h, const float *in, int B, int C, int H, int W, float *out,
+                       void *stream);
+int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W, float *out,
+                       void *stream);
+
+/* ---- introspection ------------------------------------------------------------------ */
+/* Bytes of handle-owned device memory (workspace + packed weights). */
+size_t mc_workspace_bytes(mc_handle *h);
+/* Algorithmic FLOPs / HBM bytes of one inference forward at (B,H,W), computed from the
+ * layer table (SURVEY §8d fusion model). */
+int mc_forward_cost(mc_handle *h, int B, int H, int W, double *flops, double *bytes);
+/* Time the launches of the last forward plan by kind with HIP events on `stream`
+ * (bench.py roofline leg): runs the cached plan `iters` times.  out_ms: [0] all conv-MFMA
+ * kernels, [1] everything else, [2] whole forward; out_n: launches per forward by kind. */
+int mc_profile_forward(mc_handle *h, int iters, float out_ms[3], int out_n[3], void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOCON_HIP_H */

@@ -1,0 +1,404 @@
+// Non-GEMM kernels of the MonoCon forward: parameter packing, 7x7 stem, 2x2 max-pool, depthwise
+// 4x4 transposed convolution, layout transposes and the attentive-norm dense-head passes.
+// All activations are NHWC fp32; every kernel is bandwidth-bound and written for 16-byte
+// per-lane accesses.
+#include "kernels.h"
+#include "conv_mfma.h"
+
+namespace mc {
+
+// ============================================================================ packing
+__global__ void pack_conv_w_kernel(const float *__restrict__ w, int Cout, int Cin, int kk, float *dst,
+                                   int CinTotal, int CoutP, int n_off, int c_off) {
+    const size_t total = (size_t)Cout * Cin * kk;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int tap = e % kk;
+        const int c = (e / kk) % Cin;
+        const int n = e / ((size_t)kk * Cin);
+        const int cg = c + c_off;
+        dst[(((size_t)tap * (CinTotal >> 2) + (cg >> 2)) * CoutP + n + n_off) * 4 + (cg & 3)] = w[e];
+    }
+}
+
+hipError_t launch_pack_conv_w(const float *w, int Cout, int Cin, int ks, float *dst, int CinTotal, int CoutP,
+                              int n_off, int c_off, hipStream_t st) {
+    const size_t total = (size_t)Cout * Cin * ks * ks;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_conv_w_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, ks * ks, dst, CinTotal,
+                       CoutP, n_off, c_off);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero(float *p, size_t n, hipStream_t st) { return hipMemsetAsync(p, 0, n * sizeof(float), st); }
+
+hipError_t launch_copy(const float *src, float *dst, size_t n, hipStream_t st) {
+    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+}
+
+__global__ void fold_bn_kernel(const float *g, const float *b, const float *rm, const float *rv, float eps, int C,
+                               float *scale, float *shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float inv = 1.0f / sqrtf(rv[c] + eps);
+    const float s = (g ? g[c] : 1.f) * inv;
+    scale[c] = s;
+    shift[c] = (b ? b[c] : 0.f) - rm[c] * s;
+}
+
+hipError_t launch_fold_bn(const float *g, const float *b, const float *rm, const float *rv, float eps, int C,
+                          float *scale, float *shift, hipStream_t st) {
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((C + 63) / 64), dim3(64), 0, st, g, b, rm, rv, eps, C, scale, shift);
+    return hipGetLastError();
+}
+
+__global__ void pack_stem_w_kernel(const float *w, float *dst) {
+    // (16,3,7,7) -> [c][r][s][16]
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 16 * 147) return;
+    const int o = e / 147, rem = e % 147;
+    dst[rem * 16 + o] = w[e];
+}
+hipError_t launch_pack_stem_w(const float *w, float *dst, hipStream_t st) {
+    hipLaunchKernelGGL(pack_stem_w_kernel, dim3((16 * 147 + 255) / 256), dim3(256), 0, st, w, dst);
+    return hipGetLastError();
+}
+
+__global__ void pack_deconv_w_kernel(const float *w, int C, float *dst) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= C * 16) return;
+    const int c = e / 16, k = e % 16;
+    dst[k * C + c] = w[e];
+}
+hipError_t launch_pack_deconv_w(const float *w, int C, float *dst, hipStream_t st) {
+    hipLaunchKernelGGL(pack_deconv_w_kernel, dim3((C * 16 + 255) / 256), dim3(256), 0, st, w, C, dst);
+    return hipGetLastError();
+}
+
+// ============================================================================ 7x7 stem
+// NCHW (B,3,H,W) -> NHWC (B,H,W,16), conv7x7 pad 3 + folded BN + ReLU.  VALU direct convolution:
+// a 16x64-pixel tile per workgroup, 4 x-adjacent pixels x 16 channels per thread; weights are
+// wave-uniform and come through the scalar cache.  (reference model/backbone/dla.py:231-234)
+constexpr int ST_TH = 16, ST_TW = 64, ST_LW = 72;
+__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img, int B, int H, int W,
+                                                   const float *__restrict__ wpk, const float *__restrict__ scale,
+                                                   const float *__restrict__ shift, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float tile[3][ST_TH + 6][ST_LW];
+    const int tiles_x = (W + ST_TW - 1) / ST_TW, tiles_y = (H + ST_TH - 1) / ST_TH;
+    const int bt = blockIdx.x;
+    const int b = bt / (tiles_x * tiles_y);
+    const int ty0 = ((bt / tiles_x) % tiles_y) * ST_TH, tx0 = (bt % tiles_x) * ST_TW;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 3 * (ST_TH + 6) * ST_LW; e += 256) {
+        const int lx = e % ST_LW, ly = (e / ST_LW) % (ST_TH + 6), c = e / (ST_LW * (ST_TH + 6));
+        const int y = ty0 - 3 + ly, x = tx0 - 3 + lx;
+        float v = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = img[(((size_t)b * 3 + c) * H + y) * W + x];
+        tile[c][ly][lx] = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    float acc[4][16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[p][o] = 0.f;
+    for (int c = 0; c < 3; ++c) {
+        for (int r = 0; r < 7; ++r) {
+            float in[12];
+            const f32x4 *row = reinterpret_cast<const f32x4 *>(&tile[c][ty + r][tx * 4]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const f32x4 v = row[q];
+                in[q * 4 + 0] = v[0]; in[q * 4 + 1] = v[1]; in[q * 4 + 2] = v[2]; in[q * 4 + 3] = v[3];
+            }
+            const float *wr = wpk + (c * 7 + r) * 7 * 16;
+#pragma unroll
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int o = 0; o < 16; ++o) {
+                    const float wv = wr[s * 16 + o];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[p][o] = fmaf(in[p + s], wv, acc[p][o]);
+                }
+        }
+    }
+    const int y = ty0 + ty;
+    if (y >= H) return;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int x = tx0 + tx * 4 + p;
+        if (x >= W) continue;
+        f32x4 *dst = reinterpret_cast<f32x4 *>(out + (((size_t)b * H + y) * W + x) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc[p][q * 4 + j], scale[q * 4 + j], shift[q * 4 + j]), 0.f);
+            dst[q] = v;
+        }
+    }
+}
+
+hipError_t launch_stem(const float *img, int B, int H, int W, const float *wpk, const float *scale,
+                       const float *shift, float *out, hipStream_t st) {
+    const int tiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
+    hipLaunchKernelGGL(stem_kernel, dim3(B * tiles), dim3(256), 0, st, img, B, H, W, wpk, scale, shift, out);
+    return hipGetLastError();
+}
+
+// ============================================================================ pool / deconv / layout
+__global__ void maxpool2_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4, f32x4 *__restrict__ out) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % C4;
+        const size_t p = e / C4;
+        const int x = p % Wo, y = (p / Wo) % Ho, b = p / ((size_t)Wo * Ho);
+        const f32x4 *r0 = in + (((size_t)b * H + 2 * y) * W + 2 * x) * C4 + c;
+        const f32x4 *r1 = r0 + (size_t)W * C4;
+        const f32x4 a = r0[0], bb = r0[C4], cc = r1[0], d = r1[C4];
+        f32x4 m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], bb[j]), fmaxf(cc[j], d[j]));
+        out[e] = m;
+    }
+}
+static inline int grid_for(size_t total, int bs) {
+    size_t g = (total + bs - 1) / bs;
+    return (int)(g > 16384 ? 16384 : (g == 0 ? 1 : g));
+}
+hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st) {
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const f32x4 *>(in), B, H, W, C / 4, reinterpret_cast<f32x4 *>(out));
+    return hipGetLastError();
+}
+
+// depthwise ConvTranspose2d(k=4, s=2, p=1): out[oy,ox] = sum over the <=2x2 inputs with
+// oy = 2*iy - 1 + ky (reference model/backbone/dla_neck.py:58-65)
+__global__ void deconv4_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4,
+                               const f32x4 *__restrict__ wpk, f32x4 *__restrict__ out) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % C4;
+        const size_t p = e / C4;
+        const int ox = p % Wo, oy = (p / Wo) % Ho, b = p / ((size_t)Wo * Ho);
+        const int iy1 = (oy + 1) >> 1, ky1 = oy + 1 - 2 * iy1;   // ky1 in {0,1}
+        const int ix1 = (ox + 1) >> 1, kx1 = ox + 1 - 2 * ix1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int iy = iy1 - dy, ky = ky1 + 2 * dy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int ix = ix1 - dx, kx = kx1 + 2 * dx;
+                if (ix < 0 || ix >= W) continue;
+                const f32x4 v = in[(((size_t)b * H + iy) * W + ix) * C4 + c];
+                const f32x4 w = wpk[(ky * 4 + kx) * C4 + c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], w[j], acc[j]);
+            }
+        }
+        out[e] = acc;
+    }
+}
+hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out, hipStream_t st) {
+    const size_t total = (size_t)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(deconv4_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const f32x4 *>(in), B, H, W, C / 4, reinterpret_cast<const f32x4 *>(wpk),
+                       reinterpret_cast<f32x4 *>(out));
+    return hipGetLastError();
+}
+
+// tiled transposes between (B,C,HW) and (B,HW,C) through LDS, 32x32 tiles
+__global__ void transpose_kernel(const float *__restrict__ in, int B, int R, int Cn, float *__restrict__ out) {
+    // in: (B, R, Cn) row-major -> out: (B, Cn, R)
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        t[i][tx] = (r < R && c < Cn) ? in[((size_t)b * R + r) * Cn + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < Cn) out[((size_t)b * Cn + c) * R + r] = t[tx][i];
+    }
+}
+hipError_t launch_nchw_to_nhwc(const float *in, int B, int C, int H, int W, float *out, hipStream_t st) {
+    const int HW = H * W;   // (B, C, HW) -> (B, HW, C)
+    hipLaunchKernelGGL(transpose_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, st, in, B, C, HW, out);
+    return hipGetLastError();
+}
+hipError_t launch_nhwc_to_nchw(const float *in, int B, int C, int H, int W, float *out, hipStream_t st) {
+    const int HW = H * W;   // (B, HW, C) -> (B, C, HW)
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (HW + 31) / 32, B), dim3(256), 0, st, in, B, HW, C, out);
+    return hipGetLastError();
+}
+
+// ============================================================================ dense heads
+// Row table: the 65 output channels grouped by producing head (head order = conv column order of
+// the fused 64->576 3x3): heatmap, wh, offset, center2kpt_offset, kpt_heatmap, kpt_heatmap_offset,
+// dim, depth, dir_feat(cls 12 + reg 12).   (reference monocon_heads.py:76-88,165-200)
+static HeadRow g_rows[NUM_OUT_ROWS];
+static int g_row_begin[NUM_HEADS + 1];
+static bool g_rows_init = false;
+static void init_rows() {
+    if (g_rows_init) return;
+    // head -> (pred index, channels, epilogue)
+    const int hp[8][3] = {{0, 3, 1}, {2, 2, 0}, {3, 2, 0}, {5, 18, 0}, {1, 9, 1}, {4, 2, 0}, {6, 3, 0}, {7, 2, 0}};
+    int r = 0;
+    for (int h = 0; h < 8; ++h) {
+        g_row_begin[h] = r;
+        for (int c = 0; c < hp[h][1]; ++c) {
+            int epi = hp[h][2];
+            if (h == 7) epi = (c == 0) ? 2 : 0;
+            g_rows[r++] = HeadRow{h, hp[h][0], c, epi};
+        }
+    }
+    g_row_begin[8] = r;
+    for (int c = 0; c < 12; ++c) g_rows[r++] = HeadRow{8, 8, c, 0};
+    for (int c = 0; c < 12; ++c) g_rows[r++] = HeadRow{8, 9, c, 0};
+    g_row_begin[9] = r;
+    g_rows_init = true;
+}
+const HeadRow *head_rows() { init_rows(); return g_rows; }
+const int *head_row_begin() { init_rows(); return g_row_begin; }
+
+// AttnBN attention path (reference model/norm/attentive_norm.py:79-91,154-164), eval mode.
+// One 64-lane workgroup per (image, head); lane = channel.
+__global__ __launch_bounds__(64) void head_attn_kernel(const float *__restrict__ stats, int chunks, int HW,
+                                                        HeadAttnParams p, float *__restrict__ scale,
+                                                        float *__restrict__ shift) {
+    const int b = blockIdx.x, h = blockIdx.y, c = threadIdx.x;
+    const int CP = NUM_HEADS * HEAD_CH;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        const float *q = stats + (((size_t)b * chunks + k) * CP + h * HEAD_CH + c) * 2;
+        s1 += (double)q[0];
+        s2 += (double)q[1];
+    }
+    const double n = (double)HW;
+    const float rm = p.rm[h][c], rv = p.rv[h][c];
+    const double mean = (double)rm + s1 / n;
+    const double var = (s2 - s1 * s1 / n) / (n - 1.0);          // unbiased (torch.var_mean)
+    const float sstat = (float)(mean / sqrt(var + 1e-3));
+    __shared__ float y[NUM_AFFINE];
+    for (int k = 0; k < NUM_AFFINE; ++k) {
+        float v = sstat * p.att_w[h][k * HEAD_CH + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (c == 0) {
+            const float t = v * p.att_scale[h][k] + p.att_shift[h][k];
+            y[k] = fminf(fmaxf(t + 3.f, 0.f), 6.f) / 6.f;
+        }
+    }
+    __syncthreads();
+    float gam = 0.f, bet = 0.f;
+#pragma unroll
+    for (int k = 0; k < NUM_AFFINE; ++k) {
+        gam = fmaf(y[k], p.weight_[h][k * HEAD_CH + c], gam);
+        bet = fmaf(y[k], p.bias_[h][k * HEAD_CH + c], bet);
+    }
+    const float inv = 1.0f / sqrtf(rv + 1e-3f);
+    const float sc = gam * inv;
+    const size_t o = ((size_t)b * NUM_HEADS + h) * HEAD_CH + c;
+    scale[o] = sc;
+    shift[o] = bet - rm * sc;
+}
+hipError_t launch_head_attn(const float *stats, int B, int chunks, int HW, const HeadAttnParams &p, float *scale,
+                            float *shift, hipStream_t st) {
+    hipLaunchKernelGGL(head_attn_kernel, dim3(B, NUM_HEADS), dim3(64), 0, st, stats, chunks, HW, p, scale, shift);
+    return hipGetLastError();
+}
+
+// Second head pass: AttnBN apply + ReLU + 1x1 conv + output non-linearity, NCHW stores.
+// One wave per (64-pixel tile, head): the [64 px][64 ch] hidden block is normalised while being
+// staged into LDS, then lane = pixel accumulates the head's output rows against wave-uniform
+// weights.  (reference monocon_heads.py:114-120,165-200)
+struct HeadApplyDev {
+    HeadApplyArgs a;
+    HeadRow rows[NUM_OUT_ROWS];
+    int row_begin[NUM_HEADS + 1];
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int NR>
+__device__ __forceinline__ void head_rows_compute(const HeadApplyDev &d, const float *hl, int lane, int h, int rb,
+                                                  int b, int hw, bool ok) {
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+    const float *w = d.a.w + (size_t)rb * HEAD_CH;
+    for (int c = 0; c < HEAD_CH; ++c) {
+        const float v = hl[lane * 65 + c];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[r] = fmaf(v, w[r * HEAD_CH + c], acc[r]);
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const HeadRow row = d.rows[rb + r];
+        float v = acc[r] + d.a.b[rb + r];
+        if (row.epi == 1) {
+            v = fminf(fmaxf(sigmoidf_(v), 1e-4f), 1.0f - 1e-4f);
+        } else if (row.epi == 2) {
+            v = 1.0f / (sigmoidf_(v) + 1e-12f) - 1.0f;
+        }
+        d.a.pred[row.pred][((size_t)b * d.a.pred_c[row.pred] + row.ch) * d.a.HW + hw] = v;
+    }
+}
+
+__global__ __launch_bounds__(192) void head_apply_kernel(const HeadApplyDev d) {
+    __shared__ float hlds[3][64 * 65];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.y * 3 + wave;
+    const int tiles = (d.a.HW + 63) / 64;
+    const int b = blockIdx.x / tiles, hw0 = (blockIdx.x % tiles) * 64;
+    float *hl = hlds[wave];
+    // stage + normalise: 16 lanes cover one pixel's 64 channels (float4 each)
+    const int c4 = lane & 15;
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(d.a.scale + ((size_t)b * NUM_HEADS + h) * HEAD_CH + c4 * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4 *>(d.a.shift + ((size_t)b * NUM_HEADS + h) * HEAD_CH + c4 * 4);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int px = it * 4 + (lane >> 4);
+        const int hw = hw0 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (hw < d.a.HW)
+            v = *reinterpret_cast<const f32x4 *>(d.a.hidden + ((size_t)b * d.a.HW + hw) * (NUM_HEADS * HEAD_CH) +
+                                                 h * HEAD_CH + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hl[px * 65 + c4 * 4 + j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+    }
+    __syncthreads();
+    const int rb = d.row_begin[h], nr = d.row_begin[h + 1] - rb;
+    const int hw = hw0 + lane;
+    const bool ok = hw < d.a.HW;
+    switch (nr) {
+        case 2: head_rows_compute<2>(d, hl, lane, h, rb, b, hw, ok); break;
+        case 3: head_rows_compute<3>(d, hl, lane, h, rb, b, hw, ok); break;
+        case 9: head_rows_compute<9>(d, hl, lane, h, rb, b, hw, ok); break;
+        case 18: head_rows_compute<18>(d, hl, lane, h, rb, b, hw, ok); break;
+        case 24: head_rows_compute<24>(d, hl, lane, h, rb, b, hw, ok); break;
+        default: break;
+    }
+}
+
+hipError_t launch_head_apply(const HeadApplyArgs &a, hipStream_t st) {
+    init_rows();
+    HeadApplyDev d;
+    d.a = a;
+    for (int i = 0; i < NUM_OUT_ROWS; ++i) d.rows[i] = g_rows[i];
+    for (int i = 0; i <= NUM_HEADS; ++i) d.row_begin[i] = g_row_begin[i];
+    const int tiles = (a.HW + 63) / 64;
+    hipLaunchKernelGGL(head_apply_kernel, dim3(a.B * tiles, 3), dim3(192), 0, st, d);
+    return hipGetLastError();
+}
+
+}  // namespace mc

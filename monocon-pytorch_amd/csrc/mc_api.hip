@@ -1,0 +1,813 @@
+// C-ABI of libmonocon_hip.so (include/monocon_hip.h): handle, parameter binding/packing, the
+// DLA-34 -> DLAUp -> dense-head launch plan, decode and the op-level test entry points.
+//
+// The network is described once per handle as a table of layers keyed by the reference's
+// state_dict names; a launch plan (list of fully-resolved kernel launches + handle-owned NHWC
+// activation buffers) is built per input shape and replayed on the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/monocon_hip.h"
+#include "conv_mfma.h"
+#include "kernels.h"
+
+using namespace mc;
+
+namespace {
+
+struct Bound {
+    void *ptr;
+    int64_t numel;
+    int dtype;
+};
+
+struct Tensor {   // NHWC activation
+    float *p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t numel() const { return (size_t)B * H * W * C; }
+};
+
+struct ConvLayer {
+    std::string conv, bn;   // state_dict prefixes ("" bn => bias-only / raw)
+    int ks = 1, stride = 1, cin = 0, cout = 0, coutp = 0, ntile = 0;
+    float bn_eps = 1e-5f;
+    float *wpk = nullptr, *scale = nullptr, *shift = nullptr;
+};
+
+struct DeconvLayer {
+    std::string name;
+    int C = 0;
+    float *wpk = nullptr;
+};
+
+enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_DECONV, OP_HEAD_ATTN, OP_HEAD_APPLY, OP_TO_NCHW };
+
+struct Op {
+    OpKind kind;
+    // conv
+    ConvArgs ca{};
+    int ks = 0, stride = 0;
+    // generic
+    const float *in = nullptr;
+    float *out = nullptr;
+    const float *w = nullptr, *scale = nullptr, *shift = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    int chunks = 0;
+    HeadApplyArgs ha{};
+    double flops = 0, bytes = 0;
+};
+
+struct Plan {
+    int B = 0, H = 0, W = 0;
+    std::vector<Op> ops;
+    std::vector<void *> bufs;
+    size_t bytes = 0;
+    Tensor feat;
+    int stem_op = -1, head_apply_op = -1;
+    double flops = 0, hbm_bytes = 0;
+};
+
+}  // namespace
+
+struct mc_handle {
+    int device = 0;
+    std::string err;
+    std::unordered_map<std::string, Bound> bound;
+    std::map<std::string, ConvLayer> convs;
+    std::map<std::string, DeconvLayer> deconvs;
+    // stem
+    float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
+    // fused head 3x3 (64 -> 9*64) and second pass
+    ConvLayer head3;
+    float *head_bias = nullptr, *head_rm = nullptr;
+    float *att_scale = nullptr, *att_shift = nullptr;   // [9][10]
+    float *head_w1 = nullptr, *head_b1 = nullptr;       // [65][64], [65]
+    HeadAttnParams hap{};
+    bool layers_built = false, packed = false;
+    size_t param_bytes = 0;
+    std::vector<void *> param_bufs;
+    std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
+    Plan *last_plan = nullptr;
+    float *decode_filt = nullptr;
+    size_t decode_filt_n = 0;
+};
+
+static std::string g_create_err;
+
+static int fail(mc_handle *h, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return -1;
+}
+
+#define HIPCHK(h, expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static const char *HEAD_NAMES[NUM_HEADS] = {"heatmap_head", "wh_head", "offset_head", "center2kpt_offset_head",
+                                            "kpt_heatmap_head", "kpt_heatmap_offset_head", "dim_head", "depth_head",
+                                            "dir_feat"};
+static const int PRED_CH[MC_NUM_PREDS] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
+
+// ------------------------------------------------------------------------------ allocation
+static int dev_alloc(mc_handle *h, float **p, size_t nfloats, std::vector<void *> &track, size_t &acct) {
+    void *q = nullptr;
+    const size_t bytes = (nfloats == 0 ? 4 : nfloats) * sizeof(float);
+    HIPCHK(h, hipMalloc(&q, bytes));
+    HIPCHK(h, hipMemset(q, 0, bytes));
+    track.push_back(q);
+    acct += bytes;
+    *p = static_cast<float *>(q);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ layer table
+static void add_conv(mc_handle *h, const std::string &conv, const std::string &bn, int cin, int cout, int ks,
+                     int stride) {
+    ConvLayer L;
+    L.conv = conv; L.bn = bn; L.cin = cin; L.cout = cout; L.ks = ks; L.stride = stride;
+    L.coutp = conv_coutp(cout);
+    h->convs[conv] = L;
+}
+static void add_block(mc_handle *h, const std::string &n, int cin, int cout, int stride) {
+    add_conv(h, n + ".conv1", n + ".bn1", cin, cout, 3, stride);
+    add_conv(h, n + ".conv2", n + ".bn2", cout, cout, 3, 1);
+}
+static void add_tree(mc_handle *h, const std::string &n, int levels, int cin, int cout, int stride, bool level_root,
+                     int root_dim) {
+    if (root_dim == 0) root_dim = 2 * cout;
+    if (level_root) root_dim += cin;
+    if (levels == 1) {
+        add_block(h, n + ".tree1", cin, cout, stride);
+        add_block(h, n + ".tree2", cout, cout, 1);
+        add_conv(h, n + ".root.conv", n + ".root.bn", root_dim, cout, 1, 1);
+    } else {
+        add_tree(h, n + ".tree1", levels - 1, cin, cout, stride, false, 0);
+        add_tree(h, n + ".tree2", levels - 1, cout, cout, 1, false, root_dim + cout);
+    }
+    if (cin != cout) add_conv(h, n + ".project.0", n + ".project.1", cin, cout, 1, 1);
+}
+
+static int build_layers(mc_handle *h) {
+    if (h->layers_built) return 0;
+    add_conv(h, "backbone.level0.0", "backbone.level0.1", 16, 16, 3, 1);
+    add_conv(h, "backbone.level1.0", "backbone.level1.1", 16, 32, 3, 2);
+    add_tree(h, "backbone.level2", 1, 32, 64, 2, false, 0);
+    add_tree(h, "backbone.level3", 2, 64, 128, 2, true, 0);
+    add_tree(h, "backbone.level4", 2, 128, 256, 2, true, 0);
+    add_tree(h, "backbone.level5", 1, 256, 512, 2, true, 0);
+    int neck_in[4] = {64, 128, 256, 512};
+    for (int i = 0; i < 3; ++i) {
+        const int j = 4 - i - 2;   // first level of this IDA
+        const int out = neck_in[j];
+        for (int t = 1; t < 4 - j; ++t) {
+            const std::string pre = "neck.ida_" + std::to_string(i) + ".";
+            const std::string ts = std::to_string(t);
+            add_conv(h, pre + "proj_" + ts + ".conv", pre + "proj_" + ts + ".bn1", neck_in[j + t], out, 3, 1);
+            add_conv(h, pre + "node_" + ts + ".conv", pre + "node_" + ts + ".bn1", 2 * out, out, 3, 1);
+            DeconvLayer D;
+            D.name = pre + "up_" + ts;
+            D.C = out;
+            h->deconvs[D.name] = D;
+        }
+        for (int t = j + 1; t < 4; ++t) neck_in[t] = out;
+    }
+    for (auto &kv : h->convs) {
+        ConvLayer &L = kv.second;
+        const size_t wn = (size_t)L.ks * L.ks * L.cin * L.coutp;
+        if (dev_alloc(h, &L.wpk, wn, h->param_bufs, h->param_bytes)) return -1;
+        if (dev_alloc(h, &L.scale, L.cout, h->param_bufs, h->param_bytes)) return -1;
+        if (dev_alloc(h, &L.shift, L.cout, h->param_bufs, h->param_bytes)) return -1;
+    }
+    for (auto &kv : h->deconvs)
+        if (dev_alloc(h, &kv.second.wpk, (size_t)16 * kv.second.C, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->stem_w, 147 * 16, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->stem_scale, 16, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->stem_shift, 16, h->param_bufs, h->param_bytes)) return -1;
+    ConvLayer &H3 = h->head3;
+    H3.conv = "head.*.0"; H3.ks = 3; H3.stride = 1; H3.cin = 64; H3.cout = NUM_HEADS * HEAD_CH;
+    H3.ntile = 64;             // one head per 64-column tile
+    H3.coutp = H3.cout;
+    if (dev_alloc(h, &H3.wpk, (size_t)9 * 64 * H3.coutp, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->head_bias, H3.cout, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->head_rm, H3.cout, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->att_scale, NUM_HEADS * NUM_AFFINE, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->att_shift, NUM_HEADS * NUM_AFFINE, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->head_w1, NUM_OUT_ROWS * HEAD_CH, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->head_b1, NUM_OUT_ROWS, h->param_bufs, h->param_bytes)) return -1;
+    HIPCHK(h, hipDeviceSynchronize());   // zero-fills above ran on the null stream
+    h->layers_built = true;
+    return 0;
+}
+
+static float *P(mc_handle *h, const std::string &name, int64_t expect_numel = -1) {
+    auto it = h->bound.find(name);
+    if (it == h->bound.end()) {
+        h->err = "parameter not bound: " + name;
+        return nullptr;
+    }
+    if (it->second.dtype != MC_F32) {
+        h->err = "parameter is not fp32: " + name;
+        return nullptr;
+    }
+    if (expect_numel >= 0 && it->second.numel != expect_numel) {
+        h->err = "parameter has wrong size: " + name;
+        return nullptr;
+    }
+    return static_cast<float *>(it->second.ptr);
+}
+
+// ------------------------------------------------------------------------------ plan builder
+namespace {
+struct Builder {
+    mc_handle *h;
+    Plan *pl;
+    bool ok = true;
+    std::map<const float *, Tensor> pooled;   // max-pool de-duplication (nested trees re-pool the same input)
+
+    Tensor alloc(int B, int H, int W, int C) {
+        Tensor t;
+        t.B = B; t.H = H; t.W = W; t.C = C;
+        if (dev_alloc(h, &t.p, t.numel(), pl->bufs, pl->bytes)) ok = false;
+        return t;
+    }
+    float *alloc_raw(size_t n) {
+        float *p = nullptr;
+        if (dev_alloc(h, &p, n, pl->bufs, pl->bytes)) ok = false;
+        return p;
+    }
+
+    Tensor conv(const ConvLayer &L, const std::vector<Tensor> &srcs, const Tensor *res, bool relu,
+                Tensor *into = nullptr, const float *scale = nullptr, const float *shift = nullptr,
+                bool use_layer_affine = true, float **stats_out = nullptr, const float *stat_shift = nullptr,
+                int *chunks_out = nullptr) {
+        const Tensor &s0 = srcs[0];
+        const int Ho = (s0.H + 2 * (L.ks / 2) - L.ks) / L.stride + 1;
+        const int Wo = (s0.W + 2 * (L.ks / 2) - L.ks) / L.stride + 1;
+        Tensor out = into ? *into : alloc(s0.B, Ho, Wo, L.cout);
+        Op op{};
+        op.kind = OP_CONV;
+        op.ks = L.ks; op.stride = L.stride;
+        ConvArgs &a = op.ca;
+        a.nsrc = (int)srcs.size();
+        int cin = 0;
+        double in_elems = 0;
+        for (int i = 0; i < a.nsrc; ++i) {
+            a.src[i].p = srcs[i].p;
+            a.src[i].C = srcs[i].C;
+            cin += srcs[i].C;
+            in_elems += (double)srcs[i].numel();
+        }
+        if (cin != L.cin) { ok = false; h->err = "channel mismatch at " + L.conv; }
+        a.B = s0.B; a.Hin = s0.H; a.Win = s0.W; a.Hout = Ho; a.Wout = Wo;
+        a.Cin = cin; a.Cout = L.cout; a.CoutP = L.coutp;
+        a.wpk = L.wpk;
+        a.scale = use_layer_affine ? L.scale : scale;
+        a.bias = use_layer_affine ? L.shift : shift;
+        a.res = res ? res->p : nullptr;
+        a.res_ld = res ? res->C : 0;
+        a.out = out.p; a.out_ld = out.C; a.out_coff = 0;
+        a.relu = relu ? 1 : 0;
+        const int ppr = (Wo + 7) / 8, ppi = ppr * ((Ho + 3) / 4);
+        a.ntile = L.ntile;
+        const int pb = (L.ntile ? L.ntile : conv_ntile(L.cout)) == 128 ? 4 : 8;
+        const int chunks = (ppi + pb - 1) / pb;
+        if (stats_out) {
+            *stats_out = alloc_raw((size_t)s0.B * chunks * L.coutp * 2);
+            a.stats = *stats_out;
+            a.stat_shift = stat_shift;
+        }
+        if (chunks_out) *chunks_out = chunks;
+        op.flops = 2.0 * s0.B * Ho * Wo * (double)L.cout * cin * L.ks * L.ks;
+        op.bytes = 4.0 * (in_elems + (double)s0.B * Ho * Wo * L.cout * (res ? 2 : 1));
+        pl->ops.push_back(op);
+        return out;
+    }
+
+    Tensor pool(const Tensor &x) {
+        auto it = pooled.find(x.p);
+        if (it != pooled.end()) return it->second;
+        Tensor o = alloc(x.B, x.H / 2, x.W / 2, x.C);
+        Op op{};
+        op.kind = OP_POOL;
+        op.in = x.p; op.out = o.p; op.B = x.B; op.H = x.H; op.W = x.W; op.C = x.C;
+        op.bytes = 4.0 * ((double)x.numel() + (double)o.numel());
+        pl->ops.push_back(op);
+        pooled[x.p] = o;
+        return o;
+    }
+
+    Tensor deconv(const DeconvLayer &D, const Tensor &x) {
+        Tensor o = alloc(x.B, x.H * 2, x.W * 2, x.C);
+        Op op{};
+        op.kind = OP_DECONV;
+        op.in = x.p; op.out = o.p; op.w = D.wpk; op.B = x.B; op.H = x.H; op.W = x.W; op.C = x.C;
+        op.flops = 2.0 * 4.0 * (double)o.numel();
+        op.bytes = 4.0 * ((double)x.numel() + (double)o.numel());
+        pl->ops.push_back(op);
+        return o;
+    }
+
+    const ConvLayer &L(const std::string &n) {
+        auto it = h->convs.find(n);
+        if (it == h->convs.end()) { ok = false; h->err = "no layer " + n; static ConvLayer d; return d; }
+        return it->second;
+    }
+
+    Tensor block(const std::string &n, const Tensor &x, const Tensor *residual) {
+        // reference model/backbone/dla.py:34-51
+        Tensor y = conv(L(n + ".conv1"), {x}, nullptr, true);
+        const Tensor &r = residual ? *residual : x;
+        return conv(L(n + ".conv2"), {y}, &r, true);
+    }
+
+    Tensor tree(const std::string &n, int levels, int cin, int cout, int stride, bool level_root, const Tensor &x,
+                std::vector<Tensor> children) {
+        // reference model/backbone/dla.py:187-205.  In eval mode the outer `project` of a two-level
+        // tree is dead (the nested tree recomputes its own residual, dla.py:193-194) and is skipped.
+        Tensor bottom = stride > 1 ? pool(x) : x;
+        if (level_root) children.push_back(bottom);
+        if (levels == 1) {
+            Tensor residual = bottom;
+            if (cin != cout) residual = conv(L(n + ".project.0"), {bottom}, nullptr, false);
+            Tensor x1 = block(n + ".tree1", x, &residual);
+            Tensor x2 = block(n + ".tree2", x1, nullptr);
+            std::vector<Tensor> cat = {x2, x1};
+            for (auto &c : children) cat.push_back(c);
+            return conv(L(n + ".root.conv"), cat, nullptr, true);
+        }
+        Tensor x1 = tree(n + ".tree1", levels - 1, cin, cout, stride, false, x, {});
+        children.push_back(x1);
+        return tree(n + ".tree2", levels - 1, cout, cout, 1, false, x1, children);
+    }
+};
+}  // namespace
+
+static Plan *get_plan(mc_handle *h, int B, int H, int W) {
+    auto key = std::make_tuple(B, H, W);
+    auto it = h->plans.find(key);
+    if (it != h->plans.end()) return it->second.get();
+    std::unique_ptr<Plan> pl(new Plan());
+    pl->B = B; pl->H = H; pl->W = W;
+    Builder bd{h, pl.get()};
+
+    // stem: NCHW image -> NHWC 16ch (reference dla.py:231-234)
+    Tensor x0 = bd.alloc(B, H, W, 16);
+    {
+        Op op{};
+        op.kind = OP_STEM;
+        op.out = x0.p; op.B = B; op.H = H; op.W = W;
+        op.w = h->stem_w; op.scale = h->stem_scale; op.shift = h->stem_shift;
+        op.flops = 2.0 * B * H * W * 16.0 * 147.0;
+        op.bytes = 4.0 * ((double)B * 3 * H * W + (double)x0.numel());
+        pl->stem_op = (int)pl->ops.size();
+        pl->ops.push_back(op);
+    }
+    Tensor l0 = bd.conv(bd.L("backbone.level0.0"), {x0}, nullptr, true);
+    Tensor l1 = bd.conv(bd.L("backbone.level1.0"), {l0}, nullptr, true);
+    Tensor l2 = bd.tree("backbone.level2", 1, 32, 64, 2, false, l1, {});
+    Tensor l3 = bd.tree("backbone.level3", 2, 64, 128, 2, true, l2, {});
+    Tensor l4 = bd.tree("backbone.level4", 2, 128, 256, 2, true, l3, {});
+    Tensor l5 = bd.tree("backbone.level5", 1, 256, 512, 2, true, l4, {});
+
+    // DLAUp (reference dla_neck.py:94-106,136-143): layers = [l2,l3,l4,l5]
+    std::vector<Tensor> layers = {l2, l3, l4, l5};
+    for (int i = 0; i < 3; ++i) {
+        const int j = 4 - i - 2;
+        for (int t = 1; t < 4 - j; ++t) {
+            const std::string pre = "neck.ida_" + std::to_string(i) + ".";
+            const std::string ts = std::to_string(t);
+            Tensor p = bd.conv(bd.L(pre + "proj_" + ts + ".conv"), {layers[j + t]}, nullptr, true);
+            Tensor u = bd.deconv(h->deconvs[pre + "up_" + ts], p);
+            layers[j + t] = bd.conv(bd.L(pre + "node_" + ts + ".conv"), {layers[j + t - 1], u}, nullptr, true);
+        }
+    }
+    Tensor feat = layers[3];
+    pl->feat = feat;
+
+    // heads pass 1: fused 3x3 64 -> 9x64 (+bias) with per-(image,channel) statistics
+    float *stats = nullptr;
+    int chunks = 0;
+    Tensor hidden = bd.conv(h->head3, {feat}, nullptr, false, nullptr, nullptr, h->head_bias, false, &stats,
+                            h->head_rm, &chunks);
+    float *hs_scale = bd.alloc_raw((size_t)B * NUM_HEADS * HEAD_CH);
+    float *hs_shift = bd.alloc_raw((size_t)B * NUM_HEADS * HEAD_CH);
+    {
+        Op op{};
+        op.kind = OP_HEAD_ATTN;
+        op.in = stats; op.B = B; op.chunks = chunks; op.H = feat.H; op.W = feat.W;
+        op.out = hs_scale; op.shift = hs_shift;
+        pl->ops.push_back(op);
+    }
+    {
+        Op op{};
+        op.kind = OP_HEAD_APPLY;
+        HeadApplyArgs &a = op.ha;
+        a.hidden = hidden.p; a.scale = hs_scale; a.shift = hs_shift;
+        a.w = h->head_w1; a.b = h->head_b1;
+        a.B = B; a.HW = feat.H * feat.W;
+        for (int i = 0; i < MC_NUM_PREDS; ++i) a.pred_c[i] = PRED_CH[i];
+        op.flops = 2.0 * B * a.HW * 64.0 * NUM_OUT_ROWS;
+        op.bytes = 4.0 * ((double)hidden.numel() + (double)B * a.HW * NUM_OUT_ROWS);
+        pl->head_apply_op = (int)pl->ops.size();
+        pl->ops.push_back(op);
+    }
+    if (!bd.ok) {
+        for (void *q : pl->bufs) (void)hipFree(q);
+        return nullptr;
+    }
+    for (auto &op : pl->ops) {
+        pl->flops += op.flops;
+        pl->hbm_bytes += op.bytes;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;   // buffer zero-fills ran on the null stream
+    Plan *ret = pl.get();
+    h->plans[key] = std::move(pl);
+    return ret;
+}
+
+static int run_op(mc_handle *h, const Op &op, hipStream_t st) {
+    switch (op.kind) {
+        case OP_STEM:
+            HIPCHK(h, launch_stem(op.in, op.B, op.H, op.W, op.w, op.scale, op.shift, op.out, st));
+            break;
+        case OP_CONV:
+            HIPCHK(h, launch_conv(op.ca, op.ks, op.stride, st));
+            break;
+        case OP_POOL:
+            HIPCHK(h, launch_maxpool2(op.in, op.B, op.H, op.W, op.C, op.out, st));
+            break;
+        case OP_DECONV:
+            HIPCHK(h, launch_deconv4(op.in, op.B, op.H, op.W, op.C, op.w, op.out, st));
+            break;
+        case OP_HEAD_ATTN:
+            HIPCHK(h, launch_head_attn(op.in, op.B, op.chunks, op.H * op.W, h->hap, op.out,
+                                       const_cast<float *>(op.shift), st));
+            break;
+        case OP_HEAD_APPLY:
+            HIPCHK(h, launch_head_apply(op.ha, st));
+            break;
+        case OP_TO_NCHW:
+            HIPCHK(h, launch_nhwc_to_nchw(op.in, op.B, op.C, op.H, op.W, op.out, st));
+            break;
+    }
+    return 0;
+}
+
+// ================================================================================== C ABI
+extern "C" {
+
+int mc_version(void) { return 1; }
+
+int mc_create(int device, mc_handle **out) {
+    if (!out) return fail(nullptr, "mc_create: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, "mc_create: no HIP device visible (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, "mc_create: device %d out of range (%d visible)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, "mc_create: device is %s; this library is built for gfx950 only", prop.gcnArchName);
+    mc_handle *h = new mc_handle();
+    h->device = device;
+    *out = h;
+    return 0;
+}
+
+int mc_destroy(mc_handle *h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    for (auto &kv : h->plans)
+        for (void *q : kv.second->bufs) (void)hipFree(q);
+    for (void *q : h->param_bufs) (void)hipFree(q);
+    if (h->decode_filt) (void)hipFree(h->decode_filt);
+    delete h;
+    return 0;
+}
+
+const char *mc_last_error(mc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int mc_bind_params(mc_handle *h, const mc_tensor_desc *descs, int n) {
+    if (!h || !descs) return fail(h, "mc_bind_params: null argument");
+    for (int i = 0; i < n; ++i) {
+        if (!descs[i].name || !descs[i].ptr) return fail(h, "mc_bind_params: entry %d has a null name/pointer", i);
+        h->bound[descs[i].name] = Bound{descs[i].ptr, descs[i].numel, descs[i].dtype};
+    }
+    h->packed = false;
+    return 0;
+}
+
+int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
+    if (!h) return -1;
+    if (train_mode != 0) return fail(h, "mc_pack_params: train_mode=%d not available in this build", train_mode);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (build_layers(h)) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NEEDP(var, name, numel)                    \
+    float *var = P(h, (name), (numel));            \
+    if (!var) return -1;
+    for (auto &kv : h->convs) {
+        ConvLayer &L = kv.second;
+        NEEDP(w, L.conv + ".weight", (int64_t)L.cout * L.cin * L.ks * L.ks);
+        HIPCHK(h, launch_pack_conv_w(w, L.cout, L.cin, L.ks, L.wpk, L.cin, L.coutp, 0, 0, st));
+        NEEDP(g, L.bn + ".weight", L.cout);
+        NEEDP(b, L.bn + ".bias", L.cout);
+        NEEDP(rm, L.bn + ".running_mean", L.cout);
+        NEEDP(rv, L.bn + ".running_var", L.cout);
+        HIPCHK(h, launch_fold_bn(g, b, rm, rv, 1e-5f, L.cout, L.scale, L.shift, st));
+    }
+    for (auto &kv : h->deconvs) {
+        NEEDP(w, kv.second.name + ".weight", (int64_t)kv.second.C * 16);
+        HIPCHK(h, launch_pack_deconv_w(w, kv.second.C, kv.second.wpk, st));
+    }
+    {
+        NEEDP(w, "backbone.base_layer.0.weight", 16 * 147);
+        HIPCHK(h, launch_pack_stem_w(w, h->stem_w, st));
+        NEEDP(g, "backbone.base_layer.1.weight", 16);
+        NEEDP(b, "backbone.base_layer.1.bias", 16);
+        NEEDP(rm, "backbone.base_layer.1.running_mean", 16);
+        NEEDP(rv, "backbone.base_layer.1.running_var", 16);
+        HIPCHK(h, launch_fold_bn(g, b, rm, rv, 1e-5f, 16, h->stem_scale, h->stem_shift, st));
+    }
+    // heads
+    const HeadRow *rows = head_rows();
+    const int *rb = head_row_begin();
+    (void)rows;
+    for (int hd = 0; hd < NUM_HEADS; ++hd) {
+        const std::string pre = std::string("head.") + HEAD_NAMES[hd];
+        NEEDP(w3, pre + ".0.weight", 64 * 64 * 9);
+        NEEDP(b3, pre + ".0.bias", 64);
+        HIPCHK(h, launch_pack_conv_w(w3, 64, 64, 3, h->head3.wpk, 64, h->head3.coutp, hd * HEAD_CH, 0, st));
+        HIPCHK(h, launch_copy(b3, h->head_bias + hd * HEAD_CH, 64, st));
+        const std::string an = pre + ".1";
+        NEEDP(rm, an + ".running_mean", 64);
+        NEEDP(rv, an + ".running_var", 64);
+        HIPCHK(h, launch_copy(rm, h->head_rm + hd * HEAD_CH, 64, st));
+        NEEDP(wg, an + ".weight_", 640);
+        NEEDP(wb, an + ".bias_", 640);
+        NEEDP(aw, an + ".attn_weights.attention.0.weight", 640);
+        NEEDP(ag, an + ".attn_weights.attention.1.weight", 10);
+        NEEDP(ab, an + ".attn_weights.attention.1.bias", 10);
+        NEEDP(arm, an + ".attn_weights.attention.1.running_mean", 10);
+        NEEDP(arv, an + ".attn_weights.attention.1.running_var", 10);
+        HIPCHK(h, launch_fold_bn(ag, ab, arm, arv, 1e-5f, 10, h->att_scale + hd * NUM_AFFINE,
+                                 h->att_shift + hd * NUM_AFFINE, st));
+        h->hap.att_w[hd] = aw;
+        h->hap.att_scale[hd] = h->att_scale + hd * NUM_AFFINE;
+        h->hap.att_shift[hd] = h->att_shift + hd * NUM_AFFINE;
+        h->hap.weight_[hd] = wg;
+        h->hap.bias_[hd] = wb;
+        h->hap.rm[hd] = rm;
+        h->hap.rv[hd] = rv;
+        if (hd < 8) {
+            const int nr = rb[hd + 1] - rb[hd];
+            NEEDP(w1, pre + ".3.weight", (int64_t)nr * 64);
+            NEEDP(b1, pre + ".3.bias", nr);
+            HIPCHK(h, launch_copy(w1, h->head_w1 + (size_t)rb[hd] * HEAD_CH, (size_t)nr * 64, st));
+            HIPCHK(h, launch_copy(b1, h->head_b1 + rb[hd], nr, st));
+        } else {
+            NEEDP(wc, "head.dir_cls.0.weight", 12 * 64);
+            NEEDP(bc, "head.dir_cls.0.bias", 12);
+            NEEDP(wr, "head.dir_reg.0.weight", 12 * 64);
+            NEEDP(br, "head.dir_reg.0.bias", 12);
+            HIPCHK(h, launch_copy(wc, h->head_w1 + (size_t)rb[8] * HEAD_CH, 12 * 64, st));
+            HIPCHK(h, launch_copy(wr, h->head_w1 + (size_t)(rb[8] + 12) * HEAD_CH, 12 * 64, st));
+            HIPCHK(h, launch_copy(bc, h->head_b1 + rb[8], 12, st));
+            HIPCHK(h, launch_copy(br, h->head_b1 + rb[8] + 12, 12, st));
+        }
+    }
+#undef NEEDP
+    h->packed = true;
+    return 0;
+}
+
+int mc_forward_infer(mc_handle *h, const float *img, int B, int H, int W, float *const preds[MC_NUM_PREDS],
+                     float *feat_nchw, void *stream) {
+    if (!h) return -1;
+    if (!img || !preds) return fail(h, "mc_forward_infer: null argument");
+    if (B < 1 || H < 32 || W < 32 || (H % 32) || (W % 32))
+        return fail(h, "mc_forward_infer: bad shape B=%d H=%d W=%d (H, W must be multiples of 32)", B, H, W);
+    if (!h->packed) return fail(h, "mc_forward_infer: call mc_bind_params + mc_pack_params first");
+    HIPCHK(h, hipSetDevice(h->device));
+    Plan *pl = get_plan(h, B, H, W);
+    if (!pl) return -1;
+    h->last_plan = pl;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    pl->ops[pl->stem_op].in = img;
+    for (int i = 0; i < MC_NUM_PREDS; ++i) {
+        if (!preds[i]) return fail(h, "mc_forward_infer: preds[%d] is NULL", i);
+        pl->ops[pl->head_apply_op].ha.pred[i] = preds[i];
+    }
+    for (const Op &op : pl->ops)
+        if (run_op(h, op, st)) return -1;
+    if (feat_nchw) HIPCHK(h, launch_nhwc_to_nchw(pl->feat.p, B, pl->feat.C, pl->feat.H, pl->feat.W, feat_nchw, st));
+    return 0;
+}
+
+int mc_decode(mc_handle *h, const float *const preds[MC_NUM_PREDS], const float *P2, const float *P2inv, int B, int C,
+              int H, int W, int K, float thr, float pad_h, float pad_w, float *scores, int64_t *flat_index,
+              int64_t *cls, float *box2d, float *box3d, uint8_t *keep_localmax, uint8_t *keep_thr, void *stream) {
+    if (!h) return -1;
+    if (!preds || !P2 || !P2inv || !scores || !flat_index || !cls || !box2d || !box3d)
+        return fail(h, "mc_decode: null argument");
+    const int need[] = {0, 2, 3, 5, 6, 7, 8, 9};
+    for (int i : need)
+        if (!preds[i]) return fail(h, "mc_decode: preds[%d] is NULL", i);
+    if (B < 1 || C < 1 || H < 1 || W < 1 || K < 1 || K > 1024 || (int64_t)K > (int64_t)C * H * W)
+        return fail(h, "mc_decode: bad shape B=%d C=%d H=%d W=%d K=%d (1 <= K <= min(1024, C*H*W))", B, C, H, W, K);
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)B * C * H * W;
+    if (n > h->decode_filt_n) {
+        if (h->decode_filt) HIPCHK(h, hipFree(h->decode_filt));
+        h->decode_filt = nullptr;
+        h->decode_filt_n = 0;
+        void *q = nullptr;
+        HIPCHK(h, hipMalloc(&q, n * sizeof(float)));
+        h->decode_filt = static_cast<float *>(q);
+        h->decode_filt_n = n;
+    }
+    DecodeArgs a{};
+    for (int i = 0; i < MC_NUM_PREDS; ++i) a.pred[i] = preds[i];
+    a.P2 = P2; a.P2inv = P2inv;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.K = K;
+    a.thr = thr; a.pad_h = pad_h; a.pad_w = pad_w;
+    a.scores = scores; a.flat_index = flat_index; a.cls = cls;
+    a.box2d = box2d; a.box3d = box3d;
+    a.keep_localmax = keep_localmax; a.keep_thr = keep_thr;
+    a.filt = h->decode_filt;
+    HIPCHK(h, launch_decode(a, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- op-level
+int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[], int nsrc, int B, int Hin, int Win,
+               const float *weight_oihw, int Cout, int ksize, int stride, const float *scale, const float *bias,
+               const float *residual, int relu, float *out, void *stream) {
+    if (!h) return -1;
+    if (!src || !src_channels || !weight_oihw || !out) return fail(h, "mc_op_conv: null argument");
+    if (nsrc < 1 || nsrc > 4) return fail(h, "mc_op_conv: nsrc=%d (1..4)", nsrc);
+    if (!((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1)))
+        return fail(h, "mc_op_conv: unsupported k=%d stride=%d", ksize, stride);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ConvArgs a{};
+    int cin = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!src[i] || src_channels[i] % 16) return fail(h, "mc_op_conv: source %d needs C %% 16 == 0", i);
+        a.src[i].p = src[i];
+        a.src[i].C = src_channels[i];
+        cin += src_channels[i];
+    }
+    a.nsrc = nsrc;
+    a.B = B; a.Hin = Hin; a.Win = Win;
+    a.Hout = (Hin + 2 * (ksize / 2) - ksize) / stride + 1;
+    a.Wout = (Win + 2 * (ksize / 2) - ksize) / stride + 1;
+    a.Cin = cin; a.Cout = Cout; a.CoutP = conv_coutp(Cout);
+    const size_t wn = (size_t)ksize * ksize * cin * a.CoutP;
+    void *wpk = nullptr;
+    HIPCHK(h, hipMalloc(&wpk, wn * sizeof(float)));
+    HIPCHK(h, hipMemsetAsync(wpk, 0, wn * sizeof(float), st));
+    HIPCHK(h, launch_pack_conv_w(weight_oihw, Cout, cin, ksize, static_cast<float *>(wpk), cin, a.CoutP, 0, 0, st));
+    a.wpk = static_cast<float *>(wpk);
+    a.scale = scale; a.bias = bias; a.res = residual; a.res_ld = Cout;
+    a.out = out; a.out_ld = Cout; a.out_coff = 0; a.relu = relu;
+    hipError_t e = launch_conv(a, ksize, stride, st);
+    hipError_t e2 = hipStreamSynchronize(st);   // test entry point: weights are a temporary
+    (void)hipFree(wpk);
+    HIPCHK(h, e);
+    HIPCHK(h, e2);
+    return 0;
+}
+
+int mc_op_stem(mc_handle *h, const float *img, int B, int H, int W, const float *weight_oihw, const float *scale,
+               const float *bias, float *out, void *stream) {
+    if (!h) return -1;
+    if (!img || !weight_oihw || !scale || !bias || !out) return fail(h, "mc_op_stem: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    void *wpk = nullptr;
+    HIPCHK(h, hipMalloc(&wpk, 147 * 16 * sizeof(float)));
+    HIPCHK(h, launch_pack_stem_w(weight_oihw, static_cast<float *>(wpk), st));
+    hipError_t e = launch_stem(img, B, H, W, static_cast<float *>(wpk), scale, bias, out, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(wpk);
+    HIPCHK(h, e);
+    HIPCHK(h, e2);
+    return 0;
+}
+
+int mc_op_maxpool2(mc_handle *h, const float *in, int B, int H, int W, int C, float *out, void *stream) {
+    if (!h) return -1;
+    if (!in || !out || (C % 4) || (H % 2) || (W % 2)) return fail(h, "mc_op_maxpool2: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_maxpool2(in, B, H, W, C, out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int mc_op_deconv4x4(mc_handle *h, const float *in, int B, int H, int W, int C, const float *weight, float *out,
+                    void *stream) {
+    if (!h) return -1;
+    if (!in || !out || !weight || (C % 4)) return fail(h, "mc_op_deconv4x4: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    void *wpk = nullptr;
+    HIPCHK(h, hipMalloc(&wpk, (size_t)16 * C * sizeof(float)));
+    HIPCHK(h, launch_pack_deconv_w(weight, C, static_cast<float *>(wpk), st));
+    hipError_t e = launch_deconv4(in, B, H, W, C, static_cast<float *>(wpk), out, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(wpk);
+    HIPCHK(h, e);
+    HIPCHK(h, e2);
+    return 0;
+}
+
+int mc_op_nchw_to_nhwc(mc_handle *h, const float *in, int B, int C, int H, int W, float *out, void *stream) {
+    if (!h) return -1;
+    if (!in || !out) return fail(h, "mc_op_nchw_to_nhwc: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_nchw_to_nhwc(in, B, C, H, W, out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W, float *out, void *stream) {
+    if (!h) return -1;
+    if (!in || !out) return fail(h, "mc_op_nhwc_to_nchw: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_nhwc_to_nchw(in, B, C, H, W, out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------- introspection
+size_t mc_workspace_bytes(mc_handle *h) {
+    if (!h) return 0;
+    size_t n = h->param_bytes + h->decode_filt_n * sizeof(float);
+    for (auto &kv : h->plans) n += kv.second->bytes;
+    return n;
+}
+
+int mc_forward_cost(mc_handle *h, int B, int H, int W, double *flops, double *bytes) {
+    if (!h) return -1;
+    if (!h->packed) return fail(h, "mc_forward_cost: pack parameters first");
+    HIPCHK(h, hipSetDevice(h->device));
+    Plan *pl = get_plan(h, B, H, W);
+    if (!pl) return -1;
+    if (flops) *flops = pl->flops;
+    if (bytes) *bytes = pl->hbm_bytes;
+    return 0;
+}
+
+int mc_profile_forward(mc_handle *h, int iters, float out_ms[3], int out_n[3], void *stream) {
+    if (!h) return -1;
+    Plan *pl = h->last_plan;
+    if (!pl) return fail(h, "mc_profile_forward: run mc_forward_infer first");
+    if (iters < 1) iters = 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t nops = pl->ops.size();
+    std::vector<hipEvent_t> ev(nops + 1);
+    for (auto &e : ev) HIPCHK(h, hipEventCreate(&e));
+    double acc_conv = 0, acc_other = 0, acc_all = 0;
+    int n_conv = 0, n_other = 0;
+    for (int it = 0; it < iters; ++it) {
+        HIPCHK(h, hipEventRecord(ev[0], st));
+        for (size_t i = 0; i < nops; ++i) {
+            if (run_op(h, pl->ops[i], st)) return -1;
+            HIPCHK(h, hipEventRecord(ev[i + 1], st));
+        }
+        HIPCHK(h, hipEventSynchronize(ev[nops]));
+        n_conv = n_other = 0;
+        for (size_t i = 0; i < nops; ++i) {
+            float ms = 0;
+            HIPCHK(h, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            if (pl->ops[i].kind == OP_CONV) { acc_conv += ms; ++n_conv; } else { acc_other += ms; ++n_other; }
+        }
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, ev[0], ev[nops]));
+        acc_all += ms;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    if (out_ms) { out_ms[0] = (float)(acc_conv / iters); out_ms[1] = (float)(acc_other / iters); out_ms[2] = (float)(acc_all / iters); }
+    if (out_n) { out_n[0] = n_conv; out_n[1] = n_other; out_n[2] = (int)nops; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,221 @@
+"""Host-side wrapper of one libmonocon_hip handle: binds a torch ``state_dict``, keeps the
+packed device copies coherent with the master parameters, and exposes the forward /
+decode / op-level calls on torch tensors (raw ``data_ptr()`` + current HIP stream).
+
+PyTorch is plumbing here (device memory, streams); every device computation is a
+kernel of libmonocon_hip.so.  No CPU path exists: a non-CUDA tensor raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import netspec
+
+PRED_KEYS = tuple(k for k, _ in netspec.PRED_KEYS)
+PRED_CH = tuple(c for _, c in netspec.PRED_KEYS)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_cuda(t, what):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise _lib.MonoconHipError("%s must be a CUDA(HIP) tensor; libmonocon_hip has no CPU path" % what)
+    if not t.is_contiguous():
+        raise _lib.MonoconHipError("%s must be contiguous" % what)
+    return t
+
+
+class Engine:
+    """One handle per process per GPU (SURVEY §8b threading rules)."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.MonoconHipError("no HIP device visible; libmonocon_hip has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        h = C.c_void_p()
+        rc = self.lib.mc_create(self.device.index, C.byref(h))
+        _lib.check(None, rc, "mc_create")
+        self.h = h
+        self._sig = None
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def bind_state(self, state):
+        """Bind (and pack) a name -> CUDA tensor mapping with the reference's 449 keys.
+        Re-binds only when a pointer changed, re-packs only when a tensor's ``_version``
+        changed (optimizer step, load_state_dict, ...)."""
+        ptr_sig = tuple(v.data_ptr() for v in state.values())
+        ver_sig = tuple(v._version for v in state.values())
+        if self._sig is not None and self._sig == (ptr_sig, ver_sig):
+            return
+        if self._sig is None or self._sig[0] != ptr_sig:
+            descs = (_lib.TensorDesc * len(state))()
+            names = []
+            for i, (k, v) in enumerate(state.items()):
+                _need_cuda(v, k)
+                if v.dtype == torch.float32:
+                    dt = _lib.MC_F32
+                elif v.dtype == torch.int64:
+                    dt = _lib.MC_I64
+                else:
+                    raise _lib.MonoconHipError("%s: unsupported dtype %s" % (k, v.dtype))
+                names.append(k.encode())
+                descs[i] = _lib.TensorDesc(names[-1], v.data_ptr(), v.numel(), dt)
+            _lib.check(self.h, self.lib.mc_bind_params(self.h, descs, len(state)), "mc_bind_params")
+            self._keep = (state, names)
+        with torch.cuda.device(self.device):
+            _lib.check(self.h, self.lib.mc_pack_params(self.h, 0, _stream()), "mc_pack_params")
+        self._sig = (ptr_sig, ver_sig)
+
+    # ------------------------------------------------------------------ forward
+    def forward_infer(self, img, want_feat=False):
+        """(B,3,H,W) fp32 NCHW -> OrderedDict of the ten NCHW prediction maps."""
+        _need_cuda(img, "img")
+        if img.dtype != torch.float32 or img.dim() != 4 or img.shape[1] != 3:
+            raise _lib.MonoconHipError("img must be (B,3,H,W) float32")
+        B, _, H, W = img.shape
+        fh, fw = H // 4, W // 4
+        preds = [torch.empty((B, c, fh, fw), dtype=torch.float32, device=img.device) for c in PRED_CH]
+        feat = torch.empty((B, 64, fh, fw), dtype=torch.float32, device=img.device) if want_feat else None
+        arr = (C.c_void_p * _lib.NUM_PREDS)(*[p.data_ptr() for p in preds])
+        with torch.cuda.device(img.device):
+            rc = self.lib.mc_forward_infer(self.h, _ptr(img), B, H, W, arr, _ptr(feat), _stream())
+        _lib.check(self.h, rc, "mc_forward_infer")
+        out = dict(zip(PRED_KEYS, preds))
+        return (out, feat) if want_feat else out
+
+    def forward_cost(self, B, H, W):
+        fl, by = C.c_double(), C.c_double()
+        _lib.check(self.h, self.lib.mc_forward_cost(self.h, B, H, W, C.byref(fl), C.byref(by)), "mc_forward_cost")
+        return fl.value, by.value
+
+    def profile_forward(self, iters=3):
+        ms = (C.c_float * 3)()
+        n = (C.c_int * 3)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.h, self.lib.mc_profile_forward(self.h, iters, ms, n, _stream()), "mc_profile_forward")
+        return {"conv_ms": ms[0], "other_ms": ms[1], "total_ms": ms[2],
+                "n_conv": n[0], "n_other": n[1], "n_ops": n[2]}
+
+    def workspace_bytes(self):
+        return int(self.lib.mc_workspace_bytes(self.h))
+
+    # ------------------------------------------------------------------ decode
+    def decode(self, pred, P2, P2inv, pad_hw, topk, thres, want_keep=False):
+        """Dense decode.  pred: dict of NCHW CUDA maps; P2 (B,3,4), P2inv (B,4,4) CUDA fp32."""
+        heat = _need_cuda(pred["center_heatmap_pred"], "center_heatmap_pred")
+        B, Cc, H, W = heat.shape
+        dev = heat.device
+        arr = (C.c_void_p * _lib.NUM_PREDS)()
+        for i, k in enumerate(PRED_KEYS):
+            t = pred.get(k)
+            arr[i] = _need_cuda(t, k).data_ptr() if t is not None else None
+        _need_cuda(P2, "P2"); _need_cuda(P2inv, "P2inv")
+        K = int(topk)
+        scores = torch.empty((B, K), dtype=torch.float32, device=dev)
+        flat = torch.empty((B, K), dtype=torch.int64, device=dev)
+        cls = torch.empty((B, K), dtype=torch.int64, device=dev)
+        box2d = torch.empty((B, K, 5), dtype=torch.float32, device=dev)
+        box3d = torch.empty((B, K, 7), dtype=torch.float32, device=dev)
+        keep = torch.empty((B, Cc, H, W), dtype=torch.uint8, device=dev) if want_keep else None
+        kthr = torch.empty((B, K), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = self.lib.mc_decode(self.h, arr, _ptr(P2), _ptr(P2inv), B, Cc, H, W, K, float(thres),
+                                    float(pad_hw[0]), float(pad_hw[1]), _ptr(scores), _ptr(flat), _ptr(cls),
+                                    _ptr(box2d), _ptr(box3d), _ptr(keep), _ptr(kthr), _stream())
+        _lib.check(self.h, rc, "mc_decode")
+        return dict(scores=scores, flat_index=flat, cls=cls, box2d=box2d, box3d=box3d, keep=keep,
+                    box_mask=kthr.bool())
+
+    # ------------------------------------------------------------------ op level (tests)
+    def op_conv(self, srcs, weight, stride=1, scale=None, bias=None, residual=None, relu=False):
+        """srcs: list of NHWC CUDA tensors (virtual concat); weight OIHW; returns NHWC."""
+        for s in srcs:
+            _need_cuda(s, "src")
+        B, H, W, _ = srcs[0].shape
+        Cout, _, k, _ = weight.shape
+        Ho = (H + 2 * (k // 2) - k) // stride + 1
+        Wo = (W + 2 * (k // 2) - k) // stride + 1
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=srcs[0].device)
+        sp = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+        sc = (C.c_int * len(srcs))(*[s.shape[3] for s in srcs])
+        with torch.cuda.device(out.device):
+            rc = self.lib.mc_op_conv(self.h, sp, sc, len(srcs), B, H, W, _ptr(_need_cuda(weight, "weight")), Cout, k,
+                                     stride, _ptr(scale), _ptr(bias), _ptr(residual), int(relu), _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_op_conv")
+        return out
+
+    def op_stem(self, img, weight, scale, bias):
+        B, _, H, W = img.shape
+        out = torch.empty((B, H, W, 16), dtype=torch.float32, device=img.device)
+        with torch.cuda.device(out.device):
+            rc = self.lib.mc_op_stem(self.h, _ptr(_need_cuda(img, "img")), B, H, W, _ptr(weight), _ptr(scale),
+                                     _ptr(bias), _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_op_stem")
+        return out
+
+    def op_maxpool2(self, x):
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, H // 2, W // 2, Cc), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(out.device):
+            rc = self.lib.mc_op_maxpool2(self.h, _ptr(_need_cuda(x, "x")), B, H, W, Cc, _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_op_maxpool2")
+        return out
+
+    def op_deconv4x4(self, x, weight):
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, 2 * H, 2 * W, Cc), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(out.device):
+            rc = self.lib.mc_op_deconv4x4(self.h, _ptr(_need_cuda(x, "x")), B, H, W, Cc, _ptr(weight), _ptr(out),
+                                          _stream())
+        _lib.check(self.h, rc, "mc_op_deconv4x4")
+        return out
+
+    def to_nhwc(self, x):
+        B, Cc, H, W = x.shape
+        out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(out.device):
+            rc = self.lib.mc_op_nchw_to_nhwc(self.h, _ptr(_need_cuda(x, "x")), B, Cc, H, W, _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_op_nchw_to_nhwc")
+        return out
+
+    def to_nchw(self, x):
+        B, H, W, Cc = x.shape
+        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(out.device):
+            rc = self.lib.mc_op_nhwc_to_nchw(self.h, _ptr(_need_cuda(x, "x")), B, Cc, H, W, _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_op_nhwc_to_nchw")
+        return out
+
+
+def p2_inverse(P2):
+    """(B,3,4) numpy/torch -> (B,4,4) fp32 inverse of the view-padded projection
+    (reference monocon_heads.py:544-546 builds eye(4) with P2 in the top rows and inverts it).
+    Host-side 4x4 inverses in float64, rounded to fp32."""
+    P2 = np.asarray(P2, dtype=np.float64).reshape(-1, 3, 4)
+    out = np.zeros((P2.shape[0], 4, 4), dtype=np.float64)
+    for i, p in enumerate(P2):
+        v = np.eye(4)
+        v[:3, :4] = p
+        out[i] = np.linalg.inv(v)
+    return out.astype(np.float32)

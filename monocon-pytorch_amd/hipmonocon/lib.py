@@ -1,0 +1,77 @@
+"""ctypes binding of libmonocon_hip.so (C-ABI declared in include/monocon_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this
+module raises.  Tensors cross the boundary as raw device pointers only.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmonocon_hip.so")
+
+MC_F32, MC_I64 = 0, 1
+NUM_PREDS = 10
+
+EXPORTS = (
+    "mc_create", "mc_destroy", "mc_last_error", "mc_version", "mc_bind_params", "mc_pack_params",
+    "mc_forward_infer", "mc_decode", "mc_op_conv", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
+    "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_forward_cost",
+    "mc_profile_forward",
+)
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p), ("numel", C.c_int64), ("dtype", C.c_int32)]
+
+
+class MonoconHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MonoconHipError(
+            "libmonocon_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C monocon-pytorch_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    fp = C.POINTER(C.c_float)
+    lib.mc_version.restype = i
+    lib.mc_create.argtypes = [i, C.POINTER(vp)]
+    lib.mc_destroy.argtypes = [vp]
+    lib.mc_last_error.argtypes = [vp]
+    lib.mc_last_error.restype = C.c_char_p
+    lib.mc_bind_params.argtypes = [vp, C.POINTER(TensorDesc), i]
+    lib.mc_pack_params.argtypes = [vp, i, vp]
+    lib.mc_forward_infer.argtypes = [vp, vp, i, i, i, C.POINTER(vp), vp, vp]
+    lib.mc_decode.argtypes = [vp, C.POINTER(vp), vp, vp, i, i, i, i, i, f, f, f, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mc_op_conv.argtypes = [vp, C.POINTER(vp), C.POINTER(i), i, i, i, i, vp, i, i, i, vp, vp, vp, i, vp, vp]
+    lib.mc_op_stem.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, vp]
+    lib.mc_op_maxpool2.argtypes = [vp, vp, i, i, i, i, vp, vp]
+    lib.mc_op_deconv4x4.argtypes = [vp, vp, i, i, i, i, vp, vp, vp]
+    lib.mc_op_nchw_to_nhwc.argtypes = [vp, vp, i, i, i, i, vp, vp]
+    lib.mc_op_nhwc_to_nchw.argtypes = [vp, vp, i, i, i, i, vp, vp]
+    lib.mc_workspace_bytes.argtypes = [vp]
+    lib.mc_workspace_bytes.restype = C.c_size_t
+    lib.mc_forward_cost.argtypes = [vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.mc_profile_forward.argtypes = [vp, i, fp, C.POINTER(i), vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int or name not in ("mc_last_error", "mc_workspace_bytes"):
+            if name not in ("mc_last_error", "mc_workspace_bytes"):
+                fn.restype = i
+    _lib = lib
+    return lib
+
+
+def check(handle, rc, what):
+    if rc != 0:
+        msg = load().mc_last_error(handle)
+        raise MonoconHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,84 @@
+"""Decode parity: bit-exact keep mask / top-K indices / classes / threshold mask, floats to 1e-4.
+GPU-only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from hipmonocon import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from hipmonocon.engine import Engine
+    return Engine()
+
+
+def run(eng, d, K, thres=0.4, want_keep=True, pad_hw=(384, 1280)):
+    from hipmonocon.engine import p2_inverse
+    B = d["center_heatmap_pred"].shape[0]
+    pred = {k: torch.from_numpy(v).to(eng.device) for k, v in d.items()}
+    P2 = np.stack([synth.KITTI_P2] * B)
+    return eng.decode(pred, torch.from_numpy(P2).to(eng.device), torch.from_numpy(p2_inverse(P2)).to(eng.device),
+                      pad_hw, K, thres, want_keep=want_keep)
+
+
+@pytest.mark.parametrize("K", [30, 100])
+def test_decode_vs_reference_golden(eng, K):
+    g = load_golden("decode_k%d.npz" % K)
+    d = synth.make_decode_inputs(int(g["seed"]), 4, 96, 320, topk=K)
+    R = run(eng, d, K)
+    HW = 96 * 320
+    assert np.array_equal(np.packbits(R["keep"].cpu().numpy().astype(bool)), g["keep_packed"])
+    assert np.array_equal((R["flat_index"] % HW).cpu().numpy(), g["ind"])
+    assert np.array_equal(R["cls"].cpu().numpy(), g["cls"])
+    assert np.array_equal(R["scores"].cpu().numpy(), g["scores"])
+    for i in range(4):
+        mk = R["box_mask"][i].cpu()
+        assert int(mk.sum()) == g["box2d.%d" % i].shape[0]           # threshold mask identical
+        assert rel_err(R["box2d"][i].cpu()[mk], g["box2d.%d" % i]) < 1e-4
+        assert rel_err(R["box3d"][i].cpu()[mk], g["box3d.%d" % i]) < 1e-4
+        assert np.array_equal(R["cls"][i].cpu()[mk].numpy(), g["label.%d" % i])
+
+
+def test_decode_config5_b64_k100_vs_oracle(eng):
+    """BASELINE config #5: B=64, K=100, thr 0.4 -- indices / masks bit-exact vs the CPU oracle."""
+    from oracle import monocon_oracle as O
+    d = synth.make_decode_inputs(4242, 64, 96, 320, topk=100)
+    R = run(eng, d, 100)
+    ref = O.decode({k: torch.from_numpy(v) for k, v in d.items()}, np.stack([synth.KITTI_P2] * 64), (384, 1280),
+                   topk=100, thres=0.4)
+    assert torch.equal(R["keep"].cpu().bool(), ref["keep"])
+    assert torch.equal(R["flat_index"].cpu(), ref["flat_index"])
+    assert torch.equal(R["cls"].cpu(), ref["cls"])
+    assert torch.equal(R["scores"].cpu(), ref["scores"])
+    assert torch.equal(R["box_mask"].cpu(), ref["box_mask"])
+    assert rel_err(R["box2d"].cpu(), ref["box2d"]) < 1e-4
+    assert rel_err(R["box3d"].cpu(), ref["box3d_shift"]) < 1e-4
+
+
+def test_decode_ties_canonical_order(eng):
+    """plateaus and clamped maxima: ties resolve by ascending flat index (oracle's canonical order)."""
+    from oracle import monocon_oracle as O
+    d = synth.make_decode_inputs(77, 2, 16, 32, topk=40)
+    h = d["center_heatmap_pred"]
+    h[:] = np.float32(1e-4)                   # everything tied at the clamp floor ...
+    h[0, 1, 3:5, 7:9] = np.float32(1 - 1e-4)  # ... except a 2x2 plateau at the ceiling
+    h[1, 2, 10, 20] = 0.5
+    R = run(eng, d, 40, pad_hw=(64, 128))
+    ref = O.decode({k: torch.from_numpy(v) for k, v in d.items()}, np.stack([synth.KITTI_P2] * 2), (64, 128),
+                   topk=40, thres=0.4)
+    assert torch.equal(R["keep"].cpu().bool(), ref["keep"])
+    assert torch.equal(R["flat_index"].cpu(), ref["flat_index"])
+    assert torch.equal(R["scores"].cpu(), ref["scores"])
+
+
+def test_decode_k_limits(eng):
+    from hipmonocon.lib import MonoconHipError
+    d = synth.make_decode_inputs(5, 1, 8, 8, topk=4)
+    R = run(eng, d, 1)
+    assert R["scores"].shape == (1, 1)
+    with pytest.raises(MonoconHipError):
+        run(eng, d, 2000)

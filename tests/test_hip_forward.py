@@ -1,0 +1,79 @@
+"""Whole-network inference parity: HIP forward (C-ABI) vs the golden vectors produced by the
+real reference, and vs the CPU oracle on fresh seeds.  GPU-only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, GOLDEN_SEED
+from hipmonocon import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4      # north_star: fp32 heat-maps within 1e-4 relative (norm-wise, per tensor), judged
+                # against the reference run in fp64 (the reference's own fp32 CPU output sits
+                # 2e-5..1e-4 from its fp64 run)
+TOL_F32 = 2e-4  # vs the reference's fp32 output: two independent fp32 round-off budgets stack
+
+
+@pytest.fixture(scope="module")
+def eng(golden_sd):
+    from hipmonocon.engine import Engine
+    e = Engine()
+    e.state = {k: v.to(e.device) for k, v in golden_sd.items()}
+    e.bind_state(e.state)
+    return e
+
+
+def test_small_eval_forward_vs_reference_golden(eng):
+    g = load_golden("fwd_small_eval.npz")
+    img = synth.make_batch(GOLDEN_SEED + 1, 2, 64, 128, with_labels=False)["img"].to(eng.device)
+    preds, feat = eng.forward_infer(img, want_feat=True)
+    assert rel_err(feat.cpu(), g["feat"]) < TOL
+    for k, v in preds.items():
+        assert tuple(v.shape) == g[k].shape
+        assert rel_err(v.cpu(), g["f64." + k]) < TOL, k     # vs the reference run in fp64
+        assert rel_err(v.cpu(), g[k]) < TOL_F32, k          # vs the reference run in fp32
+
+
+def test_full_res_eval_forward_vs_reference_golden(eng):
+    g = load_golden("fwd_full_eval.npz")
+    img = synth.make_batch(GOLDEN_SEED + 2, 2, 384, 1280, with_labels=False)["img"].to(eng.device)
+    preds = eng.forward_infer(img)
+    for k, v in preds.items():
+        s = v.cpu().reshape(-1)[::97]
+        assert rel_err(s, g[k + ".f64sample"]) < TOL, k
+        assert rel_err(s, g[k + ".sample"]) < TOL_F32, k
+        ref_sum = float(g[k + ".sum"])
+        assert abs(float(v.double().sum()) - ref_sum) <= 2e-5 * abs(ref_sum) + 1e-2, k
+
+
+def test_forward_vs_oracle_other_shape(eng):
+    """fresh input, batch 3, non-square multiple of 32, compared with the CPU oracle."""
+    from oracle import monocon_oracle as O
+    img = synth.make_batch(991, 3, 96, 160, with_labels=False)["img"]
+    sd = {k: v.cpu() for k, v in eng.state.items()}
+    with torch.no_grad():
+        ref, feat, _ = O.forward(sd, img)
+    preds = eng.forward_infer(img.to(eng.device))
+    for k, v in preds.items():
+        assert rel_err(v.cpu(), ref[k]) < TOL, k
+
+
+def test_repack_follows_parameter_update(eng):
+    """in-place update of a master weight must be picked up (``_version`` tracking)."""
+    img = synth.make_batch(5, 1, 64, 64, with_labels=False)["img"].to(eng.device)
+    a = eng.forward_infer(img)["wh_pred"].clone()
+    w = eng.state["head.wh_head.3.bias"]
+    w.add_(1.0)
+    eng.bind_state(eng.state)
+    b = eng.forward_infer(img)["wh_pred"]
+    w.sub_(1.0)
+    eng.bind_state(eng.state)
+    assert torch.allclose(b, a + 1.0, atol=1e-5)
+
+
+def test_bad_shapes_raise(eng):
+    from hipmonocon.lib import MonoconHipError
+    with pytest.raises(MonoconHipError):
+        eng.forward_infer(torch.zeros(1, 3, 60, 64, device=eng.device))
+    with pytest.raises(MonoconHipError):
+        eng.forward_infer(torch.zeros(1, 3, 64, 64))

@@ -1,0 +1,113 @@
+"""Op-level parity of the HIP kernels (through the C-ABI) against plain torch CPU ops in fp64.
+GPU-only: run with ``-m gpu`` on the MI355X box."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from hipmonocon import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6   # fp32 MFMA FMA chain vs fp64, norm-wise
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from hipmonocon.engine import Engine
+    return Engine()
+
+
+def rnd(seed, name, shape, std=1.0):
+    return torch.from_numpy(synth.normalish(seed, name, shape, 0.0, std).astype(np.float32))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+CONV_CASES = [
+    # (name, B, H, W, [Cin...], Cout, k, stride, residual, relu, affine)
+    ("s1_64_64", 2, 16, 24, [64], 64, 3, 1, True, True, True),
+    ("s1_128_128_t128", 1, 12, 40, [128], 128, 3, 1, True, True, True),
+    ("s1_16_16_t32", 1, 20, 24, [16], 16, 3, 1, False, True, True),
+    ("s1_cat_64_64_to64", 2, 8, 16, [64, 64], 64, 3, 1, False, True, True),
+    ("s1_odd_edges", 1, 6, 10, [32], 64, 3, 1, False, False, False),
+    ("s1_tiny_2x4", 2, 2, 4, [256], 512, 3, 1, True, True, True),
+    ("s2_32_64", 2, 16, 32, [32], 64, 3, 2, False, True, True),
+    ("s2_16_32", 1, 24, 16, [16], 32, 3, 2, False, True, True),
+    ("s2_256_512", 1, 8, 8, [256], 512, 3, 2, False, True, True),
+    ("k1_root4", 1, 12, 16, [128, 128, 64, 128], 128, 1, 1, False, True, True),
+    ("k1_project", 2, 8, 8, [32], 64, 1, 1, False, False, True),
+    ("k1_root3_512", 1, 4, 8, [512, 512, 256], 512, 1, 1, False, True, True),
+    ("head_576", 1, 8, 16, [64], 576, 3, 1, False, False, True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(eng, case):
+    name, B, H, W, cins, cout, k, stride, use_res, relu, affine = case
+    seed = 100 + CONV_CASES.index(case)
+    xs = [rnd(seed, "x%d" % i, (B, c, H, W)) for i, c in enumerate(cins)]
+    w = rnd(seed, "w", (cout, sum(cins), k, k), (2.0 / (k * k * sum(cins))) ** 0.5)
+    scale = (1.0 + 0.1 * rnd(seed, "sc", (cout,))) if affine else None
+    bias = 0.1 * rnd(seed, "bi", (cout,)) if affine else None
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), None, stride, k // 2)
+    res = rnd(seed, "res", tuple(ref.shape)) if use_res else None
+    if affine:
+        ref = ref * scale.double()[None, :, None, None] + bias.double()[None, :, None, None]
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    dev = eng.device
+    out = eng.op_conv([nhwc(x).to(dev) for x in xs], w.to(dev), stride,
+                      scale.to(dev) if affine else None, bias.to(dev) if affine else None,
+                      nhwc(res).to(dev) if use_res else None, relu)
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < TOL
+
+
+def test_conv_is_transpose_sensitive(eng):
+    """asymmetric one-hot weight: output channel n must read input channel (n*7)%C at tap (0,2)."""
+    B, H, W, Cc = 1, 8, 8, 64
+    x = rnd(1, "x", (B, Cc, H, W))
+    w = torch.zeros(Cc, Cc, 3, 3)
+    for n in range(Cc):
+        w[n, (n * 7) % Cc, 0, 2] = 1.0
+    ref = F.conv2d(x, w, None, 1, 1)
+    got = eng.op_conv([nhwc(x).to(eng.device)], w.to(eng.device)).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, ref)
+
+
+def test_stem(eng):
+    x = rnd(3, "img", (2, 3, 40, 72))
+    w = rnd(3, "w", (16, 3, 7, 7), 0.1)
+    sc, bi = 1.0 + 0.1 * rnd(3, "s", (16,)), 0.1 * rnd(3, "b", (16,))
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, 1, 3) * sc.double()[None, :, None, None]
+                 + bi.double()[None, :, None, None])
+    d = eng.device
+    got = eng.op_stem(x.to(d), w.to(d), sc.to(d), bi.to(d)).cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < TOL
+
+
+def test_maxpool(eng):
+    x = rnd(4, "x", (2, 32, 12, 20))
+    got = eng.op_maxpool2(nhwc(x).to(eng.device)).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, F.max_pool2d(x, 2, 2))
+
+
+def test_deconv(eng):
+    x = rnd(5, "x", (2, 64, 6, 10))
+    w = rnd(5, "w", (64, 1, 4, 4), 0.5)
+    ref = F.conv_transpose2d(x.double(), w.double(), None, stride=2, padding=1, groups=64)
+    got = eng.op_deconv4x4(nhwc(x).to(eng.device), w.to(eng.device)).cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < TOL
+
+
+def test_layout_roundtrip(eng):
+    x = rnd(6, "x", (2, 19, 7, 33)).to(eng.device)
+    y = eng.to_nhwc(x)
+    assert torch.equal(y.cpu(), x.cpu().permute(0, 2, 3, 1))
+    assert torch.equal(eng.to_nchw(y).cpu(), x.cpu())
