@@ -120,8 +120,9 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
 /* Bytes of handle-owned device memory (workspace + packed weights). */
 size_t mc_workspace_bytes(mc_handle *h);
 /* Algorithmic FLOPs / HBM bytes of one inference forward at (B,H,W), computed from the
- * layer table (SURVEY §8d fusion model). */
-int mc_forward_cost(mc_handle *h, int B, int H, int W, double *flops, double *bytes);
+ * layer table (SURVEY §8d fusion model): [0] = the fused conv-MFMA launches, [1] = all other
+ * launches (stem, pools, deconvs, head passes). */
+int mc_forward_cost(mc_handle *h, int B, int H, int W, double flops[2], double bytes[2]);
 /* Time the launches of the last forward plan by kind with HIP events on `stream`
  * (bench.py roofline leg): runs the cached plan `iters` times.  out_ms: [0] all conv-MFMA
  * kernels, [1] everything else, [2] whole forward; out_n: launches per forward by kind. */

@@ -120,6 +120,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
     const size_t colP = (size_t)a.CoutP;
     const float *wlane = a.wpk + ((size_t)g * colP + n0 + wn * WTN * 32 + li) * 4;
 
+    // B fragment of step s (= tap * CK/8 + k8) of the K-chunk starting at concat channel kc
+    constexpr int K8 = CK / 8, NS = KS * KS * K8;
+    auto load_b = [&](f32x4(&dst)[WTN], int kc, int s) {
+        const int tap = s / K8, k8 = s % K8;
+        const float *wp = wlane + ((size_t)(tap * Cin4 + ((kc + k8 * 8) >> 2)) * colP) * 4;
+#pragma unroll
+        for (int tn = 0; tn < WTN; ++tn) dst[tn] = *reinterpret_cast<const f32x4 *>(wp + tn * 32 * 4);
+    };
+    auto load_a = [&](f32x4(&dst)[WTM], int s) {
+        const int tap = s / K8, k8 = s % K8;
+#pragma unroll
+        for (int tm = 0; tm < WTM; ++tm)
+            dst[tm] = *reinterpret_cast<const f32x4 *>(
+                &lds[a_off[tm] + ((tap / KS) * IW + (tap % KS)) * CKP + k8 * 8]);
+    };
+    f32x4 bcur[WTN];
+    load_b(bcur, 0, 0);   // weights do not depend on the staged tile: in flight across the barriers
+
     int kbase = 0;   // channel offset of the current source inside the virtual concat
     for (int si = 0; si < a.nsrc; ++si) {
         const float *sp = a.src[si].p;
@@ -145,30 +163,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
                 *reinterpret_cast<f32x4 *>(&lds[(p * NPIX + pix) * CKP + c4 * 4]) = v;
             }
             __syncthreads();
-            // ---- MFMA over taps x channel groups of 8
+            // ---- MFMA over taps x channel groups of 8; both operands are fetched one step ahead
+            //      (explicit register double-buffering: hipcc otherwise issues each weight load
+            //      right in front of the MFMA that consumes it and exposes the full L2 latency)
             const int kc = kbase + c0;
+            const int kc_next = (kc + CK < a.Cin) ? kc + CK : kc;   // last chunk: harmless re-load
+            f32x4 acur[WTM];
+            load_a(acur, 0);
 #pragma unroll
-            for (int tap = 0; tap < KS * KS; ++tap) {
+            for (int s = 0; s < NS; ++s) {
+                f32x4 anext[WTM], bnext[WTN];
+                if (s + 1 < NS) {
+                    load_a(anext, s + 1);
+                    load_b(bnext, kc, s + 1);
+                } else {
+                    load_b(bnext, kc_next, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
-                for (int k8 = 0; k8 < CK / 8; ++k8) {
-                    f32x4 af[WTM], bf[WTN];
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int tm = 0; tm < WTM; ++tm)
-                        af[tm] = *reinterpret_cast<const f32x4 *>(
-                            &lds[a_off[tm] + ((tap / KS) * IW + (tap % KS)) * CKP + k8 * 8]);
-                    const float *wp = wlane + ((size_t)(tap * Cin4 + ((kc + k8 * 8) >> 2)) * colP) * 4;
 #pragma unroll
-                    for (int tn = 0; tn < WTN; ++tn)
-                        bf[tn] = *reinterpret_cast<const f32x4 *>(wp + tn * 32 * 4);
+                        for (int tn = 0; tn < WTN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                acur[tm][j], bcur[tn][j], acc[tm][tn], 0, 0, 0);
+                if (s + 1 < NS) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int tm = 0; tm < WTM; ++tm)
-#pragma unroll
-                            for (int tn = 0; tn < WTN; ++tn)
-                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                    af[tm][j], bf[tn][j], acc[tm][tn], 0, 0, 0);
+                    for (int tm = 0; tm < WTM; ++tm) acur[tm] = anext[tm];
                 }
+#pragma unroll
+                for (int tn = 0; tn < WTN; ++tn) bcur[tn] = bnext[tn];
             }
         }
         kbase += Cs;
@@ -245,6 +270,8 @@ inline int conv_coutp(int Cout) {
     const int t = conv_ntile(Cout);
     return (Cout + t - 1) / t * t;
 }
+// patches (4x8 output pixels each) per workgroup for a tile family -- must match launch_tile()
+inline int conv_patches_per_block(int ntile, int stride) { return (ntile == 128 || stride == 2) ? 4 : 8; }
 // K-chunk: 32 when every source is a multiple of 32 channels and the 3x3 is stride 1 (or 1x1).
 inline int conv_ck(int ks, int stride, const int *src_c, int nsrc) {
     bool all32 = true;

@@ -29,8 +29,15 @@ template <int KS, int S, int CK>
 static hipError_t launch_tile(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
     const int nt = a.ntile ? a.ntile : conv_ntile(a.Cout);
     if (nt == 128) return launch_one<KS, S, CK, 2, 2, 2, 2>(a, st, resolved);
-    if (nt == 64) return launch_one<KS, S, CK, 4, 1, 2, 2>(a, st, resolved);
-    return launch_one<KS, S, CK, 4, 1, 2, 1>(a, st, resolved);
+    if constexpr (S == 2) {
+        // stride-2 halos are 9x17 pixels per patch: keep 4 patches per workgroup so that several
+        // workgroups fit a CU's LDS and load / MFMA / store phases of different groups overlap
+        if (nt == 64) return launch_one<KS, S, CK, 4, 1, 1, 2>(a, st, resolved);
+        return launch_one<KS, S, CK, 4, 1, 1, 1>(a, st, resolved);
+    } else {
+        if (nt == 64) return launch_one<KS, S, CK, 4, 1, 2, 2>(a, st, resolved);
+        return launch_one<KS, S, CK, 4, 1, 2, 1>(a, st, resolved);
+    }
 }
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved) {

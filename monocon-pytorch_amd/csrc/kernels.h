@@ -59,8 +59,8 @@ struct HeadApplyArgs {
     const float *hidden;     // [B][HW][576]
     const float *scale;      // [B][9][64]
     const float *shift;
-    const float *w;          // [65][64] 1x1 weights (rows in HeadRow order)
-    const float *b;          // [65]
+    const float *__restrict__ w;   // [64][65] transposed 1x1 weights (columns in HeadRow order)
+    const float *__restrict__ b;   // [65]
     float *pred[10];         // NCHW outputs
     int pred_c[10];
     int B, HW;

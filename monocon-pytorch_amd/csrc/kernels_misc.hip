@@ -318,86 +318,117 @@ hipError_t launch_head_attn(const float *stats, int B, int chunks, int HW, const
 // Second head pass: AttnBN apply + ReLU + 1x1 conv + output non-linearity, NCHW stores.
 // One wave per (64-pixel tile, head): the [64 px][64 ch] hidden block is normalised while being
 // staged into LDS, then lane = pixel accumulates the head's output rows against wave-uniform
-// weights.  (reference monocon_heads.py:114-120,165-200)
-struct HeadApplyDev {
-    HeadApplyArgs a;
-    HeadRow rows[NUM_OUT_ROWS];
-    int row_begin[NUM_HEADS + 1];
-};
-
+// weights (scalar loads of the transposed [64][65] panel).  The head -> (prediction tensor,
+// channel, epilogue) routing is a compile-time table so that no kernel-argument array is ever
+// indexed dynamically (that would be demoted to scratch memory).
+// (reference monocon_heads.py:114-120,165-200)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int NR>
-__device__ __forceinline__ void head_rows_compute(const HeadApplyDev &d, const float *hl, int lane, int h, int rb,
-                                                  int b, int hw, bool ok) {
+// head index -> first row, row count, and per-row destination; dir_feat (head 8) feeds two tensors
+template <int H> struct HeadMap;
+template <> struct HeadMap<0> { static constexpr int RB = 0, NR = 3; };
+template <> struct HeadMap<1> { static constexpr int RB = 3, NR = 2; };
+template <> struct HeadMap<2> { static constexpr int RB = 5, NR = 2; };
+template <> struct HeadMap<3> { static constexpr int RB = 7, NR = 18; };
+template <> struct HeadMap<4> { static constexpr int RB = 25, NR = 9; };
+template <> struct HeadMap<5> { static constexpr int RB = 34, NR = 2; };
+template <> struct HeadMap<6> { static constexpr int RB = 36, NR = 3; };
+template <> struct HeadMap<7> { static constexpr int RB = 39, NR = 2; };
+template <> struct HeadMap<8> { static constexpr int RB = 41, NR = 24; };
+
+template <int H>
+__device__ __forceinline__ constexpr int row_pred(int r) {
+    constexpr int hp[8] = {0, 2, 3, 5, 1, 4, 6, 7};
+    return H < 8 ? hp[H < 8 ? H : 0] : (r < 12 ? 8 : 9);
+}
+template <int H>
+__device__ __forceinline__ constexpr int row_ch(int r) { return H < 8 ? r : (r < 12 ? r : r - 12); }
+template <int H>
+__device__ __forceinline__ constexpr int row_epi(int r) {
+    return (H == 0 || H == 4) ? 1 : ((H == 7 && r == 0) ? 2 : 0);
+}
+
+template <int H>
+__device__ __forceinline__ void head_rows_compute(const HeadApplyArgs &a, const float *hl, int lane, int b, int hw,
+                                                  bool ok) {
+    constexpr int NR = HeadMap<H>::NR, RB = HeadMap<H>::RB;
     float acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.f;
-    const float *w = d.a.w + (size_t)rb * HEAD_CH;
+    // transposed weights [64][65]: rows of one head are contiguous.  Read through the constant
+    // address space so the wave-uniform loads go down the scalar path (s_load) instead of VMEM.
+    typedef const float __attribute__((address_space(4))) cfloat;
+    cfloat *w = (cfloat *)(uintptr_t)(a.w + RB);
+#pragma unroll 4
     for (int c = 0; c < HEAD_CH; ++c) {
         const float v = hl[lane * 65 + c];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] = fmaf(v, w[r * HEAD_CH + c], acc[r]);
+        for (int r = 0; r < NR; ++r) acc[r] = fmaf(v, w[c * NUM_OUT_ROWS + r], acc[r]);
     }
     if (!ok) return;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const HeadRow row = d.rows[rb + r];
-        float v = acc[r] + d.a.b[rb + r];
-        if (row.epi == 1) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        float v = acc[r] + a.b[RB + r];
+        const int epi = row_epi<H>(r);
+        if (epi == 1) {
             v = fminf(fmaxf(sigmoidf_(v), 1e-4f), 1.0f - 1e-4f);
-        } else if (row.epi == 2) {
+        } else if (epi == 2) {
             v = 1.0f / (sigmoidf_(v) + 1e-12f) - 1.0f;
         }
-        d.a.pred[row.pred][((size_t)b * d.a.pred_c[row.pred] + row.ch) * d.a.HW + hw] = v;
+        const int p = row_pred<H>(r);
+        a.pred[p][((size_t)b * a.pred_c[p] + row_ch<H>(r)) * a.HW + hw] = v;
     }
 }
 
-__global__ __launch_bounds__(192) void head_apply_kernel(const HeadApplyDev d) {
+__global__ __launch_bounds__(192) void head_apply_kernel(const HeadApplyArgs a) {
     __shared__ float hlds[3][64 * 65];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = blockIdx.y * 3 + wave;
-    const int tiles = (d.a.HW + 63) / 64;
+    const int tiles = (a.HW + 63) / 64;
     const int b = blockIdx.x / tiles, hw0 = (blockIdx.x % tiles) * 64;
     float *hl = hlds[wave];
     // stage + normalise: 16 lanes cover one pixel's 64 channels (float4 each)
     const int c4 = lane & 15;
-    const f32x4 sc = *reinterpret_cast<const f32x4 *>(d.a.scale + ((size_t)b * NUM_HEADS + h) * HEAD_CH + c4 * 4);
-    const f32x4 sh = *reinterpret_cast<const f32x4 *>(d.a.shift + ((size_t)b * NUM_HEADS + h) * HEAD_CH + c4 * 4);
-#pragma unroll 4
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(a.scale + ((size_t)b * NUM_HEADS + h) * HEAD_CH + c4 * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift + ((size_t)b * NUM_HEADS + h) * HEAD_CH + c4 * 4);
+    f32x4 v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {      // all 16 loads in flight before the first use
+        const int hw = hw0 + it * 4 + (lane >> 4);
+        v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hw < a.HW)
+            v[it] = *reinterpret_cast<const f32x4 *>(a.hidden + ((size_t)b * a.HW + hw) * (NUM_HEADS * HEAD_CH) +
+                                                     h * HEAD_CH + c4 * 4);
+    }
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int px = it * 4 + (lane >> 4);
-        const int hw = hw0 + px;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (hw < d.a.HW)
-            v = *reinterpret_cast<const f32x4 *>(d.a.hidden + ((size_t)b * d.a.HW + hw) * (NUM_HEADS * HEAD_CH) +
-                                                 h * HEAD_CH + c4 * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hl[px * 65 + c4 * 4 + j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+        for (int j = 0; j < 4; ++j) hl[px * 65 + c4 * 4 + j] = fmaxf(fmaf(v[it][j], sc[j], sh[j]), 0.f);
     }
     __syncthreads();
-    const int rb = d.row_begin[h], nr = d.row_begin[h + 1] - rb;
     const int hw = hw0 + lane;
-    const bool ok = hw < d.a.HW;
-    switch (nr) {
-        case 2: head_rows_compute<2>(d, hl, lane, h, rb, b, hw, ok); break;
-        case 3: head_rows_compute<3>(d, hl, lane, h, rb, b, hw, ok); break;
-        case 9: head_rows_compute<9>(d, hl, lane, h, rb, b, hw, ok); break;
-        case 18: head_rows_compute<18>(d, hl, lane, h, rb, b, hw, ok); break;
-        case 24: head_rows_compute<24>(d, hl, lane, h, rb, b, hw, ok); break;
-        default: break;
+    const bool ok = hw < a.HW;
+    switch (h) {
+        case 0: head_rows_compute<0>(a, hl, lane, b, hw, ok); break;
+        case 1: head_rows_compute<1>(a, hl, lane, b, hw, ok); break;
+        case 2: head_rows_compute<2>(a, hl, lane, b, hw, ok); break;
+        case 3: head_rows_compute<3>(a, hl, lane, b, hw, ok); break;
+        case 4: head_rows_compute<4>(a, hl, lane, b, hw, ok); break;
+        case 5: head_rows_compute<5>(a, hl, lane, b, hw, ok); break;
+        case 6: head_rows_compute<6>(a, hl, lane, b, hw, ok); break;
+        case 7: head_rows_compute<7>(a, hl, lane, b, hw, ok); break;
+        default: head_rows_compute<8>(a, hl, lane, b, hw, ok); break;
     }
 }
 
 hipError_t launch_head_apply(const HeadApplyArgs &a, hipStream_t st) {
     init_rows();
-    HeadApplyDev d;
-    d.a = a;
-    for (int i = 0; i < NUM_OUT_ROWS; ++i) d.rows[i] = g_rows[i];
-    for (int i = 0; i <= NUM_HEADS; ++i) d.row_begin[i] = g_row_begin[i];
     const int tiles = (a.HW + 63) / 64;
-    hipLaunchKernelGGL(head_apply_kernel, dim3(a.B * tiles, 3), dim3(192), 0, st, d);
+    hipLaunchKernelGGL(head_apply_kernel, dim3(a.B * tiles, 3), dim3(192), 0, st, a);
     return hipGetLastError();
 }
 

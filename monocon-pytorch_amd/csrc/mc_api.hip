@@ -90,7 +90,7 @@ struct mc_handle {
     ConvLayer head3;
     float *head_bias = nullptr, *head_rm = nullptr;
     float *att_scale = nullptr, *att_shift = nullptr;   // [9][10]
-    float *head_w1 = nullptr, *head_b1 = nullptr;       // [65][64], [65]
+    float *head_w1 = nullptr, *head_w1t = nullptr, *head_b1 = nullptr;   // [65][64], transposed [64][65], [65]
     HeadAttnParams hap{};
     bool layers_built = false, packed = false;
     size_t param_bytes = 0;
@@ -209,6 +209,7 @@ static int build_layers(mc_handle *h) {
     if (dev_alloc(h, &h->att_scale, NUM_HEADS * NUM_AFFINE, h->param_bufs, h->param_bytes)) return -1;
     if (dev_alloc(h, &h->att_shift, NUM_HEADS * NUM_AFFINE, h->param_bufs, h->param_bytes)) return -1;
     if (dev_alloc(h, &h->head_w1, NUM_OUT_ROWS * HEAD_CH, h->param_bufs, h->param_bytes)) return -1;
+    if (dev_alloc(h, &h->head_w1t, NUM_OUT_ROWS * HEAD_CH, h->param_bufs, h->param_bytes)) return -1;
     if (dev_alloc(h, &h->head_b1, NUM_OUT_ROWS, h->param_bufs, h->param_bytes)) return -1;
     HIPCHK(h, hipDeviceSynchronize());   // zero-fills above ran on the null stream
     h->layers_built = true;
@@ -285,7 +286,7 @@ struct Builder {
         a.relu = relu ? 1 : 0;
         const int ppr = (Wo + 7) / 8, ppi = ppr * ((Ho + 3) / 4);
         a.ntile = L.ntile;
-        const int pb = (L.ntile ? L.ntile : conv_ntile(L.cout)) == 128 ? 4 : 8;
+        const int pb = conv_patches_per_block(L.ntile ? L.ntile : conv_ntile(L.cout), L.stride);
         const int chunks = (ppi + pb - 1) / pb;
         if (stats_out) {
             *stats_out = alloc_raw((size_t)s0.B * chunks * L.coutp * 2);
@@ -419,7 +420,7 @@ static Plan *get_plan(mc_handle *h, int B, int H, int W) {
         op.kind = OP_HEAD_APPLY;
         HeadApplyArgs &a = op.ha;
         a.hidden = hidden.p; a.scale = hs_scale; a.shift = hs_shift;
-        a.w = h->head_w1; a.b = h->head_b1;
+        a.w = h->head_w1t; a.b = h->head_b1;
         a.B = B; a.HW = feat.H * feat.W;
         for (int i = 0; i < MC_NUM_PREDS; ++i) a.pred_c[i] = PRED_CH[i];
         op.flops = 2.0 * B * a.HW * 64.0 * NUM_OUT_ROWS;
@@ -595,6 +596,8 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
             HIPCHK(h, launch_copy(br, h->head_b1 + rb[8] + 12, 12, st));
         }
     }
+    // [65][64] -> [64][65]: the second head pass reads one input channel against all rows of a head
+    HIPCHK(h, launch_nchw_to_nhwc(h->head_w1, 1, NUM_OUT_ROWS, 1, HEAD_CH, h->head_w1t, st));
 #undef NEEDP
     h->packed = true;
     return 0;
@@ -764,14 +767,20 @@ size_t mc_workspace_bytes(mc_handle *h) {
     return n;
 }
 
-int mc_forward_cost(mc_handle *h, int B, int H, int W, double *flops, double *bytes) {
+int mc_forward_cost(mc_handle *h, int B, int H, int W, double flops[2], double bytes[2]) {
     if (!h) return -1;
     if (!h->packed) return fail(h, "mc_forward_cost: pack parameters first");
     HIPCHK(h, hipSetDevice(h->device));
     Plan *pl = get_plan(h, B, H, W);
     if (!pl) return -1;
-    if (flops) *flops = pl->flops;
-    if (bytes) *bytes = pl->hbm_bytes;
+    double f[2] = {0, 0}, b[2] = {0, 0};
+    for (const Op &op : pl->ops) {
+        const int k = op.kind == OP_CONV ? 0 : 1;
+        f[k] += op.flops;
+        b[k] += op.bytes;
+    }
+    if (flops) { flops[0] = f[0]; flops[1] = f[1]; }
+    if (bytes) { bytes[0] = b[0]; bytes[1] = b[1]; }
     return 0;
 }
 

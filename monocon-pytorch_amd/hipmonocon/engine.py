@@ -105,9 +105,10 @@ class Engine:
         return (out, feat) if want_feat else out
 
     def forward_cost(self, B, H, W):
-        fl, by = C.c_double(), C.c_double()
-        _lib.check(self.h, self.lib.mc_forward_cost(self.h, B, H, W, C.byref(fl), C.byref(by)), "mc_forward_cost")
-        return fl.value, by.value
+        """-> dict(conv_flops, other_flops, conv_bytes, other_bytes) of one forward."""
+        fl, by = (C.c_double * 2)(), (C.c_double * 2)()
+        _lib.check(self.h, self.lib.mc_forward_cost(self.h, B, H, W, fl, by), "mc_forward_cost")
+        return {"conv_flops": fl[0], "other_flops": fl[1], "conv_bytes": by[0], "other_bytes": by[1]}
 
     def profile_forward(self, iters=3):
         ms = (C.c_float * 3)()
