@@ -116,6 +116,14 @@ int mc_op_nchw_to_nhwc(mc_handle *h, const float *in, int B, int C, int H, int W
 int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W, float *out,
                        void *stream);
 
+/* Tuning aid: average duration (ms) of `iters` launches of one fused-conv shape on random data.
+ * cfg: workgroup shape id (0 = the library's own choice; see csrc/conv_mfma.h ConvCfgId). */
+int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src_channels[],
+                  int Cout, int ksize, int stride, int cfg, int iters, float *ms_avg);
+
+/* Tuning aid: sustained TFLOP/s of back-to-back v_mfma_f32_32x32x2_f32 with no memory traffic. */
+int mc_bench_mfma_peak(mc_handle *h, int waves_per_simd, int iters, float *tflops);
+
 /* ---- introspection ------------------------------------------------------------------ */
 /* Bytes of handle-owned device memory (workspace + packed weights). */
 size_t mc_workspace_bytes(mc_handle *h);

@@ -53,7 +53,7 @@ struct ConvArgs {
     float *stats;            // optional [B][chunks][CoutP][2] partial (sum, sumsq) of (v - shift)
     const float *stat_shift; // [Cout] or null
     int ppr, ppi, chunks;    // patches per row / per image, workgroup chunks per image
-    int ntile;               // N tile override (0 = conv_ntile(Cout))
+    int cfg;                 // ConvCfgId workgroup shape (CFG_AUTO = conv_pick_cfg)
 };
 
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
@@ -259,19 +259,46 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
 }
 
 // ---- host-side tile selection ---------------------------------------------------------
-struct ConvTile {
-    int PB, BNT, NT;
-    size_t lds;
+// Workgroup shapes (WM x WN waves, each wave WTM x WTN 32x32 MFMA tiles).  A shape owns
+// PB = WM*WTM patches (32 output pixels each) and BNT = WN*WTN*32 output channels.
+struct ConvShape {
+    int WM, WN, WTM, WTN;
+    int PB() const { return WM * WTM; }
+    int BNT() const { return WN * WTN * 32; }
 };
+enum ConvCfgId {
+    CFG_AUTO = 0,
+    CFG_128x128 = 1,    // 2x2 waves, 2x2 tiles : 128 px x 128 ch
+    CFG_256x64 = 2,     // 4x1 waves, 2x2 tiles : 256 px x  64 ch
+    CFG_256x32 = 3,     // 4x1 waves, 2x1 tiles : 256 px x  32 ch
+    CFG_128x64 = 4,     // 2x2 waves, 2x1 tiles : 128 px x  64 ch
+    CFG_128x64m = 5,    // 4x1 waves, 1x2 tiles : 128 px x  64 ch (waves split M only)
+    CFG_128x32 = 6,     // 4x1 waves, 1x1 tiles : 128 px x  32 ch
+    CFG_64x128 = 7,     // 1x4 waves, 2x1 tiles :  64 px x 128 ch
+    CFG_64x64 = 8,      // 2x2 waves, 1x1 tiles :  64 px x  64 ch
+    CFG_COUNT = 9
+};
+inline ConvShape conv_shape(int cfg) {
+    switch (cfg) {
+        case CFG_128x128: return {2, 2, 2, 2};
+        case CFG_256x64: return {4, 1, 2, 2};
+        case CFG_256x32: return {4, 1, 2, 1};
+        case CFG_128x64: return {2, 2, 2, 1};
+        case CFG_128x64m: return {4, 1, 1, 2};
+        case CFG_128x32: return {4, 1, 1, 1};
+        case CFG_64x128: return {1, 4, 2, 1};
+        case CFG_64x64: return {2, 2, 1, 1};
+        default: return {0, 0, 0, 0};
+    }
+}
 
-// N tile (and therefore the packed column padding) used for a layer with Cout columns.
+// Column padding of the packed weights for a layer with Cout columns (every shape's BNT that
+// may be chosen for the layer divides it).
 inline int conv_ntile(int Cout) { return Cout >= 128 ? 128 : (Cout > 32 ? 64 : 32); }
 inline int conv_coutp(int Cout) {
     const int t = conv_ntile(Cout);
     return (Cout + t - 1) / t * t;
 }
-// patches (4x8 output pixels each) per workgroup for a tile family -- must match launch_tile()
-inline int conv_patches_per_block(int ntile, int stride) { return (ntile == 128 || stride == 2) ? 4 : 8; }
 // K-chunk: 32 when every source is a multiple of 32 channels and the 3x3 is stride 1 (or 1x1).
 inline int conv_ck(int ks, int stride, const int *src_c, int nsrc) {
     bool all32 = true;
@@ -279,6 +306,12 @@ inline int conv_ck(int ks, int stride, const int *src_c, int nsrc) {
     if (ks == 3 && stride == 2) return 16;
     return all32 ? 32 : 16;
 }
+// Default shape for a layer (tuned on MI355X): depends on the column count, the
+// stride (stride-2 halos are 9x17 pixels per patch, so fewer patches per workgroup keep several
+// workgroups resident per CU) and on how many workgroups the launch would have.
+int conv_pick_cfg(int Cout, int CoutP, int ks, int stride, int B, int Hout, int Wout);
+// patches per workgroup of the shape launch_conv() will use for these arguments
+inline int conv_patches_per_block(int cfg) { return conv_shape(cfg).PB(); }
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);
 

@@ -9,6 +9,7 @@ static hipError_t launch_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     a.ppr = (a.Wout + 7) / 8;
     a.ppi = a.ppr * ((a.Hout + 3) / 4);
     a.chunks = (a.ppi + Cfg::PB - 1) / Cfg::PB;
+    if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
     static bool attr_set = false;
     auto kern = conv_mfma_kernel<KS, S, CK, WM, WN, WTM, WTN>;
@@ -24,35 +25,46 @@ static hipError_t launch_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     return hipGetLastError();
 }
 
-// tile families:  T32 = 256 px x 32 ch, T64 = 256 px x 64 ch, T128 = 128 px x 128 ch
 template <int KS, int S, int CK>
-static hipError_t launch_tile(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
-    const int nt = a.ntile ? a.ntile : conv_ntile(a.Cout);
-    if (nt == 128) return launch_one<KS, S, CK, 2, 2, 2, 2>(a, st, resolved);
-    if constexpr (S == 2) {
-        // stride-2 halos are 9x17 pixels per patch: keep 4 patches per workgroup so that several
-        // workgroups fit a CU's LDS and load / MFMA / store phases of different groups overlap
-        if (nt == 64) return launch_one<KS, S, CK, 4, 1, 1, 2>(a, st, resolved);
-        return launch_one<KS, S, CK, 4, 1, 1, 1>(a, st, resolved);
-    } else {
-        if (nt == 64) return launch_one<KS, S, CK, 4, 1, 2, 2>(a, st, resolved);
-        return launch_one<KS, S, CK, 4, 1, 2, 1>(a, st, resolved);
+static hipError_t launch_shape(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
+    switch (a.cfg) {
+        case CFG_128x128: return launch_one<KS, S, CK, 2, 2, 2, 2>(a, st, resolved);
+        case CFG_256x64: return launch_one<KS, S, CK, 4, 1, 2, 2>(a, st, resolved);
+        case CFG_256x32: return launch_one<KS, S, CK, 4, 1, 2, 1>(a, st, resolved);
+        case CFG_128x64: return launch_one<KS, S, CK, 2, 2, 2, 1>(a, st, resolved);
+        case CFG_128x64m: return launch_one<KS, S, CK, 4, 1, 1, 2>(a, st, resolved);
+        case CFG_128x32: return launch_one<KS, S, CK, 4, 1, 1, 1>(a, st, resolved);
+        case CFG_64x128: return launch_one<KS, S, CK, 1, 4, 2, 1>(a, st, resolved);
+        case CFG_64x64: return launch_one<KS, S, CK, 2, 2, 1, 1>(a, st, resolved);
+        default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
+int conv_pick_cfg(int Cout, int CoutP, int ks, int stride, int B, int Hout, int Wout) {
+    // Measured on MI355X at B=32 (scratch/tune_conv.py, profiles/r1_conv_shapes.txt): the shapes
+    // are within ~10 % of each other; small 64-pixel groups win where the K loop is short (1x1)
+    // because more, shorter workgroups balance better across the 256 CUs.
+    (void)B; (void)Hout; (void)Wout; (void)CoutP;
+    const int nt = conv_ntile(Cout);
+    if (nt == 128) return ks == 1 ? CFG_64x128 : CFG_128x128;
+    if (nt == 64) return (ks == 1 || stride == 2) ? CFG_64x64 : CFG_128x64m;
+    return CFG_128x32;
+}
+
+hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
+    ConvArgs a = a_in;
     int sc[4];
     for (int i = 0; i < a.nsrc; ++i) sc[i] = a.src[i].C;
     const int ck = conv_ck(ks, stride, sc, a.nsrc);
     for (int i = 0; i < a.nsrc; ++i)
         if (sc[i] % ck) return hipErrorInvalidValue;
-    if (a.CoutP % (a.ntile ? a.ntile : conv_ntile(a.Cout))) return hipErrorInvalidValue;
+    if (a.cfg == CFG_AUTO) a.cfg = conv_pick_cfg(a.Cout, a.CoutP, ks, stride, a.B, a.Hout, a.Wout);
     if (ks == 3 && stride == 1) {
-        return ck == 32 ? launch_tile<3, 1, 32>(a, st, resolved) : launch_tile<3, 1, 16>(a, st, resolved);
+        return ck == 32 ? launch_shape<3, 1, 32>(a, st, resolved) : launch_shape<3, 1, 16>(a, st, resolved);
     } else if (ks == 3 && stride == 2) {
-        return launch_tile<3, 2, 16>(a, st, resolved);
+        return launch_shape<3, 2, 16>(a, st, resolved);
     } else if (ks == 1 && stride == 1) {
-        return ck == 32 ? launch_tile<1, 1, 32>(a, st, resolved) : launch_tile<1, 1, 16>(a, st, resolved);
+        return ck == 32 ? launch_shape<1, 1, 32>(a, st, resolved) : launch_shape<1, 1, 16>(a, st, resolved);
     }
     return hipErrorInvalidValue;
 }

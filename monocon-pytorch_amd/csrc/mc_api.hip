@@ -6,6 +6,7 @@
 // activation buffers) is built per input shape and replayed on the caller's stream.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -38,7 +39,7 @@ struct Tensor {   // NHWC activation
 
 struct ConvLayer {
     std::string conv, bn;   // state_dict prefixes ("" bn => bias-only / raw)
-    int ks = 1, stride = 1, cin = 0, cout = 0, coutp = 0, ntile = 0;
+    int ks = 1, stride = 1, cin = 0, cout = 0, coutp = 0, cfg = 0;
     float bn_eps = 1e-5f;
     float *wpk = nullptr, *scale = nullptr, *shift = nullptr;
 };
@@ -99,6 +100,7 @@ struct mc_handle {
     Plan *last_plan = nullptr;
     float *decode_filt = nullptr;
     size_t decode_filt_n = 0;
+    int force_cfg = 0;   // tuning aid (mc_bench_conv)
 };
 
 static std::string g_create_err;
@@ -201,7 +203,7 @@ static int build_layers(mc_handle *h) {
     if (dev_alloc(h, &h->stem_shift, 16, h->param_bufs, h->param_bytes)) return -1;
     ConvLayer &H3 = h->head3;
     H3.conv = "head.*.0"; H3.ks = 3; H3.stride = 1; H3.cin = 64; H3.cout = NUM_HEADS * HEAD_CH;
-    H3.ntile = 64;             // one head per 64-column tile
+    H3.cfg = CFG_128x64m;      // one head per 64-column tile
     H3.coutp = H3.cout;
     if (dev_alloc(h, &H3.wpk, (size_t)9 * 64 * H3.coutp, h->param_bufs, h->param_bytes)) return -1;
     if (dev_alloc(h, &h->head_bias, H3.cout, h->param_bufs, h->param_bytes)) return -1;
@@ -285,8 +287,8 @@ struct Builder {
         a.out = out.p; a.out_ld = out.C; a.out_coff = 0;
         a.relu = relu ? 1 : 0;
         const int ppr = (Wo + 7) / 8, ppi = ppr * ((Ho + 3) / 4);
-        a.ntile = L.ntile;
-        const int pb = conv_patches_per_block(L.ntile ? L.ntile : conv_ntile(L.cout), L.stride);
+        a.cfg = L.cfg ? L.cfg : (h->force_cfg ? h->force_cfg : conv_pick_cfg(L.cout, L.coutp, L.ks, L.stride, s0.B, Ho, Wo));
+        const int pb = conv_patches_per_block(a.cfg);
         const int chunks = (ppi + pb - 1) / pb;
         if (stats_out) {
             *stats_out = alloc_raw((size_t)s0.B * chunks * L.coutp * 2);
@@ -471,6 +473,33 @@ static int run_op(mc_handle *h, const Op &op, hipStream_t st) {
 }
 
 // ================================================================================== C ABI
+// Tuning aid: sustained rate of v_mfma_f32_32x32x2_f32 with no memory traffic (the practical
+// ceiling the conv kernel is measured against on this box: clocks follow the power budget).
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float *out, int iters, float seed) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    // seed > 0: nearly constant operands (low toggle rate); seed < 0: full-range pseudo-random
+    // operands refreshed every MFMA group (DVFS: random data draws more power, lower clocks)
+    unsigned ua = 1234567u + threadIdx.x * 7919u + blockIdx.x * 104729u, ub = ua * 2654435761u;
+    float a = fabsf(seed) + threadIdx.x * 1e-3f, b = fabsf(seed) * 0.5f + threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+        if (seed < 0.f) {
+            ua = ua * 1664525u + 1013904223u;
+            ub = ub * 22695477u + 1u;
+            a = __uint_as_float((ua >> 9) | 0x3F800000u) - 1.5f;
+            b = __uint_as_float((ub >> 9) | 0x3F800000u) - 1.5f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 3], 0, 0, 0);
+        if (seed >= 0.f) a += 1e-6f;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) out[0] = s;
+}
+
 extern "C" {
 
 int mc_version(void) { return 1; }
@@ -756,6 +785,86 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
     if (!in || !out) return fail(h, "mc_op_nhwc_to_nchw: null argument");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, launch_nhwc_to_nchw(in, B, C, H, W, out, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int mc_bench_mfma_peak(mc_handle *h, int waves_per_simd, int iters, float *tflops) {
+    if (!h || !tflops) return fail(h, "mc_bench_mfma_peak: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    void *out = nullptr;
+    HIPCHK(h, hipMalloc(&out, 64));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    const int blocks = 256 * (waves_per_simd < 0 ? -waves_per_simd : waves_per_simd);   // < 0: random operands
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, (float *)out, 100, waves_per_simd < 0 ? -1.0f : 1.0f);
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, (float *)out, iters, waves_per_simd < 0 ? -1.0f : 1.0f);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *tflops = (float)((double)blocks * 4 * iters * 16 * 4096.0 / (ms * 1e-3) / 1e12);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return 0;
+}
+
+// Tuning aid: time one fused conv launch shape on synthetic data (random, non-zero operands).
+int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src_channels[], int Cout, int ksize,
+                  int stride, int cfg, int iters, float *ms_avg) {
+    if (!h || !src_channels || !ms_avg) return fail(h, "mc_bench_conv: null argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    ConvArgs a{};
+    int cin = 0;
+    std::vector<void *> bufs;
+    auto alloc_fill = [&](size_t n, float scale) -> float * {
+        void *q = nullptr;
+        if (hipMalloc(&q, n * sizeof(float)) != hipSuccess) return nullptr;
+        bufs.push_back(q);
+        std::vector<float> hst(std::min<size_t>(n, (size_t)1 << 22));
+        unsigned s = 12345u + (unsigned)bufs.size();
+        for (auto &v : hst) { s = s * 1664525u + 1013904223u; v = scale * (((s >> 8) & 0xFFFF) / 32768.0f - 1.0f); }
+        for (size_t off = 0; off < n; off += hst.size())
+            (void)hipMemcpy((float *)q + off, hst.data(), std::min(hst.size(), n - off) * sizeof(float), hipMemcpyHostToDevice);
+        return (float *)q;
+    };
+    for (int i = 0; i < nsrc; ++i) {
+        a.src[i].C = src_channels[i];
+        a.src[i].p = alloc_fill((size_t)B * Hin * Win * src_channels[i], 1.0f);
+        if (!a.src[i].p) return fail(h, "mc_bench_conv: out of memory");
+        cin += src_channels[i];
+    }
+    a.nsrc = nsrc;
+    a.B = B; a.Hin = Hin; a.Win = Win;
+    a.Hout = (Hin + 2 * (ksize / 2) - ksize) / stride + 1;
+    a.Wout = (Win + 2 * (ksize / 2) - ksize) / stride + 1;
+    a.Cin = cin; a.Cout = Cout; a.CoutP = conv_coutp(Cout);
+    a.wpk = alloc_fill((size_t)ksize * ksize * cin * a.CoutP, 0.05f);
+    a.scale = alloc_fill(Cout, 1.0f);
+    a.bias = alloc_fill(Cout, 1.0f);
+    a.out = alloc_fill((size_t)B * a.Hout * a.Wout * Cout, 0.0f);
+    if (!a.wpk || !a.scale || !a.bias || !a.out) return fail(h, "mc_bench_conv: out of memory");
+    a.out_ld = Cout; a.relu = 1; a.cfg = cfg;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    hipError_t e = launch_conv(a, ksize, stride, nullptr);
+    if (e == hipSuccess) e = launch_conv(a, ksize, stride, nullptr);
+    if (e == hipSuccess) {
+        (void)hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_conv(a, ksize, stride, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *ms_avg = ms / iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    for (void *q : bufs) (void)hipFree(q);
+    HIPCHK(h, e);
     return 0;
 }
 

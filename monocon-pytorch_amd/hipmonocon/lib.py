@@ -16,7 +16,7 @@ EXPORTS = (
     "mc_create", "mc_destroy", "mc_last_error", "mc_version", "mc_bind_params", "mc_pack_params",
     "mc_forward_infer", "mc_decode", "mc_op_conv", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
     "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_forward_cost",
-    "mc_profile_forward",
+    "mc_profile_forward", "mc_bench_conv", "mc_bench_mfma_peak",
 )
 
 
@@ -62,6 +62,8 @@ def load():
     lib.mc_workspace_bytes.restype = C.c_size_t
     lib.mc_forward_cost.argtypes = [vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mc_profile_forward.argtypes = [vp, i, fp, C.POINTER(i), vp]
+    lib.mc_bench_mfma_peak.argtypes = [vp, i, i, fp]
+    lib.mc_bench_conv.argtypes = [vp, i, i, i, i, C.POINTER(i), i, i, i, i, i, fp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int or name not in ("mc_last_error", "mc_workspace_bytes"):
