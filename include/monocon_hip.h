@@ -55,7 +55,8 @@ int mc_version(void);
 /* ---- parameters -------------------------------------------------------------------- */
 /* Replaces nn.Module parameter ownership: MonoConDetector.state_dict()/load_state_dict()
  * (model/detector/monocon_detector.py:80-82, engine/base_engine.py:178,208).  Binds the
- * caller-owned master tensors (all 449 keys must be present). */
+ * caller-owned master tensors.  A stage can be used once all keys of its group (backbone. /
+ * neck. / head.) are bound; mc_forward_infer needs all 449. */
 int mc_bind_params(mc_handle *h, const mc_tensor_desc *descs, int n);
 /* Re-derive the device-side packed weights (OIHW -> K-major MFMA panels) and, for eval
  * mode, the folded BatchNorm scale/shift.  Call after binding and after any parameter
@@ -71,6 +72,22 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream);
  * feat_nchw (optional, may be NULL): (B,64,H/4,W/4) copy of the neck output. */
 int mc_forward_infer(mc_handle *h, const float *img, int B, int H, int W,
                      float *const preds[MC_NUM_PREDS], float *feat_nchw, void *stream);
+
+/* ---- stage-level forwards (eval mode) ---------------------------------------------------
+ * Sub-module parity for callers that use the reference's modules on their own; the detector
+ * itself uses mc_forward_infer (no NCHW round trips between stages).  (H, W) = image size.
+ * mc_backbone_forward replaces DLA.forward (model/backbone/dla.py:273-278): levels[i] is
+ *   (B, {16,32,64,128,256,512}[i], H/{1,2,4,8,16,32}[i], W/...) NCHW or NULL to skip it.
+ * mc_neck_forward replaces DLAUp.forward (model/backbone/dla_neck.py:136-143): reads
+ *   levels[2..5], writes feat (B,64,H/4,W/4).
+ * mc_head_forward replaces MonoConDenseHeads._get_predictions
+ *   (model/dense_heads/monocon_heads.py:165-200). */
+int mc_backbone_forward(mc_handle *h, const float *img, int B, int H, int W,
+                        float *const levels[6], void *stream);
+int mc_neck_forward(mc_handle *h, const float *const levels[6], int B, int H, int W,
+                    float *feat, void *stream);
+int mc_head_forward(mc_handle *h, const float *feat, int B, int H, int W,
+                    float *const preds[MC_NUM_PREDS], void *stream);
 
 /* ---- decode -------------------------------------------------------------------------
  * Replaces MonoConDenseHeads.decode_heatmap + _get_bboxes origin shift
@@ -88,6 +105,39 @@ int mc_decode(mc_handle *h, const float *const preds[MC_NUM_PREDS], const float 
               float pad_h, float pad_w, float *scores, int64_t *flat_index, int64_t *cls,
               float *box2d, float *box3d, uint8_t *keep_localmax, uint8_t *keep_thr,
               void *stream);
+
+/* ---- training: targets and losses ---------------------------------------------------------
+ * Label tensors exactly as the reference's collate_fn delivers them (all float32, device):
+ * gt_bboxes (B,M,4), gt_labels (B,M), gt_bboxes_3d (B,M,7), depths (B,M), gt_kpts_2d (B,M,18),
+ * gt_kpts_valid_mask (B,M,9), mask (B,M)   (dataset/monocon_dataset.py:160-171). */
+typedef struct mc_labels {
+    const float *gt_bboxes, *gt_labels, *gt_bboxes_3d, *depths, *gt_kpts_2d, *gt_kpts_valid_mask, *mask;
+} mc_labels;
+/* The 15 target tensors of reference utils/target_generator.py:152-177 (caller-allocated, device):
+ * heat-maps (B,3,h,w)/(B,9,h,w) f32; regression targets (B,M,{2,2,3,1,1,1,18,18}) f32; indices (B,M)
+ * and indices_kpt (B,9M) i64; mask_target (B,M) u8/bool; the two keypoint masks (B,M,18) f32. */
+typedef struct mc_targets {
+    float *center_heatmap_target, *wh_target, *offset_target, *dim_target, *alpha_cls_target,
+        *alpha_offset_target, *depth_target, *center2kpt_offset_target, *kpt_heatmap_target,
+        *kpt_heatmap_offset_target;
+    int64_t *indices, *indices_kpt;
+    uint8_t *mask_target;
+    float *mask_center2kpt_offset, *mask_kpt_heatmap_offset;
+} mc_targets;
+/* Replaces TargetGenerator.__call__ (utils/target_generator.py:30-138) and the gaussian helpers
+ * (utils/tensor_ops.py:62-125): one launch instead of a Python loop over batch x objects x 9. */
+int mc_make_targets(mc_handle *h, const mc_labels *labels, int B, int max_objs, int pad_h,
+                    int pad_w, int feat_h, int feat_w, const mc_targets *targets, void *stream);
+/* Replaces MonoConDenseHeads._get_losses + losses/*.py (model/dense_heads/monocon_heads.py:203-310):
+ * losses[10] (device) in the reference's loss_dict order: center_heatmap, wh, offset, dim,
+ * center2kpt_offset, kpt_heatmap, kpt_heatmap_offset, alpha_cls, alpha_reg, depth. */
+int mc_losses(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *targets,
+              int B, int max_objs, int feat_h, int feat_w, float *losses, void *stream);
+/* Gradient of sum_i grad_losses[i] * loss_i (grad_losses: device [10]) with respect to the RAW
+ * 1x1-conv outputs behind each prediction map (i.e. through sigmoid+clamp / the depth transform). */
+int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS],
+                       const mc_targets *targets, int B, int max_objs, int feat_h, int feat_w,
+                       const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream);
 
 /* ---- op-level entry points (unit parity tests; same kernels the forward uses) -------
  * Fused convolution, NHWC fp32: out = act(conv(cat(src...)) * scale + bias + residual).

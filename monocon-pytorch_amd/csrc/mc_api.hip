@@ -21,105 +21,9 @@
 #include "conv_mfma.h"
 #include "kernels.h"
 
-using namespace mc;
+#include "mc_internal.h"
 
-namespace {
-
-struct Bound {
-    void *ptr;
-    int64_t numel;
-    int dtype;
-};
-
-struct Tensor {   // NHWC activation
-    float *p = nullptr;
-    int B = 0, H = 0, W = 0, C = 0;
-    size_t numel() const { return (size_t)B * H * W * C; }
-};
-
-struct ConvLayer {
-    std::string conv, bn;   // state_dict prefixes ("" bn => bias-only / raw)
-    int ks = 1, stride = 1, cin = 0, cout = 0, coutp = 0, cfg = 0;
-    float bn_eps = 1e-5f;
-    float *wpk = nullptr, *scale = nullptr, *shift = nullptr;
-};
-
-struct DeconvLayer {
-    std::string name;
-    int C = 0;
-    float *wpk = nullptr;
-};
-
-enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_DECONV, OP_HEAD_ATTN, OP_HEAD_APPLY, OP_TO_NCHW };
-
-struct Op {
-    OpKind kind;
-    // conv
-    ConvArgs ca{};
-    int ks = 0, stride = 0;
-    // generic
-    const float *in = nullptr;
-    float *out = nullptr;
-    const float *w = nullptr, *scale = nullptr, *shift = nullptr;
-    int B = 0, H = 0, W = 0, C = 0;
-    int chunks = 0;
-    HeadApplyArgs ha{};
-    double flops = 0, bytes = 0;
-};
-
-struct Plan {
-    int B = 0, H = 0, W = 0;
-    std::vector<Op> ops;
-    std::vector<void *> bufs;
-    size_t bytes = 0;
-    Tensor feat;
-    int stem_op = -1, head_apply_op = -1;
-    double flops = 0, hbm_bytes = 0;
-};
-
-}  // namespace
-
-struct mc_handle {
-    int device = 0;
-    std::string err;
-    std::unordered_map<std::string, Bound> bound;
-    std::map<std::string, ConvLayer> convs;
-    std::map<std::string, DeconvLayer> deconvs;
-    // stem
-    float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
-    // fused head 3x3 (64 -> 9*64) and second pass
-    ConvLayer head3;
-    float *head_bias = nullptr, *head_rm = nullptr;
-    float *att_scale = nullptr, *att_shift = nullptr;   // [9][10]
-    float *head_w1 = nullptr, *head_w1t = nullptr, *head_b1 = nullptr;   // [65][64], transposed [64][65], [65]
-    HeadAttnParams hap{};
-    bool layers_built = false, packed = false;
-    size_t param_bytes = 0;
-    std::vector<void *> param_bufs;
-    std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
-    Plan *last_plan = nullptr;
-    float *decode_filt = nullptr;
-    size_t decode_filt_n = 0;
-    int force_cfg = 0;   // tuning aid (mc_bench_conv)
-};
-
-static std::string g_create_err;
-
-static int fail(mc_handle *h, const char *fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (h) h->err = buf; else g_create_err = buf;
-    return -1;
-}
-
-#define HIPCHK(h, expr)                                                                       \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+std::string g_create_err;
 
 static const char *HEAD_NAMES[NUM_HEADS] = {"heatmap_head", "wh_head", "offset_head", "center2kpt_offset_head",
                                             "kpt_heatmap_head", "kpt_heatmap_offset_head", "dim_head", "depth_head",
@@ -387,6 +291,8 @@ static Plan *get_plan(mc_handle *h, int B, int H, int W) {
     Tensor l3 = bd.tree("backbone.level3", 2, 64, 128, 2, true, l2, {});
     Tensor l4 = bd.tree("backbone.level4", 2, 128, 256, 2, true, l3, {});
     Tensor l5 = bd.tree("backbone.level5", 1, 256, 512, 2, true, l4, {});
+    pl->n_backbone_ops = (int)pl->ops.size();
+    { Tensor lv[6] = {l0, l1, l2, l3, l4, l5}; for (int i = 0; i < 6; ++i) pl->lv[i] = lv[i]; }
 
     // DLAUp (reference dla_neck.py:94-106,136-143): layers = [l2,l3,l4,l5]
     std::vector<Tensor> layers = {l2, l3, l4, l5};
@@ -402,6 +308,7 @@ static Plan *get_plan(mc_handle *h, int B, int H, int W) {
     }
     Tensor feat = layers[3];
     pl->feat = feat;
+    pl->n_neck_ops = (int)pl->ops.size();
 
     // heads pass 1: fused 3x3 64 -> 9x64 (+bias) with per-(image,channel) statistics
     float *stats = nullptr;
@@ -530,6 +437,7 @@ int mc_destroy(mc_handle *h) {
         for (void *q : kv.second->bufs) (void)hipFree(q);
     for (void *q : h->param_bufs) (void)hipFree(q);
     if (h->decode_filt) (void)hipFree(h->decode_filt);
+    if (h->loss_ws) (void)hipFree(h->loss_ws);
     delete h;
     return 0;
 }
@@ -555,8 +463,14 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
 #define NEEDP(var, name, numel)                    \
     float *var = P(h, (name), (numel));            \
     if (!var) return -1;
+    const bool has_bb = h->bound.count("backbone.base_layer.0.weight") != 0;
+    const bool has_neck = h->bound.count("neck.ida_0.proj_1.conv.weight") != 0;
+    const bool has_head = h->bound.count("head.heatmap_head.0.weight") != 0;
+    if (!has_bb && !has_neck && !has_head) return fail(h, "mc_pack_params: no backbone./neck./head. parameters bound");
     for (auto &kv : h->convs) {
         ConvLayer &L = kv.second;
+        const bool is_bb = L.conv.compare(0, 9, "backbone.") == 0;
+        if ((is_bb && !has_bb) || (!is_bb && !has_neck)) continue;
         NEEDP(w, L.conv + ".weight", (int64_t)L.cout * L.cin * L.ks * L.ks);
         HIPCHK(h, launch_pack_conv_w(w, L.cout, L.cin, L.ks, L.wpk, L.cin, L.coutp, 0, 0, st));
         NEEDP(g, L.bn + ".weight", L.cout);
@@ -566,10 +480,11 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         HIPCHK(h, launch_fold_bn(g, b, rm, rv, 1e-5f, L.cout, L.scale, L.shift, st));
     }
     for (auto &kv : h->deconvs) {
+        if (!has_neck) break;
         NEEDP(w, kv.second.name + ".weight", (int64_t)kv.second.C * 16);
         HIPCHK(h, launch_pack_deconv_w(w, kv.second.C, kv.second.wpk, st));
     }
-    {
+    if (has_bb) {
         NEEDP(w, "backbone.base_layer.0.weight", 16 * 147);
         HIPCHK(h, launch_pack_stem_w(w, h->stem_w, st));
         NEEDP(g, "backbone.base_layer.1.weight", 16);
@@ -582,7 +497,7 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
     const HeadRow *rows = head_rows();
     const int *rb = head_row_begin();
     (void)rows;
-    for (int hd = 0; hd < NUM_HEADS; ++hd) {
+    for (int hd = 0; hd < NUM_HEADS && has_head; ++hd) {
         const std::string pre = std::string("head.") + HEAD_NAMES[hd];
         NEEDP(w3, pre + ".0.weight", 64 * 64 * 9);
         NEEDP(b3, pre + ".0.bias", 64);
@@ -626,9 +541,10 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         }
     }
     // [65][64] -> [64][65]: the second head pass reads one input channel against all rows of a head
-    HIPCHK(h, launch_nchw_to_nhwc(h->head_w1, 1, NUM_OUT_ROWS, 1, HEAD_CH, h->head_w1t, st));
+    if (has_head) HIPCHK(h, launch_nchw_to_nhwc(h->head_w1, 1, NUM_OUT_ROWS, 1, HEAD_CH, h->head_w1t, st));
 #undef NEEDP
-    h->packed = true;
+    h->packed_groups = (has_bb ? 1 : 0) | (has_neck ? 2 : 0) | (has_head ? 4 : 0);
+    h->packed = h->packed_groups == 7;
     return 0;
 }
 
@@ -652,6 +568,73 @@ int mc_forward_infer(mc_handle *h, const float *img, int B, int H, int W, float 
     for (const Op &op : pl->ops)
         if (run_op(h, op, st)) return -1;
     if (feat_nchw) HIPCHK(h, launch_nhwc_to_nchw(pl->feat.p, B, pl->feat.C, pl->feat.H, pl->feat.W, feat_nchw, st));
+    return 0;
+}
+
+// ---- stage-level forwards (sub-module API parity: DLA.forward / DLAUp.forward / head._get_predictions)
+static Plan *stage_plan(mc_handle *h, int need_groups, int B, int H, int W, const char *who) {
+    if (B < 1 || H < 32 || W < 32 || (H % 32) || (W % 32)) {
+        fail(h, "%s: bad shape B=%d H=%d W=%d (H, W must be multiples of 32)", who, B, H, W);
+        return nullptr;
+    }
+    if ((h->packed_groups & need_groups) != need_groups) {
+        fail(h, "%s: parameters of this stage are not bound/packed", who);
+        return nullptr;
+    }
+    if (hipSetDevice(h->device) != hipSuccess) { fail(h, "%s: hipSetDevice failed", who); return nullptr; }
+    Plan *pl = get_plan(h, B, H, W);
+    if (pl) h->last_plan = pl;
+    return pl;
+}
+
+int mc_backbone_forward(mc_handle *h, const float *img, int B, int H, int W, float *const levels[6], void *stream) {
+    if (!h) return -1;
+    if (!img || !levels) return fail(h, "mc_backbone_forward: null argument");
+    Plan *pl = stage_plan(h, 1, B, H, W, "mc_backbone_forward");
+    if (!pl) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    pl->ops[pl->stem_op].in = img;
+    for (int i = 0; i < pl->n_backbone_ops; ++i)
+        if (run_op(h, pl->ops[i], st)) return -1;
+    for (int i = 0; i < 6; ++i)
+        if (levels[i]) {
+            const Tensor &t = pl->lv[i];
+            HIPCHK(h, launch_nhwc_to_nchw(t.p, t.B, t.C, t.H, t.W, levels[i], st));
+        }
+    return 0;
+}
+
+int mc_neck_forward(mc_handle *h, const float *const levels[6], int B, int H, int W, float *feat, void *stream) {
+    if (!h) return -1;
+    if (!levels || !feat) return fail(h, "mc_neck_forward: null argument");
+    Plan *pl = stage_plan(h, 2, B, H, W, "mc_neck_forward");
+    if (!pl) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int i = 2; i < 6; ++i) {
+        if (!levels[i]) return fail(h, "mc_neck_forward: levels[%d] is NULL", i);
+        const Tensor &t = pl->lv[i];
+        HIPCHK(h, launch_nchw_to_nhwc(levels[i], t.B, t.C, t.H, t.W, t.p, st));
+    }
+    for (int i = pl->n_backbone_ops; i < pl->n_neck_ops; ++i)
+        if (run_op(h, pl->ops[i], st)) return -1;
+    HIPCHK(h, launch_nhwc_to_nchw(pl->feat.p, B, pl->feat.C, pl->feat.H, pl->feat.W, feat, st));
+    return 0;
+}
+
+int mc_head_forward(mc_handle *h, const float *feat, int B, int H, int W, float *const preds[MC_NUM_PREDS],
+                    void *stream) {
+    if (!h) return -1;
+    if (!feat || !preds) return fail(h, "mc_head_forward: null argument");
+    Plan *pl = stage_plan(h, 4, B, H, W, "mc_head_forward");
+    if (!pl) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(h, launch_nchw_to_nhwc(feat, B, pl->feat.C, pl->feat.H, pl->feat.W, pl->feat.p, st));
+    for (int i = 0; i < MC_NUM_PREDS; ++i) {
+        if (!preds[i]) return fail(h, "mc_head_forward: preds[%d] is NULL", i);
+        pl->ops[pl->head_apply_op].ha.pred[i] = preds[i];
+    }
+    for (int i = pl->n_neck_ops; i < (int)pl->ops.size(); ++i)
+        if (run_op(h, pl->ops[i], st)) return -1;
     return 0;
 }
 

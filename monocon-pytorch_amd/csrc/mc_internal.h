@@ -1,0 +1,117 @@
+// Internal definitions shared by the C-ABI translation units (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/monocon_hip.h"
+#include "conv_mfma.h"
+#include "kernels.h"
+#include "train.h"
+
+using namespace mc;
+
+struct Bound {
+    void *ptr;
+    int64_t numel;
+    int dtype;
+};
+
+struct Tensor {   // NHWC activation
+    float *p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t numel() const { return (size_t)B * H * W * C; }
+};
+
+struct ConvLayer {
+    std::string conv, bn;   // state_dict prefixes ("" bn => bias-only / raw)
+    int ks = 1, stride = 1, cin = 0, cout = 0, coutp = 0, cfg = 0;
+    float bn_eps = 1e-5f;
+    float *wpk = nullptr, *scale = nullptr, *shift = nullptr;
+};
+
+struct DeconvLayer {
+    std::string name;
+    int C = 0;
+    float *wpk = nullptr;
+};
+
+enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_DECONV, OP_HEAD_ATTN, OP_HEAD_APPLY, OP_TO_NCHW };
+
+struct Op {
+    OpKind kind;
+    // conv
+    ConvArgs ca{};
+    int ks = 0, stride = 0;
+    // generic
+    const float *in = nullptr;
+    float *out = nullptr;
+    const float *w = nullptr, *scale = nullptr, *shift = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    int chunks = 0;
+    HeadApplyArgs ha{};
+    double flops = 0, bytes = 0;
+};
+
+struct Plan {
+    int B = 0, H = 0, W = 0;
+    std::vector<Op> ops;
+    std::vector<void *> bufs;
+    size_t bytes = 0;
+    Tensor feat, lv[6];
+    int stem_op = -1, head_apply_op = -1;
+    int n_backbone_ops = 0, n_neck_ops = 0;
+    double flops = 0, hbm_bytes = 0;
+};
+
+struct mc_handle {
+    int device = 0;
+    std::string err;
+    std::unordered_map<std::string, Bound> bound;
+    std::map<std::string, ConvLayer> convs;
+    std::map<std::string, DeconvLayer> deconvs;
+    // stem
+    float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
+    // fused head 3x3 (64 -> 9*64) and second pass
+    ConvLayer head3;
+    float *head_bias = nullptr, *head_rm = nullptr;
+    float *att_scale = nullptr, *att_shift = nullptr;   // [9][10]
+    float *head_w1 = nullptr, *head_w1t = nullptr, *head_b1 = nullptr;   // [65][64], transposed [64][65], [65]
+    HeadAttnParams hap{};
+    bool layers_built = false, packed = false;
+    int packed_groups = 0;   // bit0 backbone, bit1 neck, bit2 head
+    size_t param_bytes = 0;
+    std::vector<void *> param_bufs;
+    std::map<std::tuple<int, int, int>, std::unique_ptr<Plan>> plans;
+    Plan *last_plan = nullptr;
+    float *decode_filt = nullptr;
+    size_t decode_filt_n = 0;
+    int force_cfg = 0;   // tuning aid (mc_bench_conv)
+    float *loss_ws = nullptr;   // focal partials + small reduction scratch
+};
+
+extern std::string g_create_err;
+
+static inline int fail(mc_handle *h, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_err = buf;
+    return -1;
+}
+
+#define HIPCHK(h, expr)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+

@@ -1,0 +1,131 @@
+// Training-side C-ABI: target generation, losses (+ gradients wrt the prediction maps).
+#include "mc_internal.h"
+
+static int check_targets(mc_handle *h, const mc_targets *t, const char *who) {
+    if (!t) return fail(h, "%s: targets is NULL", who);
+    const void *p[] = {t->center_heatmap_target, t->wh_target, t->offset_target, t->dim_target, t->alpha_cls_target,
+                       t->alpha_offset_target, t->depth_target, t->center2kpt_offset_target, t->kpt_heatmap_target,
+                       t->kpt_heatmap_offset_target, t->indices, t->indices_kpt, t->mask_target,
+                       t->mask_center2kpt_offset, t->mask_kpt_heatmap_offset};
+    for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i)
+        if (!p[i]) return fail(h, "%s: targets field %d is NULL", who, (int)i);
+    return 0;
+}
+
+extern "C" {
+
+int mc_make_targets(mc_handle *h, const mc_labels *lab, int B, int max_objs, int pad_h, int pad_w, int fh, int fw,
+                    const mc_targets *t, void *stream) {
+    if (!h) return -1;
+    if (!lab || !lab->gt_bboxes || !lab->gt_labels || !lab->gt_bboxes_3d || !lab->depths || !lab->gt_kpts_2d ||
+        !lab->gt_kpts_valid_mask || !lab->mask)
+        return fail(h, "mc_make_targets: a label pointer is NULL");
+    if (check_targets(h, t, "mc_make_targets")) return -1;
+    if (B < 1 || max_objs < 1 || fh < 1 || fw < 1 || pad_h < 1 || pad_w < 1)
+        return fail(h, "mc_make_targets: bad shape");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t HW = (size_t)fh * fw, R = (size_t)B * max_objs;
+    HIPCHK(h, hipMemsetAsync(t->center_heatmap_target, 0, B * 3 * HW * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->kpt_heatmap_target, 0, B * 9 * HW * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->wh_target, 0, R * 2 * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->offset_target, 0, R * 2 * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->dim_target, 0, R * 3 * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->alpha_cls_target, 0, R * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->alpha_offset_target, 0, R * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->depth_target, 0, R * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->center2kpt_offset_target, 0, R * 18 * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->kpt_heatmap_offset_target, 0, R * 18 * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->indices, 0, R * 8, st));
+    HIPCHK(h, hipMemsetAsync(t->indices_kpt, 0, R * 9 * 8, st));
+    HIPCHK(h, hipMemsetAsync(t->mask_target, 0, R, st));
+    HIPCHK(h, hipMemsetAsync(t->mask_center2kpt_offset, 0, R * 18 * 4, st));
+    HIPCHK(h, hipMemsetAsync(t->mask_kpt_heatmap_offset, 0, R * 18 * 4, st));
+    mc::TargetArgs a{};
+    a.gt_bboxes = lab->gt_bboxes; a.gt_labels = lab->gt_labels; a.gt_bboxes_3d = lab->gt_bboxes_3d;
+    a.depths = lab->depths; a.gt_kpts_2d = lab->gt_kpts_2d; a.gt_kpts_valid = lab->gt_kpts_valid_mask; a.mask = lab->mask;
+    a.B = B; a.max_objs = max_objs; a.num_kpt = 9; a.num_classes = 3; a.fh = fh; a.fw = fw;
+    a.h_ratio = (float)((double)fh / (double)pad_h);
+    a.w_ratio = (float)((double)fw / (double)pad_w);
+    a.center_heatmap = t->center_heatmap_target; a.kpt_heatmap = t->kpt_heatmap_target;
+    a.wh = t->wh_target; a.offset = t->offset_target; a.dim = t->dim_target; a.alpha_cls = t->alpha_cls_target;
+    a.alpha_offset = t->alpha_offset_target; a.depth = t->depth_target; a.c2k = t->center2kpt_offset_target;
+    a.kho = t->kpt_heatmap_offset_target;
+    a.indices = reinterpret_cast<long long *>(t->indices);
+    a.indices_kpt = reinterpret_cast<long long *>(t->indices_kpt);
+    a.mask_target = t->mask_target; a.mask_c2k = t->mask_center2kpt_offset; a.mask_kho = t->mask_kpt_heatmap_offset;
+    HIPCHK(h, mc::launch_make_targets(a, st));
+    return 0;
+}
+
+static int ensure_loss_ws(mc_handle *h) {
+    if (h->loss_ws) return 0;
+    void *q = nullptr;
+    const size_t n = (size_t)2 * mc::focal_partial_floats() + 64;
+    HIPCHK(h, hipMalloc(&q, n * sizeof(float)));
+    h->loss_ws = static_cast<float *>(q);
+    return 0;
+}
+
+static void fill_gather_args(mc::GatherLossArgs &g, const float *const preds[10], float *const dpreds[10],
+                             const mc_targets *t, int B, int max_objs, int HW, float *losses, float *aux,
+                             const float *gscale) {
+    for (int i = 0; i < 10; ++i) { g.pred[i] = preds[i]; g.dpred[i] = dpreds ? dpreds[i] : nullptr; }
+    g.indices = reinterpret_cast<const long long *>(t->indices);
+    g.indices_kpt = reinterpret_cast<const long long *>(t->indices_kpt);
+    g.mask_target = t->mask_target;
+    g.wh = t->wh_target; g.offset = t->offset_target; g.dim = t->dim_target; g.alpha_cls = t->alpha_cls_target;
+    g.alpha_offset = t->alpha_offset_target; g.depth = t->depth_target; g.c2k = t->center2kpt_offset_target;
+    g.kho = t->kpt_heatmap_offset_target; g.mask_c2k = t->mask_center2kpt_offset; g.mask_kho = t->mask_kpt_heatmap_offset;
+    g.B = B; g.max_objs = max_objs; g.HW = HW; g.losses = losses; g.aux = aux; g.gscale = gscale;
+}
+
+int mc_losses(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *t, int B, int max_objs, int fh,
+              int fw, float *losses, void *stream) {
+    if (!h) return -1;
+    if (!preds || !losses) return fail(h, "mc_losses: null argument");
+    for (int i = 0; i < MC_NUM_PREDS; ++i)
+        if (!preds[i]) return fail(h, "mc_losses: preds[%d] is NULL", i);
+    if (check_targets(h, t, "mc_losses")) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (ensure_loss_ws(h)) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t HW = (size_t)fh * fw;
+    const int npf = mc::focal_partial_floats();
+    float *aux = h->loss_ws + 2 * npf;   // [0] npos center, [1] npos kpt, [2] n objects
+    HIPCHK(h, mc::launch_focal(preds[0], t->center_heatmap_target, (size_t)B * 3 * HW, h->loss_ws, losses + 0, aux + 0, st));
+    HIPCHK(h, mc::launch_focal(preds[1], t->kpt_heatmap_target, (size_t)B * 9 * HW, h->loss_ws + npf, losses + 5, aux + 1, st));
+    mc::GatherLossArgs g{};
+    fill_gather_args(g, preds, nullptr, t, B, max_objs, (int)HW, losses, aux + 2, nullptr);
+    HIPCHK(h, mc::launch_gathered_losses(g, 0, st));
+    return 0;
+}
+
+int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *t, int B, int max_objs,
+                       int fh, int fw, const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream) {
+    if (!h) return -1;
+    if (!preds || !dpreds || !grad_losses) return fail(h, "mc_losses_backward: null argument");
+    for (int i = 0; i < MC_NUM_PREDS; ++i)
+        if (!preds[i] || !dpreds[i]) return fail(h, "mc_losses_backward: preds/dpreds[%d] is NULL", i);
+    if (check_targets(h, t, "mc_losses_backward")) return -1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (ensure_loss_ws(h)) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t HW = (size_t)fh * fw;
+    const int npf = mc::focal_partial_floats();
+    float *aux = h->loss_ws + 2 * npf;
+    float *scratch_losses = aux + 8;
+    static const int PC[10] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
+    // recompute the reductions the gradients need (npos, object count, dim compensation weight)
+    HIPCHK(h, mc::launch_focal(preds[0], t->center_heatmap_target, (size_t)B * 3 * HW, h->loss_ws, scratch_losses + 0, aux + 0, st));
+    HIPCHK(h, mc::launch_focal(preds[1], t->kpt_heatmap_target, (size_t)B * 9 * HW, h->loss_ws + npf, scratch_losses + 5, aux + 1, st));
+    for (int i = 2; i < 10; ++i) HIPCHK(h, hipMemsetAsync(dpreds[i], 0, (size_t)B * PC[i] * HW * 4, st));
+    HIPCHK(h, mc::launch_focal_grad(preds[0], t->center_heatmap_target, (size_t)B * 3 * HW, aux + 0, grad_losses, 0, dpreds[0], st));
+    HIPCHK(h, mc::launch_focal_grad(preds[1], t->kpt_heatmap_target, (size_t)B * 9 * HW, aux + 1, grad_losses, 5, dpreds[1], st));
+    mc::GatherLossArgs g{};
+    fill_gather_args(g, preds, dpreds, t, B, max_objs, (int)HW, scratch_losses, aux + 2, grad_losses);
+    HIPCHK(h, mc::launch_gathered_losses(g, 1, st));
+    return 0;
+}
+
+}  // extern "C"

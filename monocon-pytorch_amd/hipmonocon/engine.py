@@ -104,6 +104,51 @@ class Engine:
         out = dict(zip(PRED_KEYS, preds))
         return (out, feat) if want_feat else out
 
+    # ------------------------------------------------------------------ stage-level forwards
+    LEVEL_CH = (16, 32, 64, 128, 256, 512)
+
+    def backbone_forward(self, img):
+        """DLA.forward: (B,3,H,W) -> tuple of the six NCHW level outputs."""
+        _need_cuda(img, "img")
+        B, _, H, W = img.shape
+        lv = [torch.empty((B, c, H >> i, W >> i), dtype=torch.float32, device=img.device)
+              for i, c in enumerate(self.LEVEL_CH)]
+        arr = (C.c_void_p * 6)(*[t.data_ptr() for t in lv])
+        with torch.cuda.device(img.device):
+            rc = self.lib.mc_backbone_forward(self.h, _ptr(img), B, H, W, arr, _stream())
+        _lib.check(self.h, rc, "mc_backbone_forward")
+        return tuple(lv)
+
+    def neck_forward(self, levels):
+        """DLAUp.forward: six NCHW levels (only 2..5 are read) -> (B,64,H/4,W/4)."""
+        l2 = _need_cuda(levels[2], "levels[2]")
+        B, _, fh, fw = l2.shape
+        H, W = fh * 4, fw * 4
+        arr = (C.c_void_p * 6)()
+        for i in range(2, 6):
+            t = _need_cuda(levels[i], "levels[%d]" % i)
+            if tuple(t.shape) != (B, self.LEVEL_CH[i], H >> i, W >> i):
+                raise _lib.MonoconHipError("levels[%d] has shape %s" % (i, tuple(t.shape)))
+            arr[i] = t.data_ptr()
+        feat = torch.empty((B, 64, fh, fw), dtype=torch.float32, device=l2.device)
+        with torch.cuda.device(l2.device):
+            rc = self.lib.mc_neck_forward(self.h, arr, B, H, W, _ptr(feat), _stream())
+        _lib.check(self.h, rc, "mc_neck_forward")
+        return feat
+
+    def head_forward(self, feat):
+        """MonoConDenseHeads._get_predictions: (B,64,h,w) NCHW -> dict of ten NCHW maps."""
+        _need_cuda(feat, "feat")
+        B, c, fh, fw = feat.shape
+        if c != 64 or feat.dtype != torch.float32:
+            raise _lib.MonoconHipError("feat must be (B,64,h,w) float32")
+        preds = [torch.empty((B, pc, fh, fw), dtype=torch.float32, device=feat.device) for pc in PRED_CH]
+        arr = (C.c_void_p * _lib.NUM_PREDS)(*[p.data_ptr() for p in preds])
+        with torch.cuda.device(feat.device):
+            rc = self.lib.mc_head_forward(self.h, _ptr(feat), B, fh * 4, fw * 4, arr, _stream())
+        _lib.check(self.h, rc, "mc_head_forward")
+        return dict(zip(PRED_KEYS, preds))
+
     def forward_cost(self, B, H, W):
         """-> dict(conv_flops, other_flops, conv_bytes, other_bytes) of one forward."""
         fl, by = (C.c_double * 2)(), (C.c_double * 2)()
@@ -147,6 +192,80 @@ class Engine:
         _lib.check(self.h, rc, "mc_decode")
         return dict(scores=scores, flat_index=flat, cls=cls, box2d=box2d, box3d=box3d, keep=keep,
                     box_mask=kthr.bool())
+
+    # ------------------------------------------------------------------ targets / losses
+    TARGET_SHAPES = (("center_heatmap_target", "map3", torch.float32), ("wh_target", 2, torch.float32),
+                     ("offset_target", 2, torch.float32), ("dim_target", 3, torch.float32),
+                     ("alpha_cls_target", 1, torch.float32), ("alpha_offset_target", 1, torch.float32),
+                     ("depth_target", 1, torch.float32), ("center2kpt_offset_target", 18, torch.float32),
+                     ("kpt_heatmap_target", "map9", torch.float32), ("kpt_heatmap_offset_target", 18, torch.float32),
+                     ("indices", 0, torch.int64), ("indices_kpt", 9, torch.int64), ("mask_target", 0, torch.bool),
+                     ("mask_center2kpt_offset", 18, torch.float32), ("mask_kpt_heatmap_offset", 18, torch.float32))
+
+    def _targets_struct(self, T):
+        st = _lib.Targets()
+        for name in _lib.TARGET_FIELDS:
+            setattr(st, name, _need_cuda(T[name], name).data_ptr())
+        return st
+
+    def make_targets(self, label, pad_hw, feat_hw, max_objs=30):
+        """TargetGenerator.__call__: dict of fp32 CUDA label tensors -> dict of the 15 target tensors."""
+        mask = _need_cuda(label["mask"], "label.mask")
+        B, dev = mask.shape[0], mask.device
+        fh, fw = feat_hw
+        lab = _lib.Labels()
+        keep = []
+        for f in ("gt_bboxes", "gt_labels", "gt_bboxes_3d", "depths", "gt_kpts_2d", "gt_kpts_valid_mask", "mask"):
+            t = _need_cuda(label[f], "label." + f)
+            if t.dtype != torch.float32:
+                raise _lib.MonoconHipError("label.%s must be float32 (collate_fn contract)" % f)
+            keep.append(t)
+            setattr(lab, f, t.data_ptr())
+        T = {}
+        for name, kind, dt in self.TARGET_SHAPES:
+            if kind == "map3":
+                shape = (B, 3, fh, fw)
+            elif kind == "map9":
+                shape = (B, 9, fh, fw)
+            elif kind == 0:
+                shape = (B, max_objs)
+            elif name == "indices_kpt":
+                shape = (B, max_objs * 9)
+            else:
+                shape = (B, max_objs, kind)
+            T[name] = torch.empty(shape, dtype=dt, device=dev)
+        st = self._targets_struct(T)
+        with torch.cuda.device(dev):
+            rc = self.lib.mc_make_targets(self.h, C.byref(lab), B, max_objs, int(pad_hw[0]), int(pad_hw[1]), fh, fw,
+                                          C.byref(st), _stream())
+        _lib.check(self.h, rc, "mc_make_targets")
+        return T
+
+    def losses(self, pred, T, max_objs=30):
+        """_get_losses: -> (10,) CUDA tensor in the reference's loss_dict order."""
+        heat = _need_cuda(pred["center_heatmap_pred"], "center_heatmap_pred")
+        B, _, fh, fw = heat.shape
+        arr = (C.c_void_p * _lib.NUM_PREDS)(*[_need_cuda(pred[k], k).data_ptr() for k in PRED_KEYS])
+        out = torch.zeros(10, dtype=torch.float32, device=heat.device)
+        st = self._targets_struct(T)
+        with torch.cuda.device(heat.device):
+            rc = self.lib.mc_losses(self.h, arr, C.byref(st), B, max_objs, fh, fw, _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_losses")
+        return out
+
+    def losses_backward(self, pred, T, grad_losses, max_objs=30):
+        """gradient of sum(grad_losses * losses) wrt the raw 1x1 outputs behind each prediction map."""
+        heat = _need_cuda(pred["center_heatmap_pred"], "center_heatmap_pred")
+        B, _, fh, fw = heat.shape
+        arr = (C.c_void_p * _lib.NUM_PREDS)(*[_need_cuda(pred[k], k).data_ptr() for k in PRED_KEYS])
+        d = [torch.empty_like(pred[k]) for k in PRED_KEYS]
+        darr = (C.c_void_p * _lib.NUM_PREDS)(*[t.data_ptr() for t in d])
+        st = self._targets_struct(T)
+        g = _need_cuda(grad_losses, "grad_losses")
+        with torch.cuda.device(heat.device):
+            rc = self.lib.mc_losses_backward(self.h, arr, C.byref(st), B, max_objs, fh, fw, _ptr(g), darr, _stream())
+        _lib.check(self.h, rc, "mc_losses_backward")
+        return dict(zip(PRED_KEYS, d))
 
     # ------------------------------------------------------------------ op level (tests)
     def op_conv(self, srcs, weight, stride=1, scale=None, bias=None, residual=None, relu=False):

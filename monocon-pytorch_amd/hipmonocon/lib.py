@@ -14,7 +14,7 @@ NUM_PREDS = 10
 
 EXPORTS = (
     "mc_create", "mc_destroy", "mc_last_error", "mc_version", "mc_bind_params", "mc_pack_params",
-    "mc_forward_infer", "mc_decode", "mc_op_conv", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
+    "mc_forward_infer", "mc_backbone_forward", "mc_neck_forward", "mc_head_forward", "mc_decode", "mc_make_targets", "mc_losses", "mc_losses_backward", "mc_op_conv", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
     "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_forward_cost",
     "mc_profile_forward", "mc_bench_conv", "mc_bench_mfma_peak",
 )
@@ -22,6 +22,21 @@ EXPORTS = (
 
 class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p), ("numel", C.c_int64), ("dtype", C.c_int32)]
+
+
+class Labels(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("gt_bboxes", "gt_labels", "gt_bboxes_3d", "depths", "gt_kpts_2d",
+                                          "gt_kpts_valid_mask", "mask")]
+
+
+TARGET_FIELDS = ("center_heatmap_target", "wh_target", "offset_target", "dim_target", "alpha_cls_target",
+                 "alpha_offset_target", "depth_target", "center2kpt_offset_target", "kpt_heatmap_target",
+                 "kpt_heatmap_offset_target", "indices", "indices_kpt", "mask_target", "mask_center2kpt_offset",
+                 "mask_kpt_heatmap_offset")
+
+
+class Targets(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in TARGET_FIELDS]
 
 
 class MonoconHipError(RuntimeError):
@@ -51,7 +66,13 @@ def load():
     lib.mc_bind_params.argtypes = [vp, C.POINTER(TensorDesc), i]
     lib.mc_pack_params.argtypes = [vp, i, vp]
     lib.mc_forward_infer.argtypes = [vp, vp, i, i, i, C.POINTER(vp), vp, vp]
+    lib.mc_backbone_forward.argtypes = [vp, vp, i, i, i, C.POINTER(vp), vp]
+    lib.mc_neck_forward.argtypes = [vp, C.POINTER(vp), i, i, i, vp, vp]
+    lib.mc_head_forward.argtypes = [vp, vp, i, i, i, C.POINTER(vp), vp]
     lib.mc_decode.argtypes = [vp, C.POINTER(vp), vp, vp, i, i, i, i, i, f, f, f, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mc_make_targets.argtypes = [vp, C.POINTER(Labels), i, i, i, i, i, i, C.POINTER(Targets), vp]
+    lib.mc_losses.argtypes = [vp, C.POINTER(vp), C.POINTER(Targets), i, i, i, i, vp, vp]
+    lib.mc_losses_backward.argtypes = [vp, C.POINTER(vp), C.POINTER(Targets), i, i, i, i, vp, C.POINTER(vp), vp]
     lib.mc_op_conv.argtypes = [vp, C.POINTER(vp), C.POINTER(i), i, i, i, i, vp, i, i, i, vp, vp, vp, i, vp, vp]
     lib.mc_op_stem.argtypes = [vp, vp, i, i, i, vp, vp, vp, vp, vp]
     lib.mc_op_maxpool2.argtypes = [vp, vp, i, i, i, i, vp, vp]

@@ -33,6 +33,6 @@ def golden_sd():
 def rel_err(a, b):
     """norm-wise error used throughout: max|a-b| / max|b|."""
     import torch
-    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).double()
-    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b).double()
+    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a.detach().cpu()).double()
+    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b.detach().cpu()).double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
