@@ -139,6 +139,18 @@ int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS],
                        const mc_targets *targets, int B, int max_objs, int feat_h, int feat_w,
                        const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream);
 
+/* ---- optimizer ---------------------------------------------------------------------------
+ * Replaces clip_grad_norm_(max_norm, L2) + torch.optim.AdamW.step (engine/monocon_engine.py:94-102;
+ * AdamW(lr 2.25e-4, wd 1e-5, betas (0.95,0.99)) :39-43).  mc_optim_bind registers n parameter
+ * tensors with their gradient and moment buffers (caller-owned fp32 device tensors);
+ * mc_clip_adamw_step computes the global gradient norm over them, the clip coefficient
+ * min(1, max_norm/(norm+1e-6)) (max_norm <= 0: no clipping) and applies one AdamW update in
+ * place.  step is 1-based.  out_norm (device float, optional) receives the pre-clip norm. */
+int mc_optim_bind(mc_handle *h, int n, float *const params[], float *const grads[],
+                  float *const exp_avg[], float *const exp_avg_sq[], const int64_t numel[]);
+int mc_clip_adamw_step(mc_handle *h, double lr, double beta1, double beta2, double eps,
+                       double weight_decay, double max_norm, int step, float *out_norm, void *stream);
+
 /* ---- op-level entry points (unit parity tests; same kernels the forward uses) -------
  * Fused convolution, NHWC fp32: out = act(conv(cat(src...)) * scale + bias + residual).
  * Replaces nn.Conv2d + nn.BatchNorm2d(eval) + ReLU (+ torch.cat, + residual add) of

@@ -438,6 +438,9 @@ int mc_destroy(mc_handle *h) {
     for (void *q : h->param_bufs) (void)hipFree(q);
     if (h->decode_filt) (void)hipFree(h->decode_filt);
     if (h->loss_ws) (void)hipFree(h->loss_ws);
+    if (h->opt_tab) (void)hipFree(h->opt_tab);
+    if (h->opt_chunks) (void)hipFree(h->opt_chunks);
+    if (h->opt_ws) (void)hipFree(h->opt_ws);
     delete h;
     return 0;
 }

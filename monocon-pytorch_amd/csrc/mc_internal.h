@@ -95,6 +95,11 @@ struct mc_handle {
     size_t decode_filt_n = 0;
     int force_cfg = 0;   // tuning aid (mc_bench_conv)
     float *loss_ws = nullptr;   // focal partials + small reduction scratch
+    // fused optimizer tables (device)
+    mc::OptTensor *opt_tab = nullptr;
+    mc::OptChunk *opt_chunks = nullptr;
+    int opt_nchunks = 0, opt_ntensors = 0;
+    float *opt_ws = nullptr;    // partials + [norm, coef]
 };
 
 extern std::string g_create_err;

@@ -1,6 +1,9 @@
 // Training-side C-ABI: target generation, losses (+ gradients wrt the prediction maps).
 #include "mc_internal.h"
 
+#include <algorithm>
+#include <cmath>
+
 static int check_targets(mc_handle *h, const mc_targets *t, const char *who) {
     if (!t) return fail(h, "%s: targets is NULL", who);
     const void *p[] = {t->center_heatmap_target, t->wh_target, t->offset_target, t->dim_target, t->alpha_cls_target,
@@ -125,6 +128,61 @@ int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS], con
     mc::GatherLossArgs g{};
     fill_gather_args(g, preds, dpreds, t, B, max_objs, (int)HW, scratch_losses, aux + 2, grad_losses);
     HIPCHK(h, mc::launch_gathered_losses(g, 1, st));
+    return 0;
+}
+
+int mc_optim_bind(mc_handle *h, int n, float *const params[], float *const grads[], float *const exp_avg[],
+                  float *const exp_avg_sq[], const int64_t numel[]) {
+    if (!h) return -1;
+    if (n < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !numel) return fail(h, "mc_optim_bind: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<mc::OptTensor> tab(n);
+    std::vector<mc::OptChunk> chunks;
+    const int CH = 1 << 16;
+    for (int i = 0; i < n; ++i) {
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 1)
+            return fail(h, "mc_optim_bind: tensor %d has a null pointer / empty size", i);
+        tab[i] = mc::OptTensor{params[i], grads[i], exp_avg[i], exp_avg_sq[i]};
+        for (int64_t b = 0; b < numel[i]; b += CH)
+            chunks.push_back(mc::OptChunk{i, (int)b, (int)std::min<int64_t>(CH, numel[i] - b)});
+    }
+    if (h->opt_tab) (void)hipFree(h->opt_tab);
+    if (h->opt_chunks) (void)hipFree(h->opt_chunks);
+    h->opt_tab = nullptr; h->opt_chunks = nullptr;
+    void *q = nullptr;
+    HIPCHK(h, hipMalloc(&q, tab.size() * sizeof(mc::OptTensor)));
+    h->opt_tab = static_cast<mc::OptTensor *>(q);
+    HIPCHK(h, hipMalloc(&q, chunks.size() * sizeof(mc::OptChunk)));
+    h->opt_chunks = static_cast<mc::OptChunk *>(q);
+    HIPCHK(h, hipMemcpy(h->opt_tab, tab.data(), tab.size() * sizeof(mc::OptTensor), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->opt_chunks, chunks.data(), chunks.size() * sizeof(mc::OptChunk), hipMemcpyHostToDevice));
+    h->opt_nchunks = (int)chunks.size();
+    h->opt_ntensors = n;
+    if (!h->opt_ws) {
+        HIPCHK(h, hipMalloc(&q, (mc::opt_partial_floats() + 8) * sizeof(float)));
+        h->opt_ws = static_cast<float *>(q);
+    }
+    return 0;
+}
+
+int mc_clip_adamw_step(mc_handle *h, double lr, double beta1, double beta2, double eps, double weight_decay,
+                       double max_norm, int step, float *out_norm, void *stream) {
+    if (!h) return -1;
+    if (!h->opt_tab) return fail(h, "mc_clip_adamw_step: call mc_optim_bind first");
+    if (step < 1) return fail(h, "mc_clip_adamw_step: step must be >= 1 (1-based, as torch.optim counts)");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mc::AdamHyper hp;
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    hp.decay = (float)(1.0 - lr * weight_decay);
+    hp.beta1 = (float)beta1; hp.one_minus_beta1 = (float)(1.0 - beta1);
+    hp.beta2 = (float)beta2; hp.one_minus_beta2 = (float)(1.0 - beta2);
+    hp.sqrt_bc2 = (float)std::sqrt(bc2);
+    hp.eps = (float)eps;
+    hp.step_size = (float)(lr / bc1);
+    float *normcoef = h->opt_ws + mc::opt_partial_floats();
+    HIPCHK(h, mc::launch_clip_adamw(h->opt_tab, h->opt_chunks, h->opt_nchunks, h->opt_ws, normcoef, (float)max_norm, hp, st));
+    if (out_norm) HIPCHK(h, hipMemcpyAsync(out_norm, normcoef, sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

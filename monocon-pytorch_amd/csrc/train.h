@@ -40,4 +40,12 @@ struct GatherLossArgs {
 };
 hipError_t launch_gathered_losses(const GatherLossArgs &a, int mode, hipStream_t st);
 
+// ---- fused clip + AdamW (reference engine/monocon_engine.py:94-102)
+struct OptTensor { float *p, *g, *m, *v; };
+struct OptChunk { int tensor, begin, count; };
+struct AdamHyper { float decay, beta1, one_minus_beta1, beta2, one_minus_beta2, sqrt_bc2, eps, step_size; };
+hipError_t launch_clip_adamw(const OptTensor *tab, const OptChunk *chunks, int nchunks, float *partial, float *normcoef,
+                             float max_norm, const AdamHyper &hp, hipStream_t st);
+int opt_partial_floats();
+
 }  // namespace mc

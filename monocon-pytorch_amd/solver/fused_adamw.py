@@ -1,0 +1,88 @@
+"""Fused gradient-clip + AdamW on MI355X.
+
+Drop-in for ``torch.optim.AdamW`` in the reference train loop (engine/monocon_engine.py:35-55,
+94-102).  The class is deliberately named ``AdamW`` (CyclicScheduler asserts on the class name,
+solver/cyclic_scheduler.py:16-17).  ``step()`` launches libmonocon_hip's multi-tensor kernels:
+global L2 gradient norm, clip coefficient and the decoupled-weight-decay Adam update in two passes
+over the parameters instead of hundreds of per-tensor launches.  Parameters without a gradient
+(the six tensors the reference never back-propagates into, SURVEY §8a quirk i) are skipped, as
+torch does.
+"""
+import ctypes as C
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+from hipmonocon import lib as _lib
+
+
+class AdamW(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None,
+                 engine=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("the fused optimizer handles one parameter group")
+        self.max_grad_norm = max_grad_norm
+        self._engine = engine
+        self._bound_sig = None
+        self._steps = 0
+        self.last_grad_norm = None      # device scalar of the most recent pre-clip norm
+
+    def set_engine(self, engine):
+        self._engine = engine
+        self._bound_sig = None
+
+    def _bind(self, plist):
+        eng = self._engine
+        if eng is None:
+            from hipmonocon.engine import Engine
+            eng = self._engine = Engine(plist[0].device.index)
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        if sig == self._bound_sig:
+            return eng
+        n = len(plist)
+        P, G, M, V = ((C.c_void_p * n)() for _ in range(4))
+        N = (C.c_int64 * n)()
+        for i, p in enumerate(plist):
+            if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or not p.grad.is_contiguous():
+                raise _lib.MonoconHipError("fused AdamW needs contiguous float32 HIP parameters and gradients")
+            st = self.state[p]
+            if len(st) == 0:
+                st['step'] = torch.tensor(0.0)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            P[i], G[i], M[i], V[i] = p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+            N[i] = p.numel()
+        _lib.check(eng.h, eng.lib.mc_optim_bind(eng.h, n, P, G, M, V, N), "mc_optim_bind")
+        self._bound_sig = sig
+        return eng
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        group = self.param_groups[0]
+        plist = [p for p in group['params'] if p.grad is not None]
+        if not plist:
+            return loss
+        eng = self._bind(plist)
+        self._steps += 1
+        for p in plist:
+            self.state[p]['step'] += 1
+        if self.last_grad_norm is None:
+            self.last_grad_norm = torch.zeros(1, dtype=torch.float32, device=plist[0].device)
+        beta1, beta2 = group['betas']
+        with torch.cuda.device(plist[0].device):
+            rc = eng.lib.mc_clip_adamw_step(eng.h, float(group['lr']), float(beta1), float(beta2), float(group['eps']),
+                                            float(group['weight_decay']),
+                                            float(self.max_grad_norm) if self.max_grad_norm else 0.0, self._steps,
+                                            C.c_void_p(self.last_grad_norm.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(eng.h, rc, "mc_clip_adamw_step")
+        # the kernels updated the parameters behind torch's back: advance their version counters
+        # (host-only bookkeeping) so autograd and the engine's packed-weight cache see the change
+        torch.autograd.graph.increment_version(plist)
+        return loss

@@ -106,3 +106,49 @@ def test_loss_gradients_vs_autograd(eng):
     for k in raw:
         ref = raw[k].grad
         assert rel_err(d[k].cpu(), ref) < 2e-4, (k, rel_err(d[k].cpu(), ref))
+
+
+def test_fused_clip_adamw_vs_reference_golden(golden_sd):
+    """three optimizer steps on the reference's recorded (pre-clip) gradients, schedule included."""
+    from solver import AdamW, CyclicScheduler
+    g = load_golden("adamw.npz")
+    names = [k[len("step0."):] for k in g.files if k.startswith("step0.")]
+    params = [torch.nn.Parameter(golden_sd[n].clone().cuda()) for n in names]
+    opt = AdamW(params, lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=None)
+    sch = CyclicScheduler(opt, total_steps=1000, target_lr_ratio=(10, 1e-4),
+                          target_momentum_ratio=(0.85 / 0.95, 1.0), period_up=0.4)
+    for step in range(3):
+        lr, b1, norm = g["sched"][step]
+        assert opt.param_groups[0]["lr"] == pytest.approx(lr, rel=1e-12)
+        assert opt.param_groups[0]["betas"][0] == pytest.approx(b1, rel=1e-12)
+        coef = min(1.0, 35.0 / (norm + 1e-6))          # the golden norm is over ALL model gradients
+        for p, n in zip(params, names):
+            p.grad = (torch.from_numpy(g["grad%d.%s" % (step, n)]) * np.float32(coef)).cuda()
+        v0 = params[0]._version
+        opt.step()
+        sch.step()
+        assert params[0]._version > v0
+        for p, n in zip(params, names):
+            assert rel_err(p.detach().cpu(), g["step%d.%s" % (step, n)]) < 2e-6, (step, n)
+
+
+def test_fused_clip_matches_torch_clip(golden_sd):
+    """global-norm clipping inside the fused step == clip_grad_norm_ followed by an unclipped step."""
+    from solver import AdamW
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (128,), (10, 64), (70000,)]
+    base = [torch.randn(s) for s in shapes]
+    grads = [torch.randn(s) * 3 for s in shapes]
+    pa = [torch.nn.Parameter(b.clone().cuda()) for b in base]
+    pb = [torch.nn.Parameter(b.clone()) for b in base]
+    oa = AdamW(pa, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.99), max_grad_norm=5.0)
+    ob = torch.optim.AdamW(pb, lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.99))
+    for it in range(3):
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad = (gr * (it + 1)).cuda()
+            q.grad = (gr * (it + 1)).clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_(pb, 5.0)
+        oa.step(); ob.step()
+        assert float(oa.last_grad_norm) == pytest.approx(float(ref_norm), rel=1e-5)
+        for p, q in zip(pa, pb):
+            assert rel_err(p.detach().cpu(), q.detach()) < 2e-6
