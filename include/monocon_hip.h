@@ -139,6 +139,24 @@ int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS],
                        const mc_targets *targets, int B, int max_objs, int feat_h, int feat_w,
                        const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream);
 
+/* ---- training step ---------------------------------------------------------------------
+ * mc_forward_train replaces `pred_dict, loss_dict = model(data_dict)` in train mode
+ * (model/detector/monocon_detector.py:53-61 -> MonoConDenseHeads.forward_train,
+ * model/dense_heads/monocon_heads.py:150-157): BatchNorm / AttnBN use batch statistics and update
+ * their running buffers in place (the bound tensors), targets are generated from the labels,
+ * preds[10] (NCHW) and losses[10] (device floats, loss_dict order) are written.
+ * mc_backward replaces total_loss.backward() (engine/monocon_engine.py:86): grad_losses is the
+ * device [10] upstream gradient of each loss (ones for `sum(loss_dict.values())`); gradients of
+ * every live parameter are WRITTEN to the tensors bound as "<key>#grad" (the six parameters the
+ * reference never back-propagates into -- SURVEY 8a quirk (i) -- are not touched).
+ * Data parallelism: every rank runs this on its own shard; averaging the "#grad" tensors across
+ * ranks (RCCL all-reduce, done by the host with torch.distributed) precedes the optimizer. */
+int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, int B, int H, int W,
+                     int max_objs, float *const preds[MC_NUM_PREDS], float *losses, void *stream);
+int mc_backward(mc_handle *h, const float *grad_losses, void *stream);
+/* Debugging aid: activation (which=0) or gradient (which=1) of node `node` of the train plan as NCHW. */
+int mc_train_debug_node(mc_handle *h, int node, int which, float *out_nchw, int dims[4], void *stream);
+
 /* ---- optimizer ---------------------------------------------------------------------------
  * Replaces clip_grad_norm_(max_norm, L2) + torch.optim.AdamW.step (engine/monocon_engine.py:94-102;
  * AdamW(lr 2.25e-4, wd 1e-5, betas (0.95,0.99)) :39-43).  mc_optim_bind registers n parameter
@@ -161,6 +179,11 @@ int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[],
                int B, int Hin, int Win, const float *weight_oihw, int Cout, int ksize,
                int stride, const float *scale, const float *bias, const float *residual,
                int relu, float *out, void *stream);
+/* Weight gradient of the same convolution: dW (O, sum C_i, k, k) = sum over pixels of dY x X
+ * (autograd's conv2d weight backward); dy: NHWC (B,Hout,Wout,Cout). */
+int mc_op_conv_wgrad(mc_handle *h, const float *const src[], const int src_channels[], int nsrc,
+                     int B, int Hin, int Win, const float *dy, int Cout, int ksize, int stride,
+                     float *dw_oihw, void *stream);
 /* 7x7 stem: NCHW (B,3,H,W) in -> NHWC (B,H,W,16) out (model/backbone/dla.py:231-234). */
 int mc_op_stem(mc_handle *h, const float *img_nchw, int B, int H, int W,
                const float *weight_oihw, const float *scale, const float *bias, float *out,

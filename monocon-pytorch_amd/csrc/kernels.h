@@ -21,7 +21,7 @@ hipError_t launch_copy(const float *src, float *dst, size_t n, hipStream_t st);
 
 // ---- backbone / neck element kernels -----------------------------------------------------
 hipError_t launch_stem(const float *img_nchw, int B, int H, int W, const float *wpk, const float *scale,
-                       const float *shift, float *out_nhwc, hipStream_t st);
+                       const float *shift, float *out_nhwc, hipStream_t st, int relu = 1);
 hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out,
                           hipStream_t st);

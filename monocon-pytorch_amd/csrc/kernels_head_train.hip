@@ -1,0 +1,383 @@
+// Train-mode kernels specific to the dense heads, plus the dgrad weight packer and the 7x7 stem
+// weight gradient.
+//
+// Head train pipeline (reference model/dense_heads/monocon_heads.py:114-131,165-200 and
+// model/norm/attentive_norm.py:79-91,154-164 under autograd):
+//   x   = conv3x3(feat) + bias                      fused MFMA conv, 9 heads side by side (576 ch)
+//   AttnBN statistics / attention / per-sample affine            attn_train_fwd_kernel (one WG per head)
+//   h   = relu(scale_bc * x + shift_bc)             affine_act (per-sample coefficients)
+//   raw = conv1x1(h; block-diagonal 576 -> 65) + b  fused MFMA conv (zeros outside the blocks)
+//   pred = sigmoid/clamp | depth transform | identity, NCHW      head_act_kernel
+// and the mirror image backwards; the AttnBN backward reduces to one per-(image, channel)
+// affine map dx = P*dout + Q*x + R (attn_train_bwd_kernel computes P, Q, R and all the small
+// parameter gradients).
+#include "kernels.h"
+#include "train.h"
+
+namespace mc {
+
+// ------------------------------------------------------------------ dgrad weight pack
+// forward W (Cout, CinTotal, k, k) -> panel of the transposed / flipped convolution that maps
+// dY (Cout channels) to dX of ONE source (channels [c_off, c_off + Cs)):
+//   dst[tap'][n/4][c_local (padded to CsP)][n%4] = W[n][c_off + c_local][k-1-r'][k-1-s']
+__global__ void pack_conv_w_dgrad_kernel(const float *__restrict__ w, int Cout, int CinTotal, int k, int c_off, int Cs,
+                                         int CsP, int CoutPad, float *__restrict__ dst) {
+    const int kk = k * k;
+    const size_t total = (size_t)Cout * Cs * kk;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int tap = e % kk;
+        const int cl = (e / kk) % Cs;
+        const int n = e / ((size_t)kk * Cs);
+        const int r = tap / k, s = tap % k;
+        const int tapd = (k - 1 - r) * k + (k - 1 - s);
+        dst[(((size_t)tapd * (CoutPad >> 2) + (n >> 2)) * CsP + cl) * 4 + (n & 3)] =
+            w[(((size_t)n * CinTotal + c_off + cl) * k + r) * k + s];
+    }
+}
+hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
+                                    float *dst, hipStream_t st) {
+    const size_t total = (size_t)Cout * Cs * k * k;
+    size_t g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(pack_conv_w_dgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, w, Cout, CinTotal, k, c_off, Cs, CsP,
+                       CoutPad, dst);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ block-diagonal 1x1 head weights
+// dense (65, 576): row r (head h(r)) holds its 64 weights at columns [64 h, 64 h + 64)
+__global__ void head_w1_dense_kernel(const float *__restrict__ w1 /*[65][64]*/, const int *__restrict__ row_head,
+                                     float *__restrict__ dense /*[65][576]*/) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NUM_OUT_ROWS * NUM_HEADS * HEAD_CH) return;
+    const int r = e / (NUM_HEADS * HEAD_CH), col = e % (NUM_HEADS * HEAD_CH);
+    const int h = col / HEAD_CH, c = col % HEAD_CH;
+    dense[e] = (row_head[r] == h) ? w1[r * HEAD_CH + c] : 0.f;
+}
+__global__ void head_w1_extract_kernel(const float *__restrict__ dense_grad /*[65][576]*/, const int *__restrict__ row_head,
+                                       float *__restrict__ dw1 /*[65][64]*/) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NUM_OUT_ROWS * HEAD_CH) return;
+    const int r = e / HEAD_CH, c = e % HEAD_CH;
+    dw1[e] = dense_grad[(size_t)r * NUM_HEADS * HEAD_CH + row_head[r] * HEAD_CH + c];
+}
+hipError_t launch_head_w1_dense(const float *w1, const int *row_head, float *dense, hipStream_t st) {
+    hipLaunchKernelGGL(head_w1_dense_kernel, dim3((NUM_OUT_ROWS * NUM_HEADS * HEAD_CH + 255) / 256), dim3(256), 0, st, w1,
+                       row_head, dense);
+    return hipGetLastError();
+}
+hipError_t launch_head_w1_extract(const float *dense_grad, const int *row_head, float *dw1, hipStream_t st) {
+    hipLaunchKernelGGL(head_w1_extract_kernel, dim3((NUM_OUT_ROWS * HEAD_CH + 255) / 256), dim3(256), 0, st, dense_grad,
+                       row_head, dw1);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ raw (B,HW,ld) -> NCHW predictions (+ epilogues)
+struct HeadActArgs {
+    const float *raw;
+    int ld, B, HW;
+    float *pred[10];
+    int row_pred[NUM_OUT_ROWS], row_ch[NUM_OUT_ROWS], row_epi[NUM_OUT_ROWS], pred_c[10];
+};
+__global__ __launch_bounds__(256) void head_act_kernel(const HeadActArgs a) {
+    __shared__ float t[64][NUM_OUT_ROWS + 2];
+    const int tiles = (a.HW + 63) / 64;
+    const int b = blockIdx.x / tiles, hw0 = (blockIdx.x % tiles) * 64;
+    for (int e = threadIdx.x; e < 64 * NUM_OUT_ROWS; e += 256) {
+        const int px = e / NUM_OUT_ROWS, r = e % NUM_OUT_ROWS;
+        t[px][r] = (hw0 + px < a.HW) ? a.raw[((size_t)b * a.HW + hw0 + px) * a.ld + r] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * NUM_OUT_ROWS; e += 256) {
+        const int r = e / 64, px = e % 64;
+        if (hw0 + px >= a.HW) continue;
+        float v = t[px][r];
+        if (a.row_epi[r] == 1) v = fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-4f), 1.0f - 1e-4f);
+        else if (a.row_epi[r] == 2) v = 1.0f / (1.0f / (1.0f + expf(-v)) + 1e-12f) - 1.0f;
+        const int p = a.row_pred[r];
+        a.pred[p][((size_t)b * a.pred_c[p] + a.row_ch[r]) * a.HW + hw0 + px] = v;
+    }
+}
+hipError_t launch_head_act(const float *raw, int ld, int B, int HW, float *const pred[10], hipStream_t st) {
+    HeadActArgs a;
+    a.raw = raw; a.ld = ld; a.B = B; a.HW = HW;
+    const HeadRow *rows = head_rows();
+    static const int PC[10] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
+    for (int i = 0; i < 10; ++i) { a.pred[i] = pred[i]; a.pred_c[i] = PC[i]; }
+    for (int r = 0; r < NUM_OUT_ROWS; ++r) { a.row_pred[r] = rows[r].pred; a.row_ch[r] = rows[r].ch; a.row_epi[r] = rows[r].epi; }
+    hipLaunchKernelGGL(head_act_kernel, dim3(B * ((HW + 63) / 64)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ten NCHW gradient maps -> (B,HW,ld) rows in HeadRow order, zero-padded to ld columns
+struct DpredPackArgs {
+    const float *dpred[10];
+    int ld, B, HW;
+    float *out;
+    int row_pred[NUM_OUT_ROWS], row_ch[NUM_OUT_ROWS], pred_c[10];
+};
+__global__ __launch_bounds__(256) void dpred_pack_kernel(const DpredPackArgs a) {
+    __shared__ float t[64][NUM_OUT_ROWS + 2];
+    const int tiles = (a.HW + 63) / 64;
+    const int b = blockIdx.x / tiles, hw0 = (blockIdx.x % tiles) * 64;
+    for (int e = threadIdx.x; e < 64 * NUM_OUT_ROWS; e += 256) {
+        const int r = e / 64, px = e % 64;
+        const int p = a.row_pred[r];
+        t[px][r] = (hw0 + px < a.HW) ? a.dpred[p][((size_t)b * a.pred_c[p] + a.row_ch[r]) * a.HW + hw0 + px] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * a.ld; e += 256) {
+        const int px = e / a.ld, r = e % a.ld;
+        if (hw0 + px < a.HW) a.out[((size_t)b * a.HW + hw0 + px) * a.ld + r] = r < NUM_OUT_ROWS ? t[px][r] : 0.f;
+    }
+}
+hipError_t launch_dpred_pack(const float *const dpred[10], int ld, int B, int HW, float *out, hipStream_t st) {
+    DpredPackArgs a;
+    a.ld = ld; a.B = B; a.HW = HW; a.out = out;
+    const HeadRow *rows = head_rows();
+    static const int PC[10] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
+    for (int i = 0; i < 10; ++i) { a.dpred[i] = dpred[i]; a.pred_c[i] = PC[i]; }
+    for (int r = 0; r < NUM_OUT_ROWS; ++r) { a.row_pred[r] = rows[r].pred; a.row_ch[r] = rows[r].ch; }
+    hipLaunchKernelGGL(dpred_pack_kernel, dim3(B * ((HW + 63) / 64)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ AttnBN train forward (one WG per head, lane = channel)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void attn_train_fwd_kernel(const AttnTrainArgs a) {
+    const int h = blockIdx.x, c = threadIdx.x;
+    const int CP = NUM_HEADS * HEAD_CH, ch = h * HEAD_CH + c;
+    const double HW = (double)a.HW, n = HW * a.B;
+    __shared__ float att[64][NUM_AFFINE];          // a[b][k] then y[b][k]   (B <= 64)
+    const float shift0 = a.rm[h][c];                // statistics were accumulated around the old running mean
+    double S1 = 0, S2 = 0;
+    for (int b = 0; b < a.B; ++b) {
+        double s1 = 0, s2 = 0;
+        for (int k = 0; k < a.chunks; ++k) {
+            const float *q = a.stats + (((size_t)b * a.chunks + k) * a.stat_ld + ch) * 2;
+            s1 += q[0]; s2 += q[1];
+        }
+        S1 += s1; S2 += s2;
+        const double m0 = s1 / HW;
+        const double mean = shift0 + m0, var = (s2 - s1 * m0) / (HW - 1.0);
+        const float sv = (float)(mean / sqrt(var + 1e-3));
+        a.sv_inst[((size_t)b * CP + ch) * 3 + 0] = sv;
+        a.sv_inst[((size_t)b * CP + ch) * 3 + 1] = (float)mean;
+        a.sv_inst[((size_t)b * CP + ch) * 3 + 2] = (float)var;
+        for (int k = 0; k < NUM_AFFINE; ++k) {
+            const float v = wave_sum(sv * a.att_w[h][k * HEAD_CH + c]);
+            if (c == 0) att[b][k] = v;
+        }
+    }
+    const double m0 = S1 / n;
+    const double mu = shift0 + m0;
+    double var = S2 / n - m0 * m0;
+    if (var < 0) var = 0;
+    const float r = (float)(1.0 / sqrt(var + 1e-3));
+    a.mu_r[ch * 2 + 0] = (float)mu;
+    a.mu_r[ch * 2 + 1] = r;
+    a.rm[h][c] = (1.f - 0.03f) * a.rm[h][c] + 0.03f * (float)mu;
+    a.rv[h][c] = (1.f - 0.03f) * a.rv[h][c] + 0.03f * (float)(var * n / (n - 1.0));
+    if (c == 0) *a.nbt[h] += 1;
+    __syncthreads();
+    // BN(10) over the batch dimension (train mode): lane k < 10 owns attention channel k
+    if (c < NUM_AFFINE) {
+        double s = 0, q = 0;
+        for (int b = 0; b < a.B; ++b) { s += att[b][c]; }
+        const double am = s / a.B;
+        for (int b = 0; b < a.B; ++b) { const double d = att[b][c] - am; q += d * d; }
+        const double av = q / a.B;
+        const float rk = (float)(1.0 / sqrt(av + 1e-5));
+        a.bn10[(h * NUM_AFFINE + c) * 2 + 0] = (float)am;
+        a.bn10[(h * NUM_AFFINE + c) * 2 + 1] = rk;
+        a.att_rm[h][c] = 0.9f * a.att_rm[h][c] + 0.1f * (float)am;
+        a.att_rv[h][c] = 0.9f * a.att_rv[h][c] + 0.1f * (float)(av * a.B / (a.B - 1.0));
+        if (c == 0) *a.att_nbt[h] += 1;
+        for (int b = 0; b < a.B; ++b) {
+            const float that = (att[b][c] - (float)am) * rk;
+            a.that[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + c] = that;
+            const float t = that * a.att_g[h][c] + a.att_b[h][c];
+            att[b][c] = fminf(fmaxf(t + 3.f, 0.f), 6.f) / 6.f;
+        }
+    }
+    __syncthreads();
+    for (int b = 0; b < a.B; ++b) {
+        float gam = 0.f, bet = 0.f;
+#pragma unroll
+        for (int k = 0; k < NUM_AFFINE; ++k) {
+            gam = fmaf(att[b][k], a.weight_[h][k * HEAD_CH + c], gam);
+            bet = fmaf(att[b][k], a.bias_[h][k * HEAD_CH + c], bet);
+        }
+        const size_t o = (size_t)b * CP + ch;
+        a.gamma_p[o] = gam;
+        const float sc = gam * r;
+        a.scale[o] = sc;
+        a.shift[o] = bet - (float)mu * sc;
+        if (c < NUM_AFFINE) a.yatt[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + c] = att[b][c];
+    }
+}
+hipError_t launch_attn_train_fwd(const AttnTrainArgs &a, hipStream_t st) {
+    if (a.B > 64 || a.B < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(NUM_HEADS), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ AttnBN train backward (one WG per head)
+// partial: [B*rb][576][2] = per row-block (sum dout, sum dout*x), dout = dh*[h>0]
+__global__ __launch_bounds__(64) void attn_train_bwd_kernel(const AttnTrainArgs a, const float *__restrict__ partial,
+                                                            int rb_per_img, AttnGradPtrs gp, float *__restrict__ coef) {
+    const int h = blockIdx.x, c = threadIdx.x;
+    const int CP = NUM_HEADS * HEAD_CH, ch = h * HEAD_CH + c;
+    const double HW = (double)a.HW, n = HW * a.B;
+    const float mu = a.mu_r[ch * 2], r = a.mu_r[ch * 2 + 1];
+    __shared__ float dgam[64][HEAD_CH], dbet[64][HEAD_CH];      // [b][c]
+    __shared__ float dyk[64][NUM_AFFINE], dak[64][NUM_AFFINE];
+    double M1 = 0, M2 = 0;
+    for (int b = 0; b < a.B; ++b) {
+        double d1 = 0, d2 = 0;
+        for (int k = 0; k < rb_per_img; ++k) {
+            const float *q = partial + (((size_t)b * rb_per_img + k) * CP + ch) * 2;
+            d1 += q[0]; d2 += q[1];
+        }
+        const float db = (float)d1, dg = (float)(r * (d2 - mu * d1));
+        dbet[b][c] = db; dgam[b][c] = dg;
+        const float gp_ = a.gamma_p[(size_t)b * CP + ch];
+        M1 += (double)gp_ * db; M2 += (double)gp_ * dg;
+    }
+    M1 /= n; M2 /= n;
+    // gradients of weight_ / bias_ and dy[b][k]
+    for (int k = 0; k < NUM_AFFINE; ++k) {
+        float gw = 0.f, gb = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            const float yv = a.yatt[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + k];
+            gw = fmaf(yv, dgam[b][c], gw);
+            gb = fmaf(yv, dbet[b][c], gb);
+        }
+        gp.d_weight_[h][k * HEAD_CH + c] = gw;
+        gp.d_bias_[h][k * HEAD_CH + c] = gb;
+        for (int b = 0; b < a.B; ++b) {
+            const float v = wave_sum(dgam[b][c] * a.weight_[h][k * HEAD_CH + c] + dbet[b][c] * a.bias_[h][k * HEAD_CH + c]);
+            if (c == 0) dyk[b][k] = v;
+        }
+    }
+    __syncthreads();
+    // hard-sigmoid + BN(10) backward over the batch: lane k owns attention channel k
+    if (c < NUM_AFFINE) {
+        const float g = a.att_g[h][c], be = a.att_b[h][c], rk = a.bn10[(h * NUM_AFFINE + c) * 2 + 1];
+        double s_dt = 0, s_dtt = 0;
+        for (int b = 0; b < a.B; ++b) {
+            const float that = a.that[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + c];
+            const float t = that * g + be;
+            const float dt = (t + 3.f > 0.f && t + 3.f < 6.f) ? dyk[b][c] / 6.f : 0.f;
+            dyk[b][c] = dt;
+            s_dt += dt; s_dtt += (double)dt * that;
+        }
+        gp.d_att_g[h][c] = (float)s_dtt;
+        gp.d_att_b[h][c] = (float)s_dt;
+        for (int b = 0; b < a.B; ++b) {
+            const float that = a.that[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + c];
+            dak[b][c] = g * rk * (dyk[b][c] - (float)(s_dt / a.B) - that * (float)(s_dtt / a.B));
+        }
+    }
+    __syncthreads();
+    float gwa[NUM_AFFINE];
+#pragma unroll
+    for (int k = 0; k < NUM_AFFINE; ++k) gwa[k] = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        const size_t o = (size_t)b * CP + ch;
+        const float sv = a.sv_inst[o * 3], m = a.sv_inst[o * 3 + 1], v = a.sv_inst[o * 3 + 2];
+        float ds = 0.f;
+#pragma unroll
+        for (int k = 0; k < NUM_AFFINE; ++k) {
+            ds = fmaf(dak[b][k], a.att_w[h][k * HEAD_CH + c], ds);
+            gwa[k] = fmaf(dak[b][k], sv, gwa[k]);
+        }
+        const double ve = (double)v + 1e-3;
+        const double dm = ds / sqrt(ve), dv = (double)ds * m * (-0.5) / (ve * sqrt(ve));
+        const float gp_ = a.gamma_p[o];
+        float *cf = coef + o * 4;
+        cf[0] = r * gp_;
+        cf[1] = (float)(-(double)r * r * M2 + 2.0 * dv / (HW - 1.0));
+        cf[2] = (float)(-(double)r * M1 + (double)r * r * mu * M2 + dm / HW - 2.0 * dv * m / (HW - 1.0));
+        cf[3] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NUM_AFFINE; ++k) gp.d_att_w[h][k * HEAD_CH + c] = gwa[k];
+}
+hipError_t launch_attn_train_bwd(const AttnTrainArgs &a, const float *partial, int rb_per_img, const AttnGradPtrs &gp,
+                                 float *coef, hipStream_t st) {
+    if (a.B > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(NUM_HEADS), dim3(64), 0, st, a, partial, rb_per_img, gp, coef);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ 7x7 stem weight gradient
+// dW[o][c][r][s] = sum_{b,y,x} dY[b,y,x,o] * img[b,c,y-3+r,x-3+s].  VALU kernel: 16x64 pixel tile per WG,
+// thread t < 147 owns tap (c,r,s) and accumulates the 16 output channels; partial [tiles][147][16].
+__global__ __launch_bounds__(192) void stem_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ dy, int B,
+                                                         int H, int W, float *__restrict__ partial) {
+    constexpr int TH = 8, TW = 32;
+    __shared__ float it[3][TH + 6][TW + 6];
+    __shared__ __attribute__((aligned(16))) float dt[TH * TW][16];
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int b = blockIdx.x / (tiles_x * tiles_y);
+    const int ty0 = ((blockIdx.x / tiles_x) % tiles_y) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    for (int e = threadIdx.x; e < 3 * (TH + 6) * (TW + 6); e += 192) {
+        const int lx = e % (TW + 6), ly = (e / (TW + 6)) % (TH + 6), c = e / ((TW + 6) * (TH + 6));
+        const int y = ty0 - 3 + ly, x = tx0 - 3 + lx;
+        it[c][ly][lx] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)b * 3 + c) * H + y) * W + x] : 0.f;
+    }
+    for (int e = threadIdx.x; e < TH * TW * 4; e += 192) {
+        const int q = e % 4, px = e / 4;
+        const int y = ty0 + px / TW, x = tx0 + px % TW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y < H && x < W) v = *reinterpret_cast<const f32x4 *>(dy + (((size_t)b * H + y) * W + x) * 16 + q * 4);
+        *reinterpret_cast<f32x4 *>(&dt[px][q * 4]) = v;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= 147) return;
+    const int c = t / 49, r = (t % 49) / 7, s = t % 7;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = 0.f;
+    for (int py = 0; py < TH; ++py)
+        for (int px = 0; px < TW; ++px) {
+            const float v = it[c][py + r][px + s];
+            const f32x4 *d = reinterpret_cast<const f32x4 *>(&dt[py * TW + px][0]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 dv = d[q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[q * 4 + j] = fmaf(v, dv[j], acc[q * 4 + j]);
+            }
+        }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) partial[((size_t)blockIdx.x * 147 + t) * 16 + o] = acc[o];
+}
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks,
+                                                                float *__restrict__ dw /*(16,3,7,7)*/) {
+    const int t = blockIdx.x / 16, o = blockIdx.x % 16;
+    double s = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[((size_t)i * 147 + t) * 16 + o];
+    __shared__ double sh[4];
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dw[o * 147 + t] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+int stem_wgrad_blocks(int B, int H, int W) { return B * ((W + 31) / 32) * ((H + 7) / 8); }
+hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
+                             hipStream_t st) {
+    const int nb = stem_wgrad_blocks(B, H, W);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(192), 0, st, img, dy, B, H, W, partial);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(147 * 16), dim3(256), 0, st, partial, nb, dw);
+    return hipGetLastError();
+}
+
+}  // namespace mc

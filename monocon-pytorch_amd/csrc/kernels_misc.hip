@@ -81,7 +81,7 @@ hipError_t launch_pack_deconv_w(const float *w, int C, float *dst, hipStream_t s
 constexpr int ST_TH = 16, ST_TW = 64, ST_LW = 72;
 __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img, int B, int H, int W,
                                                    const float *__restrict__ wpk, const float *__restrict__ scale,
-                                                   const float *__restrict__ shift, float *__restrict__ out) {
+                                                   const float *__restrict__ shift, float *__restrict__ out, int relu) {
     __shared__ __attribute__((aligned(16))) float tile[3][ST_TH + 6][ST_LW];
     const int tiles_x = (W + ST_TW - 1) / ST_TW, tiles_y = (H + ST_TH - 1) / ST_TH;
     const int bt = blockIdx.x;
@@ -133,16 +133,19 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
         for (int q = 0; q < 4; ++q) {
             f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc[p][q * 4 + j], scale[q * 4 + j], shift[q * 4 + j]), 0.f);
+            for (int j = 0; j < 4; ++j) {
+                const float t = fmaf(acc[p][q * 4 + j], scale[q * 4 + j], shift[q * 4 + j]);
+                v[j] = relu ? fmaxf(t, 0.f) : t;
+            }
             dst[q] = v;
         }
     }
 }
 
 hipError_t launch_stem(const float *img, int B, int H, int W, const float *wpk, const float *scale,
-                       const float *shift, float *out, hipStream_t st) {
+                       const float *shift, float *out, hipStream_t st, int relu) {
     const int tiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
-    hipLaunchKernelGGL(stem_kernel, dim3(B * tiles), dim3(256), 0, st, img, B, H, W, wpk, scale, shift, out);
+    hipLaunchKernelGGL(stem_kernel, dim3(B * tiles), dim3(256), 0, st, img, B, H, W, wpk, scale, shift, out, relu);
     return hipGetLastError();
 }
 

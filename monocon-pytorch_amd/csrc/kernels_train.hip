@@ -1,0 +1,409 @@
+// Train-mode element-wise / reduction kernels (NHWC fp32, 16-byte accesses, all HBM-bound):
+// BatchNorm batch statistics + running-stat update, normalise(+residual)+ReLU, the masked
+// reductions and the affine back-substitution of BatchNorm / AttnBN backward, max-pool and
+// depthwise-deconv backward, gradient dilation for stride-2 dgrad, layout packing.
+//
+// Replaces the autograd graph torch builds for nn.BatchNorm2d / ReLU / residual add / MaxPool2d /
+// ConvTranspose2d in the reference's BasicBlock, Root, Tree, Conv2dBlock, IDAUp
+// (model/backbone/dla.py:34-51,124-132,187-205; dla_neck.py:34-38,94-106).
+#include "conv_mfma.h"
+#include "train.h"
+
+namespace mc {
+
+static inline int grid_for(size_t total, int bs, int cap = 16384) {
+    size_t g = (total + bs - 1) / bs;
+    return (int)(g > (size_t)cap ? cap : (g == 0 ? 1 : g));
+}
+
+// ------------------------------------------------------------------ per-(image,row-block,channel) sums
+// mode 0: (sum(y - shift), sum((y - shift)^2));  mode 1: d = relu ? dz*[z>0] : dz -> (sum d, sum d*y)
+constexpr int RED_ROWS = 256;
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restrict__ y, const float *__restrict__ dz,
+                                                          const float *__restrict__ z, const float *__restrict__ shift,
+                                                          int rows_per_img, int C, int mode, int relu,
+                                                          float *__restrict__ partial, int Cstride) {
+    const int C4 = C >> 2;
+    const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
+    const int tid = threadIdx.x;
+    const int c4 = tid % C4, rg = tid / C4;
+    const int rb_per_img = (rows_per_img + RED_ROWS - 1) / RED_ROWS;
+    const int b = blockIdx.x / rb_per_img, rb = blockIdx.x % rb_per_img;
+    const int r0 = rb * RED_ROWS, r1 = min(rows_per_img, r0 + RED_ROWS);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    const bool active = tid < C4 * RG;
+    f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+    if (active && mode == 0 && shift) sh = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
+    if (active) {
+        for (int r = r0 + rg; r < r1; r += RG) {
+            const size_t o = ((size_t)b * rows_per_img + r) * C + c4 * 4;
+            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + o);
+            if (mode == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = yv[j] - sh[j]; s1[j] += d; s2[j] += d * d; }
+            } else {
+                f32x4 d = *reinterpret_cast<const f32x4 *>(dz + o);
+                if (relu) {
+                    const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[j] = zv[j] > 0.f ? d[j] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[j] += d[j]; s2[j] += d[j] * yv[j]; }
+            }
+        }
+    }
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s1[j]; red[tid * 8 + 4 + j] = s2[j]; }
+    __syncthreads();
+    if (tid < C4) {
+        float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a1[j] += red[(g * C4 + tid) * 8 + j]; a2[j] += red[(g * C4 + tid) * 8 + 4 + j]; }
+        float *dst = partial + ((size_t)blockIdx.x * Cstride + tid * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dst[j * 2] = a1[j]; dst[j * 2 + 1] = a2[j]; }
+    }
+}
+int chan_reduce_blocks(int B, int rows_per_img) { return B * ((rows_per_img + RED_ROWS - 1) / RED_ROWS); }
+hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, const float *shift, int B, int rows_per_img,
+                              int C, int mode, int relu, float *partial, int Cstride, hipStream_t st) {
+    if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chan_reduce_kernel, dim3(chan_reduce_blocks(B, rows_per_img)), dim3(256), 0, st, y, dz, z, shift,
+                       rows_per_img, C, mode, relu, partial, Cstride);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ BatchNorm (train) finalise
+// partial: [nb][Cstride][2] sums of (y - shift), (y - shift)^2 over n = nb * rows values per channel.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int nb, int Cstride, double n,
+                                                          const float *shift, const float *gamma, const float *beta,
+                                                          float eps, float momentum, float *running_mean,
+                                                          float *running_var, long long *nbt, float *a_out, float *b_out,
+                                                          float *mean_out, float *rstd_out) {
+    const int c = blockIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const float *p = partial + ((size_t)i * Cstride + c) * 2;
+        s1 += p[0]; s2 += p[1];
+    }
+    __shared__ double sh[8];
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((threadIdx.x & 63) == 0) { sh[(threadIdx.x >> 6) * 2] = s1; sh[(threadIdx.x >> 6) * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s1 = sh[0] + sh[2] + sh[4] + sh[6];
+        s2 = sh[1] + sh[3] + sh[5] + sh[7];
+        const double m0 = s1 / n;
+        const double mean = (shift ? (double)shift[c] : 0.0) + m0;
+        double var = s2 / n - m0 * m0;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+        const float a = g * rstd;
+        if (a_out) { a_out[c] = a; b_out[c] = be - (float)mean * a; }
+        mean_out[c] = (float)mean;
+        rstd_out[c] = rstd;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * n / (n - 1.0));
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
+}
+hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
+                              const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
+                              long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nb, Cstride, n, shift, gamma, beta, eps,
+                       momentum, rm, rv, nbt, a, b, mean, rstd);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ z = act(a*y + b (+ res))
+// per_sample: coefficient index = b*C + c (AttnBN) instead of c (BatchNorm)
+__global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict__ y, const float *__restrict__ a,
+                                                         const float *__restrict__ bb, const f32x4 *__restrict__ res,
+                                                         size_t total4, int C4, size_t rows_per_img, int per_sample,
+                                                         int relu, f32x4 *__restrict__ z) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = e % C4;
+        const size_t row = e / C4;
+        const size_t ci = (per_sample ? (row / rows_per_img) * C4 : 0) + c4;
+        const f32x4 av = reinterpret_cast<const f32x4 *>(a)[ci], bv = reinterpret_cast<const f32x4 *>(bb)[ci];
+        f32x4 v = y[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
+        if (res) { const f32x4 r = res[e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += r[j]; }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f); }
+        z[e] = v;
+    }
+}
+hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
+                             int C, int per_sample, int relu, float *z, hipStream_t st) {
+    const size_t total4 = (size_t)B * rows_per_img * (C / 4);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(y),
+                       a, b, reinterpret_cast<const f32x4 *>(res), total4, C / 4, rows_per_img, per_sample, relu,
+                       reinterpret_cast<f32x4 *>(z));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ BatchNorm backward finalise
+// partial: [nb][Cstride][2] = (sum d, sum d*y).  dy = P*d + Q*y + R with
+//   P = a, Q = -a*r*S2/n, R = -a*S1/n + a*r*mean*S2/n,  S2 = r*(sum d*y - mean*sum d);  dgamma = S2, dbeta = S1.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb, int Cstride,
+                                                              double n, const float *gamma, const float *mean,
+                                                              const float *rstd, float *dgamma, float *dbeta,
+                                                              float *coef /*[C][4]*/) {
+    const int c = blockIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const float *p = partial + ((size_t)i * Cstride + c) * 2;
+        s1 += p[0]; s2 += p[1];
+    }
+    __shared__ double sh[8];
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((threadIdx.x & 63) == 0) { sh[(threadIdx.x >> 6) * 2] = s1; sh[(threadIdx.x >> 6) * 2 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s1 = sh[0] + sh[2] + sh[4] + sh[6];
+        s2 = sh[1] + sh[3] + sh[5] + sh[7];
+        const double r = rstd[c], mu = mean[c], g = gamma ? gamma[c] : 1.0;
+        const double S2 = r * (s2 - mu * s1);
+        if (dgamma) dgamma[c] = (float)S2;
+        if (dbeta) dbeta[c] = (float)s1;
+        const double a = g * r;
+        coef[c * 4 + 0] = (float)a;
+        coef[c * 4 + 1] = (float)(-a * r * S2 / n);
+        coef[c * 4 + 2] = (float)(-a * s1 / n + a * r * mu * S2 / n);
+        coef[c * 4 + 3] = 0.f;
+    }
+}
+hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
+                                  const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nb, Cstride, n, gamma, mean, rstd, dgamma,
+                       dbeta, coef);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ dy = P*d + Q*y + R,  d = relu ? dz*[z>0] : dz
+// gres_mode: 0 none, 1 gres = d, 2 gres += d (gradient of the residual input)
+__global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict__ dz, const f32x4 *__restrict__ z,
+                                                         const f32x4 *__restrict__ y, const float *__restrict__ coef,
+                                                         size_t total4, int C4, size_t rows_per_img, int per_sample,
+                                                         int relu, f32x4 *__restrict__ dy, f32x4 *__restrict__ gres,
+                                                         int gres_mode) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = e % C4;
+        const size_t row = e / C4;
+        const size_t ci = ((per_sample ? (row / rows_per_img) * C4 : 0) + c4) * 4;
+        f32x4 d = dz[e];
+        if (relu) { const f32x4 zv = z[e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = zv[j] > 0.f ? d[j] : 0.f; }
+        const f32x4 yv = y[e];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 cf = reinterpret_cast<const f32x4 *>(coef)[ci + j];
+            o[j] = fmaf(cf[0], d[j], fmaf(cf[1], yv[j], cf[2]));
+        }
+        dy[e] = o;
+        if (gres_mode == 1) gres[e] = d;
+        else if (gres_mode == 2) { f32x4 g = gres[e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] += d[j];
+            gres[e] = g; }
+    }
+}
+hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
+                             int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st) {
+    const size_t total4 = (size_t)B * rows_per_img * (C / 4);
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(dz),
+                       reinterpret_cast<const f32x4 *>(z), reinterpret_cast<const f32x4 *>(y), coef, total4, C / 4,
+                       rows_per_img, per_sample, relu, reinterpret_cast<f32x4 *>(dy), reinterpret_cast<f32x4 *>(gres),
+                       gres_mode);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ small helpers
+__global__ void add_kernel(f32x4 *__restrict__ a, const f32x4 *__restrict__ b, size_t n4) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        f32x4 x = a[e];
+        const f32x4 yv = b[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] += yv[j];
+        a[e] = x;
+    }
+}
+hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, reinterpret_cast<f32x4 *>(a),
+                       reinterpret_cast<const f32x4 *>(b), n / 4);
+    return hipGetLastError();
+}
+
+// column sums of a [rows][C] matrix -> out[C] (conv bias gradients); one workgroup per 4 columns group
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, size_t rows, int C, int ld,
+                                                     float *__restrict__ out) {
+    const int c = blockIdx.x;
+    double s = 0;
+    for (size_t r = threadIdx.x; r < rows; r += 256) s += x[r * ld + c];
+    __shared__ double sh[4];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, st, x, rows, C, ld, out);
+    return hipGetLastError();
+}
+
+// stride-2 dgrad helper: out (B,2H,2W,C) = zeros with out[2y,2x] = in[y,x]
+__global__ void dilate2_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4, f32x4 *__restrict__ out) {
+    const size_t total = (size_t)B * 4 * H * W * C4;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % C4;
+        const size_t p = e / C4;
+        const int ox = p % (2 * W), oy = (p / (2 * W)) % (2 * H);
+        const size_t b = p / ((size_t)4 * W * H);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!(ox & 1) && !(oy & 1)) v = in[((b * H + (oy >> 1)) * W + (ox >> 1)) * C4 + c];
+        out[e] = v;
+    }
+}
+hipError_t launch_dilate2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st) {
+    const size_t total = (size_t)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(dilate2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(in), B,
+                       H, W, C / 4, reinterpret_cast<f32x4 *>(out));
+    return hipGetLastError();
+}
+
+// 2x2/2 max-pool backward: gradient goes to the first maximum in window scan order (torch)
+__global__ void maxpool2_bwd_kernel(const f32x4 *__restrict__ x, const f32x4 *__restrict__ dout, int B, int H, int W,
+                                    int C4, f32x4 *__restrict__ dx, int accumulate) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % C4;
+        const size_t p = e / C4;
+        const int ox = p % Wo, oy = (p / Wo) % Ho;
+        const size_t b = p / ((size_t)Wo * Ho);
+        const size_t i00 = ((b * H + 2 * oy) * W + 2 * ox) * C4 + c, i01 = i00 + C4, i10 = i00 + (size_t)W * C4, i11 = i10 + C4;
+        const f32x4 v00 = x[i00], v01 = x[i01], v10 = x[i10], v11 = x[i11], g = dout[e];
+        f32x4 g00, g01, g10, g11;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m = fmaxf(fmaxf(v00[j], v01[j]), fmaxf(v10[j], v11[j]));
+            const int k = v00[j] == m ? 0 : (v01[j] == m ? 1 : (v10[j] == m ? 2 : 3));
+            g00[j] = k == 0 ? g[j] : 0.f; g01[j] = k == 1 ? g[j] : 0.f;
+            g10[j] = k == 2 ? g[j] : 0.f; g11[j] = k == 3 ? g[j] : 0.f;
+        }
+        if (accumulate) {
+            f32x4 t;
+            t = dx[i00]; for (int j = 0; j < 4; ++j) t[j] += g00[j]; dx[i00] = t;
+            t = dx[i01]; for (int j = 0; j < 4; ++j) t[j] += g01[j]; dx[i01] = t;
+            t = dx[i10]; for (int j = 0; j < 4; ++j) t[j] += g10[j]; dx[i10] = t;
+            t = dx[i11]; for (int j = 0; j < 4; ++j) t[j] += g11[j]; dx[i11] = t;
+        } else {
+            dx[i00] = g00; dx[i01] = g01; dx[i10] = g10; dx[i11] = g11;
+        }
+    }
+}
+hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
+                               hipStream_t st) {
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(x),
+                       reinterpret_cast<const f32x4 *>(dout), B, H, W, C / 4, reinterpret_cast<f32x4 *>(dx), accumulate);
+    return hipGetLastError();
+}
+
+// depthwise ConvTranspose2d(k4,s2,p1) backward wrt input: din[iy,ix] = sum_{ky,kx} dout[2iy-1+ky, 2ix-1+kx] * w[ky,kx]
+__global__ void deconv4_bwd_data_kernel(const f32x4 *__restrict__ dout, int B, int H, int W, int C4,
+                                        const f32x4 *__restrict__ wpk, f32x4 *__restrict__ din) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = e % C4;
+        const size_t p = e / C4;
+        const int ix = p % W, iy = (p / W) % H;
+        const size_t b = p / ((size_t)W * H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int oy = 2 * iy - 1 + ky;
+            if (oy < 0 || oy >= 2 * H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                const int ox = 2 * ix - 1 + kx;
+                if (ox < 0 || ox >= 2 * W) continue;
+                const f32x4 g = dout[((b * 2 * H + oy) * 2 * W + ox) * C4 + c], w = wpk[(ky * 4 + kx) * C4 + c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(g[j], w[j], acc[j]);
+            }
+        }
+        din[e] = acc;
+    }
+}
+hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C, const float *wpk, float *din,
+                                   hipStream_t st) {
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(deconv4_bwd_data_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const f32x4 *>(dout), B, H, W, C / 4, reinterpret_cast<const f32x4 *>(wpk),
+                       reinterpret_cast<f32x4 *>(din));
+    return hipGetLastError();
+}
+
+// ... and wrt the (C,1,4,4) weights: dw[c,ky,kx] = sum_{b,iy,ix} in[b,iy,ix,c] * dout[b,2iy-1+ky,2ix-1+kx,c].
+// One workgroup per (image row-block); partial [blocks][16][C] then reduced by colsum-like pass.
+__global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restrict__ in, const float *__restrict__ dout,
+                                                            int B, int H, int W, int C, float *__restrict__ partial) {
+    // threads cover channels (C <= 256); each block handles one (b, iy) input row
+    const int b = blockIdx.x / H, iy = blockIdx.x % H;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        for (int ix = 0; ix < W; ++ix) {
+            const float v = in[(((size_t)b * H + iy) * W + ix) * C + c];
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const int oy = 2 * iy - 1 + ky;
+                if (oy < 0 || oy >= 2 * H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int ox = 2 * ix - 1 + kx;
+                    if (ox < 0 || ox >= 2 * W) continue;
+                    acc[ky * 4 + kx] = fmaf(v, dout[(((size_t)b * 2 * H + oy) * 2 * W + ox) * C + c], acc[ky * 4 + kx]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) partial[((size_t)blockIdx.x * 16 + k) * C + c] = acc[k];
+    }
+}
+__global__ __launch_bounds__(256) void deconv4_bwd_w_reduce_kernel(const float *__restrict__ partial, int nblocks, int C,
+                                                                   float *__restrict__ dw /*(C,1,4,4)*/) {
+    const int c = blockIdx.x / 16, k = blockIdx.x % 16;
+    double s = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[((size_t)i * 16 + k) * C + c];
+    __shared__ double sh[4];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dw[c * 16 + k] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+size_t deconv4_bwd_w_partial_floats(int B, int H, int C) { return (size_t)B * H * 16 * C; }
+hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(deconv4_bwd_w_kernel, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial);
+    hipLaunchKernelGGL(deconv4_bwd_w_reduce_kernel, dim3(C * 16), dim3(256), 0, st, partial, B * H, C, dw);
+    return hipGetLastError();
+}
+
+}  // namespace mc

@@ -438,6 +438,7 @@ int mc_destroy(mc_handle *h) {
     for (void *q : h->param_bufs) (void)hipFree(q);
     if (h->decode_filt) (void)hipFree(h->decode_filt);
     if (h->loss_ws) (void)hipFree(h->loss_ws);
+    if (h->train && h->train_free) h->train_free(h->train);
     if (h->opt_tab) (void)hipFree(h->opt_tab);
     if (h->opt_chunks) (void)hipFree(h->opt_chunks);
     if (h->opt_ws) (void)hipFree(h->opt_ws);
@@ -454,12 +455,13 @@ int mc_bind_params(mc_handle *h, const mc_tensor_desc *descs, int n) {
         h->bound[descs[i].name] = Bound{descs[i].ptr, descs[i].numel, descs[i].dtype};
     }
     h->packed = false;
+    h->bind_gen++;
     return 0;
 }
 
 int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
     if (!h) return -1;
-    if (train_mode != 0) return fail(h, "mc_pack_params: train_mode=%d not available in this build", train_mode);
+    (void)train_mode;   // the same panels serve both modes; train mode ignores the folded BN scale/shift
     HIPCHK(h, hipSetDevice(h->device));
     if (build_layers(h)) return -1;
     hipStream_t st = static_cast<hipStream_t>(stream);

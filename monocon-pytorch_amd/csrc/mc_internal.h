@@ -18,6 +18,8 @@
 
 using namespace mc;
 
+struct TrainState;   // mc_train_plan.hip
+
 struct Bound {
     void *ptr;
     int64_t numel;
@@ -100,6 +102,10 @@ struct mc_handle {
     mc::OptChunk *opt_chunks = nullptr;
     int opt_nchunks = 0, opt_ntensors = 0;
     float *opt_ws = nullptr;    // partials + [norm, coef]
+    // train-step plan (mc_train_plan.hip)
+    TrainState *train = nullptr;
+    void (*train_free)(TrainState *) = nullptr;
+    unsigned long long bind_gen = 0;
 };
 
 extern std::string g_create_err;

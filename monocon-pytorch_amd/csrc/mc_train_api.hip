@@ -131,6 +131,38 @@ int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS], con
     return 0;
 }
 
+int mc_op_conv_wgrad(mc_handle *h, const float *const src[], const int src_channels[], int nsrc, int B, int Hin, int Win,
+                     const float *dy, int Cout, int ksize, int stride, float *dw_oihw, void *stream) {
+    if (!h) return -1;
+    if (!src || !src_channels || !dy || !dw_oihw || nsrc < 1 || nsrc > 4) return fail(h, "mc_op_conv_wgrad: bad argument");
+    if (!((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1)))
+        return fail(h, "mc_op_conv_wgrad: unsupported k=%d stride=%d", ksize, stride);
+    if (Cout % 4) return fail(h, "mc_op_conv_wgrad: Cout must be a multiple of 4");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mc::WgradArgs a{};
+    int cin = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!src[i] || src_channels[i] % 16) return fail(h, "mc_op_conv_wgrad: source %d needs C %% 16 == 0", i);
+        a.src[i].p = src[i]; a.src[i].C = src_channels[i];
+        cin += src_channels[i];
+    }
+    a.nsrc = nsrc; a.B = B; a.Hin = Hin; a.Win = Win;
+    a.Hout = (Hin + 2 * (ksize / 2) - ksize) / stride + 1;
+    a.Wout = (Win + 2 * (ksize / 2) - ksize) / stride + 1;
+    a.Cin = cin; a.Cout = Cout; a.dy = dy; a.dy_ld = Cout;
+    mc::wgrad_plan(a, ksize, stride);
+    void *part = nullptr;
+    HIPCHK(h, hipMalloc(&part, mc::wgrad_partial_floats(a, ksize) * sizeof(float)));
+    a.partial = static_cast<float *>(part);
+    hipError_t e = mc::launch_wgrad(a, ksize, stride, dw_oihw, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(part);
+    HIPCHK(h, e);
+    HIPCHK(h, e2);
+    return 0;
+}
+
 int mc_optim_bind(mc_handle *h, int n, float *const params[], float *const grads[], float *const exp_avg[],
                   float *const exp_avg_sq[], const int64_t numel[]) {
     if (!h) return -1;

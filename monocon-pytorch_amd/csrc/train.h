@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "conv_mfma.h"
+
 namespace mc {
 
 // ---- target generator (reference utils/target_generator.py:30-177)
@@ -47,5 +49,76 @@ struct AdamHyper { float decay, beta1, one_minus_beta1, beta2, one_minus_beta2, 
 hipError_t launch_clip_adamw(const OptTensor *tab, const OptChunk *chunks, int nchunks, float *partial, float *normcoef,
                              float max_norm, const AdamHyper &hp, hipStream_t st);
 int opt_partial_floats();
+
+// ---- train-mode element-wise / reduction kernels (kernels_train.hip)
+int chan_reduce_blocks(int B, int rows_per_img);
+hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, const float *shift, int B, int rows_per_img,
+                              int C, int mode, int relu, float *partial, int Cstride, hipStream_t st);
+hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
+                              const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
+                              long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st);
+hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
+                             int C, int per_sample, int relu, float *z, hipStream_t st);
+hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
+                                  const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
+                                  hipStream_t st);
+hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
+                             int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st);
+hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st);
+hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *out, hipStream_t st);
+hipError_t launch_dilate2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
+hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
+                               hipStream_t st);
+hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C, const float *wpk, float *din,
+                                   hipStream_t st);
+size_t deconv4_bwd_w_partial_floats(int B, int H, int C);
+hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
+                                hipStream_t st);
+
+// ---- head / stem train kernels (kernels_head_train.hip)
+hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
+                                    float *dst, hipStream_t st);
+hipError_t launch_head_w1_dense(const float *w1, const int *row_head, float *dense, hipStream_t st);
+hipError_t launch_head_w1_extract(const float *dense_grad, const int *row_head, float *dw1, hipStream_t st);
+hipError_t launch_head_act(const float *raw, int ld, int B, int HW, float *const pred[10], hipStream_t st);
+hipError_t launch_dpred_pack(const float *const dpred[10], int ld, int B, int HW, float *out, hipStream_t st);
+struct AttnTrainArgs {
+    const float *stats;            // [B][chunks][stat_ld][2] partial (sum, sumsq) of (x - running_mean)
+    int chunks, stat_ld, B, HW;
+    float *rm[9], *rv[9];          // AttnBN running statistics (updated in place, momentum 0.03)
+    long long *nbt[9];
+    const float *att_w[9], *att_g[9], *att_b[9];
+    float *att_rm[9], *att_rv[9];  // attention BN(10) running statistics (momentum 0.1)
+    long long *att_nbt[9];
+    const float *weight_[9], *bias_[9];
+    // saved for backward
+    float *sv_inst;                // [B][576][3]  s, instance mean, instance (unbiased) variance
+    float *mu_r;                   // [576][2]     batch mean, rstd
+    float *bn10;                   // [9][10][2]   attention batch mean, rstd
+    float *that, *yatt;            // [B][9][10]   normalised attention logits, hard-sigmoid outputs
+    float *gamma_p;                // [B][576]     per-sample gamma'
+    float *scale, *shift;          // [B][576]     folded per-sample affine
+};
+struct AttnGradPtrs { float *d_weight_[9], *d_bias_[9], *d_att_w[9], *d_att_g[9], *d_att_b[9]; };
+hipError_t launch_attn_train_fwd(const AttnTrainArgs &a, hipStream_t st);
+hipError_t launch_attn_train_bwd(const AttnTrainArgs &a, const float *partial, int rb_per_img, const AttnGradPtrs &gp,
+                                 float *coef, hipStream_t st);
+int stem_wgrad_blocks(int B, int H, int W);
+hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
+                             hipStream_t st);
+
+// ---- conv weight gradient (wgrad_mfma.hip)
+struct WgradArgs {
+    ConvSrc src[4];
+    int nsrc;
+    int B, Hin, Win, Hout, Wout, Cin, Cout;
+    const float *dy;          // NHWC (B,Hout,Wout,dy_ld); channels >= Cout must be zero / are ignored
+    int dy_ld;
+    float *partial;           // [ksplit][k*k][Cout][Cin]
+    int ksplit, n_tiles, c_tiles, ppr, ppi, groups_per_img;
+};
+void wgrad_plan(WgradArgs &a, int ks, int stride);            // fills the tiling fields
+size_t wgrad_partial_floats(const WgradArgs &a, int ks);
+hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st);
 
 }  // namespace mc

@@ -285,6 +285,20 @@ class Engine:
         _lib.check(self.h, rc, "mc_op_conv")
         return out
 
+    def op_conv_wgrad(self, srcs, dy, ksize, stride=1):
+        """weight gradient of the fused conv: srcs NHWC list, dy NHWC -> (Cout, sum C, k, k)."""
+        B, H, W, _ = srcs[0].shape
+        Cout = dy.shape[3]
+        cin = sum(s.shape[3] for s in srcs)
+        dw = torch.empty((Cout, cin, ksize, ksize), dtype=torch.float32, device=dy.device)
+        sp = (C.c_void_p * len(srcs))(*[_need_cuda(s, "src").data_ptr() for s in srcs])
+        sc = (C.c_int * len(srcs))(*[s.shape[3] for s in srcs])
+        with torch.cuda.device(dy.device):
+            rc = self.lib.mc_op_conv_wgrad(self.h, sp, sc, len(srcs), B, H, W, _ptr(_need_cuda(dy, "dy")), Cout, ksize,
+                                           stride, _ptr(dw), _stream())
+        _lib.check(self.h, rc, "mc_op_conv_wgrad")
+        return dw
+
     def op_stem(self, img, weight, scale, bias):
         B, _, H, W = img.shape
         out = torch.empty((B, H, W, 16), dtype=torch.float32, device=img.device)

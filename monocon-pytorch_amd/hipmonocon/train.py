@@ -1,0 +1,106 @@
+"""Autograd bridge of the HIP train step.
+
+``forward_train(detector, data_dict)`` runs ``mc_forward_train`` (train-mode forward, target
+generation, the ten losses) and returns ``(pred_dict, loss_dict)`` exactly like the reference's
+``MonoConDetector.forward`` in train mode (model/detector/monocon_detector.py:53-61): the loss
+values are 0-dim tensors connected to the model's parameters through one
+``torch.autograd.Function`` whose ``backward`` calls ``mc_backward``, so the reference's train
+loop (``sum(loss_dict.values()).backward()``, ``clip_grad_norm_``, ``optimizer.step()``,
+engine/monocon_engine.py:84-102) runs unchanged on top of it.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+from . import netspec
+
+PRED_KEYS = tuple(k for k, _ in netspec.PRED_KEYS)
+PRED_CH = tuple(c for _, c in netspec.PRED_KEYS)
+LABEL_FIELDS = ("gt_bboxes", "gt_labels", "gt_bboxes_3d", "depths", "gt_kpts_2d", "gt_kpts_valid_mask", "mask")
+DEAD = frozenset(netspec.DEAD_PARAMS)
+
+
+class _TrainBinding:
+    """Per-detector bookkeeping: gradient buffers bound as '<key>#grad', BN buffer list."""
+
+    def __init__(self, detector):
+        self.named = [(n, p) for n, p in detector.named_parameters()]
+        self.live = [(n, p) for n, p in self.named if n not in DEAD]
+        self.grads = {n: torch.zeros_like(p) for n, p in self.live}
+        self.buffers = [b for _, b in detector.named_buffers()]
+        self.sig = tuple(p.data_ptr() for _, p in self.named)
+
+    def state(self, detector):
+        st = dict(detector.state_dict(keep_vars=True))
+        for n, g in self.grads.items():
+            st[n + "#grad"] = g
+        return st
+
+
+def _binding(detector):
+    tb = getattr(detector, "_train_binding", None)
+    sig = tuple(p.data_ptr() for _, p in detector.named_parameters())
+    if tb is None or tb.sig != sig:
+        tb = _TrainBinding(detector)
+        object.__setattr__(detector, "_train_binding", tb)
+    return tb
+
+
+class _HipTrainStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, detector, tb, eng, img, label, max_objs, *params):
+        B, _, H, W = img.shape
+        fh, fw = H // 4, W // 4
+        preds = [torch.empty((B, c, fh, fw), dtype=torch.float32, device=img.device) for c in PRED_CH]
+        losses = torch.zeros(10, dtype=torch.float32, device=img.device)
+        lab = _lib.Labels()
+        keep = []
+        for f in LABEL_FIELDS:
+            t = label[f]
+            if not (t.is_cuda and t.dtype == torch.float32):
+                raise _lib.MonoconHipError("label.%s must be a float32 HIP tensor (collate_fn contract)" % f)
+            t = t.contiguous()
+            keep.append(t)
+            setattr(lab, f, t.data_ptr())
+        arr = (C.c_void_p * _lib.NUM_PREDS)(*[p.data_ptr() for p in preds])
+        with torch.cuda.device(img.device):
+            rc = eng.lib.mc_forward_train(eng.h, C.c_void_p(img.data_ptr()), C.byref(lab), B, H, W, int(max_objs), arr,
+                                          C.c_void_p(losses.data_ptr()),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(eng.h, rc, "mc_forward_train")
+        torch.autograd.graph.increment_version(tb.buffers)        # running statistics were updated in place
+        ctx.eng, ctx.tb, ctx.keep = eng, tb, (img, keep, preds)
+        ctx.mark_non_differentiable(*preds)
+        return (losses, *preds)
+
+    @staticmethod
+    def backward(ctx, grad_losses, *unused):
+        eng, tb = ctx.eng, ctx.tb
+        g = grad_losses.contiguous().float()
+        with torch.cuda.device(g.device):
+            rc = eng.lib.mc_backward(eng.h, C.c_void_p(g.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(eng.h, rc, "mc_backward")
+        out = []
+        for n, _ in tb.named:
+            gb = tb.grads.get(n)
+            out.append(None if gb is None else gb.clone())      # torch owns what it accumulates into .grad
+        return (None, None, None, None, None, None, *out)
+
+
+def forward_train(detector, data_dict):
+    img = data_dict["img"]
+    if not img.is_cuda:
+        raise _lib.MonoconHipError("img must live on a HIP device; libmonocon_hip has no CPU path")
+    label = data_dict["label"]
+    if float(label["mask"].sum()) == 0:
+        # the reference asserts on empty targets (losses/l1_loss.py:15, README.MD:208-210)
+        raise AssertionError("no valid objects in the batch: l1_loss requires target.numel() > 0")
+    tb = _binding(detector)
+    eng = detector._rt.get(tb.state(detector))
+    params = [p for _, p in tb.named]
+    out = _HipTrainStep.apply(detector, tb, eng, img.contiguous(), label, detector.head.max_objs, *params)
+    losses, preds = out[0], out[1:]
+    pred_dict = dict(zip(PRED_KEYS, preds))
+    loss_dict = {k: losses[i] for i, k in enumerate(netspec.LOSS_KEYS)}
+    return pred_dict, loss_dict

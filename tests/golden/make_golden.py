@@ -145,6 +145,19 @@ def main():
             out["buf." + k] = newsd[k]
     for k, v in pred.items():
         out["pred." + k + ".sample"] = strided(v, 31)
+    # the same step in fp64: the yard-stick for gradient parity (on this B=2 train-mode-BN fixture the
+    # reference's own fp32 gradients sit 5e-3..2e-2 from its fp64 gradients in the backbone)
+    mt64 = ref_model(sd, train=True, double=True)
+    b64 = synth.make_batch(SEED + 4, 2, hb, wb)
+    b64["img"] = b64["img"].double()
+    _, loss64 = mt64(b64)
+    sum(v for v in loss64.values()).backward()
+    for n, p in mt64.named_parameters():
+        if p.grad is not None:
+            out["gnorm64." + n] = p.grad.norm()
+            out["gsample64." + n] = strided(p.grad, 101)
+    for k, v in loss64.items():
+        out["f64." + k] = v if torch.is_tensor(v) else torch.tensor(float(v))
     save("train_step.npz", **out)
     assert sorted(dead) == sorted(netspec.DEAD_PARAMS), dead
 

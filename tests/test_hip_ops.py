@@ -111,3 +111,38 @@ def test_layout_roundtrip(eng):
     y = eng.to_nhwc(x)
     assert torch.equal(y.cpu(), x.cpu().permute(0, 2, 3, 1))
     assert torch.equal(eng.to_nchw(y).cpu(), x.cpu())
+
+
+WGRAD_CASES = [
+    # (name, B, H, W, [Cin...], Cout, k, stride)
+    ("wg_s1_64_64", 2, 16, 24, [64], 64, 3, 1),
+    ("wg_s1_128_128", 2, 12, 40, [128], 128, 3, 1),
+    ("wg_s1_cat_64_64_to64", 2, 8, 16, [64, 64], 64, 3, 1),
+    ("wg_s1_16_16", 1, 20, 24, [16], 16, 3, 1),
+    ("wg_s1_odd", 1, 6, 10, [32], 64, 3, 1),
+    ("wg_s2_32_64", 2, 16, 32, [32], 64, 3, 2),
+    ("wg_s2_16_32", 1, 24, 16, [16], 32, 3, 2),
+    ("wg_s2_256_512", 1, 8, 8, [256], 512, 3, 2),
+    ("wg_k1_root4", 1, 12, 16, [128, 128, 64, 128], 128, 1, 1),
+    ("wg_k1_32_64", 2, 8, 8, [32], 64, 1, 1),
+    ("wg_head_64_576", 1, 8, 16, [64], 576, 3, 1),
+    ("wg_s2_128_256_24x48", 2, 24, 48, [128], 256, 3, 2),
+    ("wg_s1_256_256_12x24", 2, 12, 24, [256], 256, 3, 1),
+    ("wg_s2_64_128_48x96", 2, 48, 96, [64], 128, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_wgrad(eng, case):
+    name, B, H, W, cins, cout, k, stride = case
+    seed = 300 + WGRAD_CASES.index(case)
+    xs = [rnd(seed, "x%d" % i, (B, c, H, W)) for i, c in enumerate(cins)]
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    dy = rnd(seed, "dy", (B, cout, Ho, Wo))
+    w = torch.zeros(cout, sum(cins), k, k, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(torch.cat(xs, 1).double(), w, None, stride, k // 2)
+    out.backward(dy.double())
+    dev = eng.device
+    got = eng.op_conv_wgrad([nhwc(x).to(dev) for x in xs], nhwc(dy).to(dev), k, stride).cpu()
+    assert got.shape == w.grad.shape
+    assert rel_err(got, w.grad) < 5e-6
