@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=3,
+                    help="also time this many full train steps (fwd+targets+losses+bwd+all-reduce+clip+AdamW); 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
 
@@ -77,6 +79,55 @@ def cpu_baseline(sd, height, width, budget_s):
     return {"value": round(2 / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle eval forward, B=2 x 3x%dx%d fp32, median of %d runs (%.3f s/run)"
                       % (height, width, len(times), med)}
+
+
+def time_train_steps(args, sd, rank, world, dist_on, sync_all):
+    """Full train step through the drop-in API (model.detector + solver): train-mode forward with
+    batch-statistics BN, target generation, the ten losses, backward, gradient all-reduce (N > 1),
+    fused clip + AdamW, cyclic schedule.  fp32 throughout (BASELINE configs[2] asks for bf16
+    activations; not built yet -- this is the fp32 reference-precision step)."""
+    from hipmonocon import synth
+    from model import MonoConDetector
+    from solver import AdamW, CyclicScheduler
+    B, H, W = args.batch, args.height, args.width
+    m = MonoConDetector(34, pretrained_backbone=False)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    opt = AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=35.0)
+    sch = CyclicScheduler(opt, total_steps=1000)
+    nb = min(B, 8)
+    small = synth.make_batch(500 + rank, nb, H, W)
+    rep = (B + nb - 1) // nb
+    batch = {"img": small["img"].repeat(rep, 1, 1, 1)[:B].cuda().contiguous(),
+             "label": {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:B].cuda().contiguous() for k, v in small["label"].items()},
+             "img_metas": {"pad_shape": [(H, W)] * B}}
+
+    def step():
+        opt.zero_grad()
+        _, loss = m(batch)
+        total = sum(v for v in loss.values())
+        total.backward()
+        opt.step()
+        sch.step()
+        return total
+
+    step()                       # warm-up (builds the plan)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        total = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(total))
+    del m, opt
+    return {"images_per_sec": round(world * B * args.train_steps / dt, 2), "ms_per_step": round(dt / args.train_steps * 1e3, 2),
+            "steps": args.train_steps, "batch_per_gpu": B, "dtype": "f32",
+            "what": "fwd(train BN)+targets+losses+bwd+%sclip+AdamW+cyclic schedule" % ("grad all-reduce+" if world > 1 else "")}
 
 
 def main():
@@ -130,6 +181,10 @@ def main():
         elapsed = float(t.item())
     assert all(torch.isfinite(v).all() for v in preds.values())
 
+    train = None
+    if args.train_steps > 0:
+        train = time_train_steps(args, sd, rank, world, dist_on, sync_all)
+
     if rank == 0:
         cost = eng.forward_cost(B, H, W)
         flops = cost["conv_flops"] + cost["other_flops"]
@@ -164,6 +219,8 @@ def main():
             },
             "workspace_gb": round(eng.workspace_bytes() / 1e9, 2),
         }
+        if train is not None:
+            out["train_step"] = train
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, H, W, args.cpu_seconds)
         print(json.dumps(out), flush=True)

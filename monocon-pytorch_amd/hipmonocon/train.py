@@ -12,6 +12,7 @@ import ctypes as C
 
 import torch
 
+from . import dist as _dist
 from . import lib as _lib
 from . import netspec
 
@@ -27,7 +28,10 @@ class _TrainBinding:
     def __init__(self, detector):
         self.named = [(n, p) for n, p in detector.named_parameters()]
         self.live = [(n, p) for n, p in self.named if n not in DEAD]
-        self.grads = {n: torch.zeros_like(p) for n, p in self.live}
+        # all live gradients in one contiguous buffer: the kernels write into its views, the data-
+        # parallel all-reduce runs once over the whole buffer (hipmonocon/dist.py)
+        self.flat = _dist.FlatGrads(self.live, self.named[0][1].device)
+        self.grads = self.flat.views
         self.buffers = [b for _, b in detector.named_buffers()]
         self.sig = tuple(p.data_ptr() for _, p in self.named)
 
@@ -81,10 +85,16 @@ class _HipTrainStep(torch.autograd.Function):
         with torch.cuda.device(g.device):
             rc = eng.lib.mc_backward(eng.h, C.c_void_p(g.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(eng.h, rc, "mc_backward")
+        tb.flat.allreduce_mean()                                  # data parallel: one RCCL all-reduce per step
         out = []
-        for n, _ in tb.named:
+        for n, p in tb.named:
             gb = tb.grads.get(n)
-            out.append(None if gb is None else gb.clone())      # torch owns what it accumulates into .grad
+            if gb is None:
+                out.append(None)
+            elif p.grad is None:
+                out.append(gb)            # becomes p.grad as a view of the flat buffer (no copy)
+            else:
+                out.append(gb.clone())    # caller is accumulating across backward passes: torch adds a copy
         return (None, None, None, None, None, None, *out)
 
 
@@ -97,6 +107,11 @@ def forward_train(detector, data_dict):
         # the reference asserts on empty targets (losses/l1_loss.py:15, README.MD:208-210)
         raise AssertionError("no valid objects in the batch: l1_loss requires target.numel() > 0")
     tb = _binding(detector)
+    for n, p in tb.live:
+        # a .grad that still aliases the flat buffer (zero_grad(set_to_none=False)) would be overwritten
+        # by the kernels before torch can accumulate into it: give torch its own copy in that case
+        if p.grad is not None and p.grad.data_ptr() == tb.grads[n].data_ptr():
+            p.grad = p.grad.clone()
     eng = detector._rt.get(tb.state(detector))
     params = [p for _, p in tb.named]
     out = _HipTrainStep.apply(detector, tb, eng, img.contiguous(), label, detector.head.max_objs, *params)
