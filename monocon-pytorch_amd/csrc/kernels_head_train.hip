@@ -149,8 +149,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void attn_train_fwd_kernel(const AttnTrainArgs a) {
-    const int h = blockIdx.x, c = threadIdx.x;
+// reduce a per-thread (s1, s2) pair across the 16 row-groups of a 1024-thread workgroup (lane = channel)
+__device__ __forceinline__ void group_reduce2(double &s1, double &s2, double (*sh)[64][2], int grp, int c) {
+    __syncthreads();
+    sh[grp][c][0] = s1; sh[grp][c][1] = s2;
+    __syncthreads();
+    s1 = 0; s2 = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { s1 += sh[g][c][0]; s2 += sh[g][c][1]; }
+}
+
+__global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArgs a) {
+    __shared__ double shred[16][64][2];
+    const int h = blockIdx.x, c = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int CP = NUM_HEADS * HEAD_CH, ch = h * HEAD_CH + c;
     const double HW = (double)a.HW, n = HW * a.B;
     __shared__ float att[64][NUM_AFFINE];          // a[b][k] then y[b][k]   (B <= 64)
@@ -158,11 +169,13 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const AttnTrainArgs 
     double S1 = 0, S2 = 0;
     for (int b = 0; b < a.B; ++b) {
         double s1 = 0, s2 = 0;
-        for (int k = 0; k < a.chunks; ++k) {
+        for (int k = grp; k < a.chunks; k += 16) {
             const float *q = a.stats + (((size_t)b * a.chunks + k) * a.stat_ld + ch) * 2;
             s1 += q[0]; s2 += q[1];
         }
+        group_reduce2(s1, s2, shred, grp, c);   // every row-group now holds the full per-image sums
         S1 += s1; S2 += s2;
+        if (grp != 0) continue;                 // wave 0 (lane = channel) does the per-image attention input
         const double m0 = s1 / HW;
         const double mean = shift0 + m0, var = (s2 - s1 * m0) / (HW - 1.0);
         const float sv = (float)(mean / sqrt(var + 1e-3));
@@ -179,14 +192,16 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const AttnTrainArgs 
     double var = S2 / n - m0 * m0;
     if (var < 0) var = 0;
     const float r = (float)(1.0 / sqrt(var + 1e-3));
-    a.mu_r[ch * 2 + 0] = (float)mu;
-    a.mu_r[ch * 2 + 1] = r;
-    a.rm[h][c] = (1.f - 0.03f) * a.rm[h][c] + 0.03f * (float)mu;
-    a.rv[h][c] = (1.f - 0.03f) * a.rv[h][c] + 0.03f * (float)(var * n / (n - 1.0));
-    if (c == 0) *a.nbt[h] += 1;
+    if (grp == 0) {
+        a.mu_r[ch * 2 + 0] = (float)mu;
+        a.mu_r[ch * 2 + 1] = r;
+        a.rm[h][c] = (1.f - 0.03f) * a.rm[h][c] + 0.03f * (float)mu;
+        a.rv[h][c] = (1.f - 0.03f) * a.rv[h][c] + 0.03f * (float)(var * n / (n - 1.0));
+        if (c == 0) *a.nbt[h] += 1;
+    }
     __syncthreads();
     // BN(10) over the batch dimension (train mode): lane k < 10 owns attention channel k
-    if (c < NUM_AFFINE) {
+    if (grp == 0 && c < NUM_AFFINE) {
         double s = 0, q = 0;
         for (int b = 0; b < a.B; ++b) { s += att[b][c]; }
         const double am = s / a.B;
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const AttnTrainArgs 
         }
     }
     __syncthreads();
-    for (int b = 0; b < a.B; ++b) {
+    for (int b = grp; b < a.B; b += 16) {
         float gam = 0.f, bet = 0.f;
 #pragma unroll
         for (int k = 0; k < NUM_AFFINE; ++k) {
@@ -223,15 +238,16 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const AttnTrainArgs 
 }
 hipError_t launch_attn_train_fwd(const AttnTrainArgs &a, hipStream_t st) {
     if (a.B > 64 || a.B < 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(NUM_HEADS), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(NUM_HEADS), dim3(1024), 0, st, a);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ AttnBN train backward (one WG per head)
 // partial: [B*rb][576][2] = per row-block (sum dout, sum dout*x), dout = dh*[h>0]
-__global__ __launch_bounds__(64) void attn_train_bwd_kernel(const AttnTrainArgs a, const float *__restrict__ partial,
-                                                            int rb_per_img, AttnGradPtrs gp, float *__restrict__ coef) {
-    const int h = blockIdx.x, c = threadIdx.x;
+__global__ __launch_bounds__(1024) void attn_train_bwd_kernel(const AttnTrainArgs a, const float *__restrict__ partial,
+                                                              int rb_per_img, AttnGradPtrs gp, float *__restrict__ coef) {
+    __shared__ double shred[16][64][2];
+    const int h = blockIdx.x, c = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int CP = NUM_HEADS * HEAD_CH, ch = h * HEAD_CH + c;
     const double HW = (double)a.HW, n = HW * a.B;
     const float mu = a.mu_r[ch * 2], r = a.mu_r[ch * 2 + 1];
@@ -240,16 +256,19 @@ __global__ __launch_bounds__(64) void attn_train_bwd_kernel(const AttnTrainArgs 
     double M1 = 0, M2 = 0;
     for (int b = 0; b < a.B; ++b) {
         double d1 = 0, d2 = 0;
-        for (int k = 0; k < rb_per_img; ++k) {
+        for (int k = grp; k < rb_per_img; k += 16) {
             const float *q = partial + (((size_t)b * rb_per_img + k) * CP + ch) * 2;
             d1 += q[0]; d2 += q[1];
         }
+        group_reduce2(d1, d2, shred, grp, c);
         const float db = (float)d1, dg = (float)(r * (d2 - mu * d1));
         dbet[b][c] = db; dgam[b][c] = dg;
         const float gp_ = a.gamma_p[(size_t)b * CP + ch];
         M1 += (double)gp_ * db; M2 += (double)gp_ * dg;
     }
     M1 /= n; M2 /= n;
+    __syncthreads();
+    if (grp != 0) return;      // the rest is small: one wave (lane = channel); no block-wide barrier below is skipped
     // gradients of weight_ / bias_ and dy[b][k]
     for (int k = 0; k < NUM_AFFINE; ++k) {
         float gw = 0.f, gb = 0.f;
@@ -312,7 +331,7 @@ __global__ __launch_bounds__(64) void attn_train_bwd_kernel(const AttnTrainArgs 
 hipError_t launch_attn_train_bwd(const AttnTrainArgs &a, const float *partial, int rb_per_img, const AttnGradPtrs &gp,
                                  float *coef, hipStream_t st) {
     if (a.B > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(NUM_HEADS), dim3(64), 0, st, a, partial, rb_per_img, gp, coef);
+    hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(NUM_HEADS), dim3(1024), 0, st, a, partial, rb_per_img, gp, coef);
     return hipGetLastError();
 }
 

@@ -248,20 +248,24 @@ hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st) {
     return hipGetLastError();
 }
 
-// column sums of a [rows][C] matrix -> out[C] (conv bias gradients); one workgroup per 4 columns group
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ x, size_t rows, int C, int ld,
-                                                     float *__restrict__ out) {
+// column sums of a [rows][ld] matrix -> out[C] (conv bias gradients): coalesced row-block partial sums
+// (chan_reduce, mode 0) followed by a per-column reduction of the partials
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ partial, int nb, int Cstride,
+                                                           float *__restrict__ out) {
     const int c = blockIdx.x;
     double s = 0;
-    for (size_t r = threadIdx.x; r < rows; r += 256) s += x[r * ld + c];
+    for (int i = threadIdx.x; i < nb; i += 256) s += partial[((size_t)i * Cstride + c) * 2];
     __shared__ double sh[4];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) out[c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
-hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *out, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(C), dim3(256), 0, st, x, rows, C, ld, out);
+size_t colsum_partial_floats(size_t rows, int ld) { return (size_t)chan_reduce_blocks(1, (int)rows) * ld * 2; }
+hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st) {
+    hipError_t e = launch_chan_reduce(x, nullptr, nullptr, nullptr, 1, (int)rows, ld, 0, 0, partial, ld, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, st, partial, chan_reduce_blocks(1, (int)rows), ld, out);
     return hipGetLastError();
 }
 

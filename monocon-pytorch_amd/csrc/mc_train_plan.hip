@@ -471,12 +471,13 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
     // ---- losses -> raw gradients -> heads
     {
         float *draw = b.alloc(raw.numel());
+        float *cs1 = b.alloc(colsum_partial_floats((size_t)B * HW, LD));
         float *db1 = b.alloc(NUM_OUT_ROWS), *dw1dense = b.alloc((size_t)NUM_OUT_ROWS * CP), *dw1 = b.alloc((size_t)NUM_OUT_ROWS * HEAD_CH);
         Tensor drawT = raw; drawT.p = draw;
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
             if (mc_losses_backward(hh, ts->preds, &ts->targets, B, ts->max_objs, fh, fw, ts->grad_losses, ts->dpred, st)) return -1;
             HIPCHK(hh, launch_dpred_pack(ts->dpred, LD, B, HW, draw, st));
-            HIPCHK(hh, launch_colsum(draw, (size_t)B * HW, NUM_OUT_ROWS, LD, db1, st));
+            HIPCHK(hh, launch_colsum(draw, (size_t)B * HW, NUM_OUT_ROWS, LD, cs1, db1, st));
             return 0;
         });
         // dense wgrad of the block-diagonal 1x1, then keep the diagonal blocks
@@ -515,6 +516,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
         const int nbr = chan_reduce_blocks(B, HW), rb_per_img = nbr / B;
         float *partial = b.alloc((size_t)nbr * CP * 2), *coef = b.alloc((size_t)B * CP * 4), *dx = b.alloc(xh.numel());
         float *db3 = b.alloc(CP), *dw3 = b.alloc((size_t)CP * 64 * 9);
+        float *cs3 = b.alloc(colsum_partial_floats((size_t)B * HW, CP));
         Tensor dxT = xh; dxT.p = dx;
         {
             const float *xp = xh.p, *hp = hn.p;
@@ -522,7 +524,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
                 HIPCHK(hh, launch_chan_reduce(xp, dh, hp, nullptr, B, HW, CP, 1, 1, partial, CP, st));
                 HIPCHK(hh, launch_attn_train_bwd(at, partial, rb_per_img, gp, coef, st));
                 HIPCHK(hh, launch_affine_bwd(dh, hp, xp, coef, B, (size_t)HW, CP, 1, 1, dx, nullptr, 0, st));
-                HIPCHK(hh, launch_colsum(dx, (size_t)B * HW, CP, CP, db3, st));
+                HIPCHK(hh, launch_colsum(dx, (size_t)B * HW, CP, CP, cs3, db3, st));
                 return 0;
             });
         }

@@ -65,7 +65,8 @@ hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, dou
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st);
 hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st);
-hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *out, hipStream_t st);
+size_t colsum_partial_floats(size_t rows, int ld);
+hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st);
 hipError_t launch_dilate2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
 hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
                                hipStream_t st);
