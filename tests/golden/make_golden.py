@@ -206,7 +206,7 @@ def main():
         mdec = ref_model(sd, test_config={"topk": K, "local_maximum_kernel": 3, "max_per_img": 30,
                                           "test_thres": 0.4})
         pd_ = {k: torch.from_numpy(v.copy()) for k, v in d.items()}
-        data = {"img_metas": {"pad_shape": [(384, 1280)] * 4}, "calib": [synth.SynthCalib() for _ in range(4)]}
+        data = {"img": torch.zeros(4, 3, 384, 1280), "img_metas": {"pad_shape": [(384, 1280)] * 4}, "calib": [synth.SynthCalib() for _ in range(4)]}
         # dense intermediates through the reference's own helpers
         from utils.tensor_ops import get_local_maximum, get_topk_from_heatmap
         filt_ref = get_local_maximum(pd_["center_heatmap_pred"], kernel=3)
@@ -218,6 +218,16 @@ def main():
             out["box2d.%d" % i] = b2d[i]
             out["box3d.%d" % i] = b3d[i]
             out["label.%d" % i] = labs[i]
+        if K == 30:      # KITTI annotation dicts produced by the reference for the same decode
+            data["img_metas"]["ori_shape"] = [(375, 1242)] * 4
+            data["img_metas"]["sample_idx"] = [11, 12, 13, 14]
+            fmt = mdec.head._get_eval_formats(data, {k: v.clone() for k, v in pd_.items()})
+            for i in range(4):
+                for field in ("img_bbox", "img_bbox2d"):
+                    a = fmt[field][i]
+                    for kk in ("alpha", "bbox", "dimensions", "location", "rotation_y", "score", "sample_idx"):
+                        out["kitti.%s.%d.%s" % (field, i, kk)] = np.asarray(a[kk], dtype=np.float64)
+                    out["kitti.%s.%d.name" % (field, i)] = np.array([("Pedestrian", "Cyclist", "Car").index(n) for n in a["name"]], dtype=np.int64)
         save("decode_k%d.npz" % K, **out)
 
     json.dump(META, open(os.path.join(HERE, "meta.json"), "w"), indent=1)

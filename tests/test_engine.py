@@ -75,3 +75,30 @@ def test_engine_trains_checkpoints_and_resumes(tmp_path):
     assert all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a)
     ev = eng2.evaluate()
     assert ev['num_results'] == 2.0
+
+
+def test_kitti_conversion_matches_reference_golden():
+    """utils/kitti_convert_utils.py (host-side) against the reference's annos for the same decode."""
+    import numpy as np
+    from conftest import load_golden
+    from hipmonocon import synth
+    from utils.kitti_convert_utils import CLASSES, convert_to_kitti_2d, convert_to_kitti_3d
+    g = load_golden("decode_k30.npz")
+    metas = {"ori_shape": [(375, 1242)] * 4, "sample_idx": [11, 12, 13, 14]}
+    res3d, res2d = [], []
+    for i in range(4):
+        b2, b3, lab = g["box2d.%d" % i], g["box3d.%d" % i], g["label.%d" % i]
+        res3d.append({"boxes_3d": torch.from_numpy(b3), "scores_3d": torch.from_numpy(b2[:, 4]), "labels_3d": torch.from_numpy(lab)})
+        res2d.append([b2[lab == c] for c in range(3)])
+    k3 = convert_to_kitti_3d(res3d, metas, [synth.SynthCalib() for _ in range(4)])
+    k2 = convert_to_kitti_2d(res2d, metas)
+    for field, ours in (("img_bbox", k3), ("img_bbox2d", k2)):
+        for i in range(4):
+            a = ours[i]
+            names = g["kitti.%s.%d.name" % (field, i)]
+            assert [CLASSES.index(n) for n in a["name"]] == names.tolist()
+            for kk in ("alpha", "bbox", "dimensions", "location", "rotation_y", "score", "sample_idx"):
+                ref = g["kitti.%s.%d.%s" % (field, i, kk)]
+                got = np.asarray(a[kk], dtype=np.float64)
+                assert got.shape == ref.shape, (field, i, kk, got.shape, ref.shape)
+                assert np.allclose(got, ref, rtol=1e-5, atol=1e-4), (field, i, kk)

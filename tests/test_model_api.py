@@ -106,3 +106,18 @@ def test_batch_eval_vis_format_matches_oracle(golden_sd):
         assert sum(len(x) for x in r["img_bbox2d"]) == int(mk.sum())
     b2, b3, lab = m.head.decode_heatmap(data, pred)
     assert rel_err(b3[0], ref["box3d"][0][ref["box_mask"][0]]) < 1e-4      # un-shifted centres
+
+
+@pytest.mark.gpu
+def test_batch_eval_kitti_format(golden_sd):
+    """default batch_eval output: KITTI annotation dicts (reference monocon_heads.py:363-376)."""
+    m = build(golden_sd, test_config={"topk": 30, "local_maximum_kernel": 3, "max_per_img": 30,
+                                      "test_thres": 0.05}).cuda().eval()
+    batch = synth.make_batch(31, 2, 96, 160, with_labels=False)
+    data = {"img": batch["img"].cuda(), "img_metas": batch["img_metas"], "calib": batch["calib"]}
+    out = m.batch_eval(data)
+    assert set(out) == {"img_bbox", "img_bbox2d"} and len(out["img_bbox"]) == len(out["img_bbox2d"]) == 2
+    for a in out["img_bbox"] + out["img_bbox2d"]:
+        n = len(a["score"])
+        assert a["bbox"].shape == (n, 4) and a["location"].shape == (n, 3) and a["dimensions"].shape == (n, 3)
+        assert len(a["name"]) == len(a["alpha"]) == len(a["rotation_y"]) == len(a["sample_idx"]) == n
