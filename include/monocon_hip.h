@@ -201,6 +201,10 @@ int mc_op_nchw_to_nhwc(mc_handle *h, const float *in, int B, int C, int H, int W
 int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W, float *out,
                        void *stream);
 
+/* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
+ * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel; 0 = automatic)
+ * for mc_op_conv and for every layer of plans built afterwards that has no fixed shape. */
+int mc_set_conv_cfg(mc_handle *h, int cfg);
 /* Tuning aid: average duration (ms) of `iters` launches of one fused-conv shape on random data.
  * cfg: workgroup shape id (0 = the library's own choice; see csrc/conv_mfma.h ConvCfgId). */
 int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src_channels[],

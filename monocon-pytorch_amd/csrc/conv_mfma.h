@@ -70,19 +70,129 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = sizeof(float) * LDS_FLOATS;
 };
 
+// Buffer-addressed memory access: every global access of the kernel goes through a buffer
+// resource (SGPR descriptor) + one lane offset kept in a VGPR + a wave-uniform SGPR offset, so
+// the K loop issues no vector-ALU address arithmetic at all -- on CDNA the MFMA shares the VALU
+// issue port, and every v_mad/v_cndmask of ANY wave on the SIMD displaces matrix issue slots
+// (measured: a staging wave next to an MFMA wave advances ~10x slower than alone).  Offsets
+// >= num_records read as zero / drop the store, which also replaces the halo and edge branches.
+constexpr int BUF_OOB = (int)0x80000000;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+
+// Epilogue shared by both kernel variants.  C/D layout of v_mfma_f32_32x32x2: column = lane&31,
+// row m = (r&3) + 8*(r>>2) + 4*(lane>>5); row m of a 4x8 patch is pixel (oy0 + (m>>3), ox0 + (m&7))
+// = (oy0 + (r>>2), ox0 + (r&3) + 4*(lane>>5)).
+template <int WM, int WN, int WTM, int WTN, int BNT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[WTM][WTN], const int *pinfo,
+                                              float *sred, int img, int n0, int wm, int wn, int g, int li) {
+    const bool do_stats = a.stats != nullptr;
+    const bool has_res = a.res != nullptr;
+    const float floor_v = a.relu ? 0.f : -__builtin_inff();
+    const __amdgpu_buffer_rsrc_t r_out =
+        make_rsrc(a.out + (size_t)img * a.Hout * a.Wout * a.out_ld, (unsigned)(a.Hout * a.Wout * a.out_ld) * 4u);
+    const __amdgpu_buffer_rsrc_t r_res =
+        make_rsrc(has_res ? a.res + (size_t)img * a.Hout * a.Wout * a.res_ld : a.out,
+                  has_res ? (unsigned)(a.Hout * a.Wout * a.res_ld) * 4u : 0u);
+    float ssum[WTN], ssq[WTN];
+#pragma unroll
+    for (int tn = 0; tn < WTN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < WTN; ++tn) {
+        const int n = n0 + (wn * WTN + tn) * 32 + li;
+        const bool nok = n < a.Cout;
+        const float sc = (a.scale && nok) ? a.scale[n] : 1.f;
+        const float bi = (a.bias && nok) ? a.bias[n] : 0.f;
+        const float sh = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
+        const int v_out = nok ? (4 * g * a.out_ld + a.out_coff + n) * 4 : BUF_OOB;
+        const int v_res = nok ? (4 * g * a.res_ld + n) * 4 : BUF_OOB;
+#pragma unroll
+        for (int tm = 0; tm < WTM; ++tm) {
+            const int p = wm * WTM + tm;
+            const int oy0 = __builtin_amdgcn_readfirstlane(pinfo[p * 4 + 1]);
+            const int ox0 = __builtin_amdgcn_readfirstlane(pinfo[p * 4 + 2]);
+            const int pv = __builtin_amdgcn_readfirstlane(pinfo[p * 4 + 3]);
+            if (!pv) continue;
+            if (oy0 + 4 <= a.Hout && ox0 + 8 <= a.Wout) {
+                // whole patch inside the image: wave-uniform offsets only
+                const int s_out = (oy0 * a.Wout + ox0) * a.out_ld * 4;
+                const int s_res = (oy0 * a.Wout + ox0) * a.res_ld * 4;
+                float rv[16];
+                if (has_res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        rv[r] = buf_load1(r_res, v_res, s_res + ((r >> 2) * a.Wout + (r & 3)) * a.res_ld * 4);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[tm][tn][r] * sc + bi;
+                    if (has_res) v += rv[r];
+                    if (do_stats) {
+                        const float d = v - sh;
+                        ssum[tn] += d;
+                        ssq[tn] += d * d;
+                    }
+                    v = fmaxf(v, floor_v);
+                    buf_store1(v, r_out, v_out, s_out + ((r >> 2) * a.Wout + (r & 3)) * a.out_ld * 4);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int y = oy0 + (r >> 2), x = ox0 + (r & 3) + 4 * g;
+                    if (nok && y < a.Hout && x < a.Wout) {
+                        const int pixel = y * a.Wout + x;
+                        float v = acc[tm][tn][r] * sc + bi;
+                        if (has_res) v += buf_load1(r_res, (pixel * a.res_ld + n) * 4, 0);
+                        const float d = v - sh;
+                        ssum[tn] += d;
+                        ssq[tn] += d * d;
+                        v = fmaxf(v, floor_v);
+                        buf_store1(v, r_out, (pixel * a.out_ld + a.out_coff + n) * 4, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (do_stats) {
+#pragma unroll
+        for (int tn = 0; tn < WTN; ++tn) {
+            ssum[tn] += __shfl_xor(ssum[tn], 32);
+            ssq[tn] += __shfl_xor(ssq[tn], 32);
+            if (g == 0) {
+                const int nl = (wn * WTN + tn) * 32 + li;
+                sred[(wm * BNT + nl) * 2 + 0] = ssum[tn];
+                sred[(wm * BNT + nl) * 2 + 1] = ssq[tn];
+            }
+        }
+    }
+}
+
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvArgs a) {
     using Cfg = ConvCfg<KS, S, CK, WM, WN, WTM, WTN>;
     constexpr int PB = Cfg::PB, BNT = Cfg::BNT, NT = Cfg::NT, PAD = Cfg::PAD;
     constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, CKP = Cfg::CKP;
     constexpr int C4 = CK / 4;
+    static_assert(NT % C4 == 0, "a thread keeps one channel group across its staging elements");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int *pinfo = reinterpret_cast<int *>(lds + PB * NPIX * CKP);   // [PB][4] = b, oy0, ox0, valid
     float *sred = lds + PB * NPIX * CKP + PB * 4;                    // [WM][BNT][2]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int g = lane >> 5, li = lane & 31;
 
@@ -101,6 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
         pinfo[tid * 4 + 2] = px * 8;
         pinfo[tid * 4 + 3] = valid;
     }
+    __syncthreads();
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -110,6 +221,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
+    // ---- staging plan: element e = tid + NT*i of the [PB][NPIX][C4] halo tile.  Its input pixel
+    //      does not depend on the K-chunk, so the lane offsets are resolved once per source; inside
+    //      the K loop a chunk is NIT buffer loads (SGPR chunk offset) + NIT ds_write_b128 at
+    //      immediate offsets.
+    constexpr int TOTAL = PB * NPIX * C4;
+    constexpr int NIT = (TOTAL + NT - 1) / NT;
+    const int c4 = tid % C4;
+    float *stage_dst = lds + (tid / C4) * CKP + c4 * 4;
+
     // A-fragment base offsets (floats) inside the LDS image for this lane
     int a_off[WTM];
 #pragma unroll
@@ -117,16 +237,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
         a_off[tm] = ((wm * WTM + tm) * NPIX + ((li >> 3) * S) * IW + (li & 7) * S) * CKP + 4 * g;
 
     const int Cin4 = a.Cin >> 2;
-    const size_t colP = (size_t)a.CoutP;
-    const float *wlane = a.wpk + ((size_t)g * colP + n0 + wn * WTN * 32 + li) * 4;
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk, (unsigned)(KS * KS * a.Cin * a.CoutP) * 4u);
+    const int w_lane = (g * a.CoutP + n0 + wn * WTN * 32 + li) * 16;   // bytes
 
     // B fragment of step s (= tap * CK/8 + k8) of the K-chunk starting at concat channel kc
     constexpr int K8 = CK / 8, NS = KS * KS * K8;
     auto load_b = [&](f32x4(&dst)[WTN], int kc, int s) {
         const int tap = s / K8, k8 = s % K8;
-        const float *wp = wlane + ((size_t)(tap * Cin4 + ((kc + k8 * 8) >> 2)) * colP) * 4;
+        const int soff = (tap * Cin4 + ((kc + k8 * 8) >> 2)) * a.CoutP * 16;
 #pragma unroll
-        for (int tn = 0; tn < WTN; ++tn) dst[tn] = *reinterpret_cast<const f32x4 *>(wp + tn * 32 * 4);
+        for (int tn = 0; tn < WTN; ++tn) dst[tn] = buf_load4(r_w, w_lane + tn * 32 * 16, soff);
     };
     auto load_a = [&](f32x4(&dst)[WTM], int s) {
         const int tap = s / K8, k8 = s % K8;
@@ -140,27 +260,38 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
 
     int kbase = 0;   // channel offset of the current source inside the virtual concat
     for (int si = 0; si < a.nsrc; ++si) {
-        const float *sp = a.src[si].p;
         const int Cs = a.src[si].C;
+        const __amdgpu_buffer_rsrc_t r_in =
+            make_rsrc(a.src[si].p + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
+        int voff[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + NT * i;
+            const int t = e / C4;
+            const int pix = t % NPIX;
+            const int p = (t / NPIX) % PB;
+            const int iy = pix / IW, ix = pix % IW;
+            const int y = pinfo[p * 4 + 1] * S - PAD + iy;
+            const int x = pinfo[p * 4 + 2] * S - PAD + ix;
+            const bool ok = e < TOTAL && pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
+            voff[i] = ok ? ((y * a.Win + x) * Cs + c4 * 4) * 4 : BUF_OOB;
+        }
         for (int c0 = 0; c0 < Cs; c0 += CK) {
-            __syncthreads();   // previous chunk's fragment reads done (also publishes pinfo)
+            if (kbase + c0 > 0) __syncthreads();   // previous chunk's fragment reads done
             // ---- stage [PB][NPIX][CK] input halo, zero-filled outside the image
-            constexpr int TOTAL = PB * NPIX * C4;
-#pragma unroll 4
-            for (int e = tid; e < TOTAL; e += NT) {
-                const int c4 = e % C4;
-                const int t = e / C4;
-                const int pix = t % NPIX;
-                const int p = t / NPIX;
-                const int iy = pix / IW, ix = pix % IW;
-                const int pb = pinfo[p * 4 + 0];
-                const int y = pinfo[p * 4 + 1] * S - PAD + iy;
-                const int x = pinfo[p * 4 + 2] * S - PAD + ix;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win)
-                    v = *reinterpret_cast<const f32x4 *>(
-                        sp + (((size_t)pb * a.Hin + y) * a.Win + x) * Cs + c0 + c4 * 4);
-                *reinterpret_cast<f32x4 *>(&lds[(p * NPIX + pix) * CKP + c4 * 4]) = v;
+            constexpr int UB = NIT > 8 ? 8 : NIT;   // loads in flight per batch
+#pragma unroll
+            for (int i0 = 0; i0 < NIT; i0 += UB) {
+                f32x4 v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (i0 + u < NIT) v[u] = buf_load4(r_in, voff[i0 + u], c0 * 4);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int i = i0 + u;
+                    if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL))
+                        *reinterpret_cast<f32x4 *>(stage_dst + i * (NT / C4) * CKP) = v[u];
+                }
             }
             __syncthreads();
             // ---- MFMA over taps x channel groups of 8; both operands are fetched one step ahead
@@ -199,50 +330,239 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(const ConvArgs 
         kbase += Cs;
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float ssum[WTN], ssq[WTN];
+    conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, sred, img, n0, wm, wn, g, li);
+    if (a.stats) {
+        __syncthreads();
+        for (int nl = tid; nl < BNT; nl += NT) {
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int tn = 0; tn < WTN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+            for (int w = 0; w < WM; ++w) {
+                s1 += sred[(w * BNT + nl) * 2 + 0];
+                s2 += sred[(w * BNT + nl) * 2 + 1];
+            }
+            float *dst = a.stats + (((size_t)img * a.chunks + chunk) * a.CoutP + n0 + nl) * 2;
+            dst[0] = s1;
+            dst[1] = s2;
+        }
+    }
+}
+
+// ---- wave-specialised variant -------------------------------------------------------------
+// Same math, same operand layouts and the same accumulation order as conv_mfma_kernel (results are
+// bit-identical), but the workgroup carries one extra PRODUCER wave that stages K-chunk i+1 into
+// the second half of a double-buffered LDS tile while the WM*WN consumer waves run the MFMA steps
+// of chunk i.  One barrier per chunk instead of two, and no MFMA wave ever waits on HBM.
+template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
+struct ConvCfgWS : ConvCfg<KS, S, CK, WM, WN, WTM, WTN> {
+    using Base = ConvCfg<KS, S, CK, WM, WN, WTM, WTN>;
+    static constexpr int NT = 64 * (WM * WN + 1);
+    static constexpr int TILE = Base::PB * Base::NPIX * Base::CKP;
+    static constexpr int LDS_FLOATS = 2 * TILE + Base::PB * 4 + 2 * WM * Base::BNT;
+    static constexpr size_t LDS_BYTES = sizeof(float) * LDS_FLOATS;
+};
+
+template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
+__global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(const ConvArgs a) {
+    using Cfg = ConvCfgWS<KS, S, CK, WM, WN, WTM, WTN>;
+    constexpr int PB = Cfg::PB, BNT = Cfg::BNT, NT = Cfg::NT, PAD = Cfg::PAD;
+    constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, CKP = Cfg::CKP, TILE = Cfg::TILE;
+    constexpr int C4 = CK / 4;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int *pinfo = reinterpret_cast<int *>(lds + 2 * TILE);   // [PB][4] = b, oy0, ox0, valid
+    float *sred = lds + 2 * TILE + PB * 4;                    // [WM][BNT][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave == WM * WN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = lane >> 5, li = lane & 31;
+
+    const int ntiles = a.CoutP / BNT;
+    const int nt = blockIdx.x % ntiles;
+    const int mchunk = blockIdx.x / ntiles;
+    const int img = mchunk / a.chunks, chunk = mchunk % a.chunks;
+    const int n0 = nt * BNT;
+
+    if (tid < PB) {
+        const int pp = chunk * PB + tid;
+        const int valid = pp < a.ppi;
+        const int py = pp / a.ppr, px = pp % a.ppr;
+        pinfo[tid * 4 + 0] = img;
+        pinfo[tid * 4 + 1] = py * 4;
+        pinfo[tid * 4 + 2] = px * 8;
+        pinfo[tid * 4 + 3] = valid;
+    }
+    __syncthreads();
+
+    f32x16 acc[WTM][WTN];
 #pragma unroll
-    for (int tn = 0; tn < WTN; ++tn) {
-        const int n = n0 + (wn * WTN + tn) * 32 + li;
-        const bool nok = n < a.Cout;
-        const float sc = (a.scale && nok) ? a.scale[n] : 1.f;
-        const float bi = (a.bias && nok) ? a.bias[n] : 0.f;
-        const float sh = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
+    for (int tm = 0; tm < WTM; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < WTM; ++tm) {
-            const int p = wm * WTM + tm;
-            const int pb = pinfo[p * 4 + 0], oy0 = pinfo[p * 4 + 1], ox0 = pinfo[p * 4 + 2];
-            const bool pv = pinfo[p * 4 + 3] != 0;
+        for (int tn = 0; tn < WTN; ++tn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * g;
-                const int y = oy0 + (m >> 3), x = ox0 + (m & 7);
-                if (pv && nok && y < a.Hout && x < a.Wout) {
-                    const size_t pixel = ((size_t)pb * a.Hout + y) * a.Wout + x;
-                    float v = acc[tm][tn][r] * sc + bi;
-                    if (a.res) v += a.res[pixel * a.res_ld + n];
-                    const float d = v - sh;
-                    ssum[tn] += d;
-                    ssq[tn] += d * d;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.out[pixel * a.out_ld + a.out_coff + n] = v;
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    if (producer) {
+        // ---- producer wave: element e = lane + 64*i of the [PB][NPIX][C4] tile; the input pixel of
+        //      each element does not depend on the chunk, so it is resolved once.
+        constexpr int TOTAL = PB * NPIX * C4;
+        constexpr int NIT = (TOTAL + 63) / 64;
+        int pidx[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = lane + 64 * i;
+            const int t = e / C4;
+            const int pix = t % NPIX;
+            const int p = (t / NPIX) % PB;
+            const int iy = pix / IW, ix = pix % IW;
+            const int y = pinfo[p * 4 + 1] * S - PAD + iy;
+            const int x = pinfo[p * 4 + 2] * S - PAD + ix;
+            const bool ok = e < TOTAL && pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
+            pidx[i] = ok ? (pinfo[p * 4 + 0] * a.Hin + y) * a.Win + x : -1;
+        }
+        constexpr int UB = NIT > 8 ? 8 : NIT;   // loads kept in flight per batch
+        int ci = 0;
+        for (int si = 0; si < a.nsrc; ++si) {
+            const float *sp = a.src[si].p;
+            const int Cs = a.src[si].C;
+            for (int c0 = 0; c0 < Cs; c0 += CK, ++ci) {
+                float *dst = lds + (ci & 1) * TILE;
+                const float *spc = sp + c0 + (lane % C4) * 4;
+#pragma unroll
+                for (int i0 = 0; i0 < NIT; i0 += UB) {
+                    f32x4 v[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int i = i0 + u;
+                        if (i < NIT) {   // unconditional load (clamped pixel) + select, see conv_mfma_kernel
+                            v[u] = *reinterpret_cast<const f32x4 *>(spc + (size_t)(pidx[i] < 0 ? 0 : pidx[i]) * Cs);
+                            if (pidx[i] < 0) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int i = i0 + u;
+                        if (i < NIT) {
+                            const int e = lane + 64 * i;
+                            if (64 * i + 63 < TOTAL || e < TOTAL)
+                                *reinterpret_cast<f32x4 *>(&dst[(e / C4) * CKP + (e % C4) * 4]) = v[u];
+                        }
+                    }
+                }
+                __syncthreads();   // chunk ci is published; consumers are done with chunk ci-1
+            }
+        }
+    } else {
+        int a_off[WTM];
+#pragma unroll
+        for (int tm = 0; tm < WTM; ++tm)
+            a_off[tm] = ((wm * WTM + tm) * NPIX + ((li >> 3) * S) * IW + (li & 7) * S) * CKP + 4 * g;
+
+        const int Cin4 = a.Cin >> 2;
+        const size_t colP = (size_t)a.CoutP;
+        const float *wlane = a.wpk + ((size_t)g * colP + n0 + wn * WTN * 32 + li) * 4;
+
+        constexpr int K8 = CK / 8, NS = KS * KS * K8;
+        auto load_b = [&](f32x4(&dst)[WTN], int kc, int s) {
+            const int tap = s / K8, k8 = s % K8;
+            const float *wp = wlane + ((size_t)(tap * Cin4 + ((kc + k8 * 8) >> 2)) * colP) * 4;
+#pragma unroll
+            for (int tn = 0; tn < WTN; ++tn) dst[tn] = *reinterpret_cast<const f32x4 *>(wp + tn * 32 * 4);
+        };
+        f32x4 bcur[WTN];
+        load_b(bcur, 0, 0);
+        const int nch = a.Cin / CK;
+        __syncthreads();   // chunk 0 staged
+        for (int ci = 0; ci < nch; ++ci) {
+            const float *tile = lds + (ci & 1) * TILE;
+            auto load_a = [&](f32x4(&dst)[WTM], int s) {
+                const int tap = s / K8, k8 = s % K8;
+#pragma unroll
+                for (int tm = 0; tm < WTM; ++tm)
+                    dst[tm] = *reinterpret_cast<const f32x4 *>(
+                        &tile[a_off[tm] + ((tap / KS) * IW + (tap % KS)) * CKP + k8 * 8]);
+            };
+            const int kc = ci * CK;
+            const int kc_next = (ci + 1 < nch) ? kc + CK : kc;
+            f32x4 acur[WTM];
+            load_a(acur, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                f32x4 anext[WTM], bnext[WTN];
+                if (s + 1 < NS) {
+                    load_a(anext, s + 1);
+                    load_b(bnext, kc, s + 1);
+                } else {
+                    load_b(bnext, kc_next, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tm = 0; tm < WTM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < WTN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                acur[tm][j], bcur[tn][j], acc[tm][tn], 0, 0, 0);
+                if (s + 1 < NS) {
+#pragma unroll
+                    for (int tm = 0; tm < WTM; ++tm) acur[tm] = anext[tm];
+                }
+#pragma unroll
+                for (int tn = 0; tn < WTN; ++tn) bcur[tn] = bnext[tn];
+            }
+            if (ci + 1 < nch) __syncthreads();   // chunk ci+1 staged, chunk ci released
+        }
+
+        // ---- epilogue (identical to conv_mfma_kernel)
+        float ssum[WTN], ssq[WTN];
+#pragma unroll
+        for (int tn = 0; tn < WTN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < WTN; ++tn) {
+            const int n = n0 + (wn * WTN + tn) * 32 + li;
+            const bool nok = n < a.Cout;
+            const float sc = (a.scale && nok) ? a.scale[n] : 1.f;
+            const float bi = (a.bias && nok) ? a.bias[n] : 0.f;
+            const float sh = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < WTM; ++tm) {
+                const int p = wm * WTM + tm;
+                const int pb = pinfo[p * 4 + 0], oy0 = pinfo[p * 4 + 1], ox0 = pinfo[p * 4 + 2];
+                const bool pv = pinfo[p * 4 + 3] != 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * g;
+                    const int y = oy0 + (m >> 3), x = ox0 + (m & 7);
+                    if (pv && nok && y < a.Hout && x < a.Wout) {
+                        const size_t pixel = ((size_t)pb * a.Hout + y) * a.Wout + x;
+                        float v = acc[tm][tn][r] * sc + bi;
+                        if (a.res) v += a.res[pixel * a.res_ld + n];
+                        const float d = v - sh;
+                        ssum[tn] += d;
+                        ssq[tn] += d * d;
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        a.out[pixel * a.out_ld + a.out_coff + n] = v;
+                    }
+                }
+            }
+        }
+        if (a.stats) {
+#pragma unroll
+            for (int tn = 0; tn < WTN; ++tn) {
+                ssum[tn] += __shfl_xor(ssum[tn], 32);
+                ssq[tn] += __shfl_xor(ssq[tn], 32);
+                if (g == 0) {
+                    const int nl = (wn * WTN + tn) * 32 + li;
+                    sred[(wm * BNT + nl) * 2 + 0] = ssum[tn];
+                    sred[(wm * BNT + nl) * 2 + 1] = ssq[tn];
                 }
             }
         }
     }
     if (a.stats) {
-#pragma unroll
-        for (int tn = 0; tn < WTN; ++tn) {
-            ssum[tn] += __shfl_xor(ssum[tn], 32);
-            ssq[tn] += __shfl_xor(ssq[tn], 32);
-            if (g == 0) {
-                const int nl = (wn * WTN + tn) * 32 + li;
-                sred[(wm * BNT + nl) * 2 + 0] = ssum[tn];
-                sred[(wm * BNT + nl) * 2 + 1] = ssq[tn];
-            }
-        }
         __syncthreads();
         for (int nl = tid; nl < BNT; nl += NT) {
             float s1 = 0.f, s2 = 0.f;
@@ -269,17 +589,18 @@ struct ConvShape {
 enum ConvCfgId {
     CFG_AUTO = 0,
     CFG_128x128 = 1,    // 2x2 waves, 2x2 tiles : 128 px x 128 ch
-    CFG_256x64 = 2,     // 4x1 waves, 2x2 tiles : 256 px x  64 ch
-    CFG_256x32 = 3,     // 4x1 waves, 2x1 tiles : 256 px x  32 ch
+    CFG_256x64 = 2,     // (retired: 8-patch shapes never won and spill under the 3-waves/SIMD cap)
+    CFG_256x32 = 3,
     CFG_128x64 = 4,     // 2x2 waves, 2x1 tiles : 128 px x  64 ch
     CFG_128x64m = 5,    // 4x1 waves, 1x2 tiles : 128 px x  64 ch (waves split M only)
     CFG_128x32 = 6,     // 4x1 waves, 1x1 tiles : 128 px x  32 ch
     CFG_64x128 = 7,     // 1x4 waves, 2x1 tiles :  64 px x 128 ch
     CFG_64x64 = 8,      // 2x2 waves, 1x1 tiles :  64 px x  64 ch
-    CFG_COUNT = 9
+    CFG_COUNT = 9,
+    CFG_WS = 16         // flag: wave-specialised kernel (producer wave + double-buffered LDS)
 };
 inline ConvShape conv_shape(int cfg) {
-    switch (cfg) {
+    switch (cfg & 15) {
         case CFG_128x128: return {2, 2, 2, 2};
         case CFG_256x64: return {4, 1, 2, 2};
         case CFG_256x32: return {4, 1, 2, 1};

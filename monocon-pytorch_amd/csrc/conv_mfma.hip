@@ -25,12 +25,44 @@ static hipError_t launch_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     return hipGetLastError();
 }
 
+template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
+static hipError_t launch_one_ws(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
+    using Cfg = ConvCfgWS<KS, S, CK, WM, WN, WTM, WTN>;
+    if (Cfg::LDS_BYTES > 160 * 1024) return hipErrorInvalidValue;
+    a.ppr = (a.Wout + 7) / 8;
+    a.ppi = a.ppr * ((a.Hout + 3) / 4);
+    a.chunks = (a.ppi + Cfg::PB - 1) / Cfg::PB;
+    if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
+    if (resolved) *resolved = a;
+    static bool attr_set = false;
+    auto kern = conv_mfma_ws_kernel<KS, S, CK, WM, WN, WTM, WTN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntiles = a.CoutP / Cfg::BNT;
+    dim3 grid((unsigned)(a.B * a.chunks * ntiles));
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+
 template <int KS, int S, int CK>
 static hipError_t launch_shape(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
+    if (a.cfg & CFG_WS) {
+        switch (a.cfg & ~CFG_WS) {
+            case CFG_128x128: return launch_one_ws<KS, S, CK, 2, 2, 2, 2>(a, st, resolved);
+            case CFG_128x64: return launch_one_ws<KS, S, CK, 2, 2, 2, 1>(a, st, resolved);
+            case CFG_128x64m: return launch_one_ws<KS, S, CK, 4, 1, 1, 2>(a, st, resolved);
+            case CFG_128x32: return launch_one_ws<KS, S, CK, 4, 1, 1, 1>(a, st, resolved);
+            case CFG_64x128: return launch_one_ws<KS, S, CK, 1, 4, 2, 1>(a, st, resolved);
+            case CFG_64x64: return launch_one_ws<KS, S, CK, 2, 2, 1, 1>(a, st, resolved);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (a.cfg) {
         case CFG_128x128: return launch_one<KS, S, CK, 2, 2, 2, 2>(a, st, resolved);
-        case CFG_256x64: return launch_one<KS, S, CK, 4, 1, 2, 2>(a, st, resolved);
-        case CFG_256x32: return launch_one<KS, S, CK, 4, 1, 2, 1>(a, st, resolved);
         case CFG_128x64: return launch_one<KS, S, CK, 2, 2, 2, 1>(a, st, resolved);
         case CFG_128x64m: return launch_one<KS, S, CK, 4, 1, 1, 2>(a, st, resolved);
         case CFG_128x32: return launch_one<KS, S, CK, 4, 1, 1, 1>(a, st, resolved);

@@ -710,6 +710,7 @@ int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[],
     a.wpk = static_cast<float *>(wpk);
     a.scale = scale; a.bias = bias; a.res = residual; a.res_ld = Cout;
     a.out = out; a.out_ld = Cout; a.out_coff = 0; a.relu = relu;
+    a.cfg = h->force_cfg;
     hipError_t e = launch_conv(a, ksize, stride, st);
     hipError_t e2 = hipStreamSynchronize(st);   // test entry point: weights are a temporary
     (void)hipFree(wpk);
@@ -853,6 +854,18 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
     (void)hipEventDestroy(e1);
     for (void *q : bufs) (void)hipFree(q);
     HIPCHK(h, e);
+    return 0;
+}
+
+int mc_set_conv_cfg(mc_handle *h, int cfg) {
+    if (!h) return -1;
+    if (cfg < 0 || (cfg & 15) >= CFG_COUNT || (cfg & ~(15 | CFG_WS))) return fail(h, "mc_set_conv_cfg: unknown shape id");
+    h->force_cfg = cfg;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    for (auto &kv : h->plans)   // plans bake the shape into their launch arguments
+        for (void *q : kv.second->bufs) (void)hipFree(q);
+    h->plans.clear();
     return 0;
 }
 

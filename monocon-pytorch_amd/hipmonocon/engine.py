@@ -268,6 +268,10 @@ class Engine:
         return dict(zip(PRED_KEYS, d))
 
     # ------------------------------------------------------------------ op level (tests)
+    def set_conv_cfg(self, cfg):
+        """force a workgroup shape of the fused conv (tuning / tests); 0 = automatic."""
+        _lib.check(self.h, self.lib.mc_set_conv_cfg(self.h, int(cfg)), "mc_set_conv_cfg")
+
     def op_conv(self, srcs, weight, stride=1, scale=None, bias=None, residual=None, relu=False):
         """srcs: list of NHWC CUDA tensors (virtual concat); weight OIHW; returns NHWC."""
         for s in srcs:

@@ -8,7 +8,8 @@ from hipmonocon.engine import Engine
 from hipmonocon import lib
 
 B = int(os.environ.get("TUNE_B", "32"))
-CFG = {1: "128x128", 2: "256x64", 3: "256x32", 4: "128x64", 5: "128x64m", 6: "128x32", 7: "64x128", 8: "64x64"}
+CFG = {1: "128x128", 4: "128x64", 5: "128x64m", 6: "128x32", 7: "64x128", 8: "64x64",
+       17: "w128x128", 20: "w128x64", 21: "w128x64m", 22: "w128x32", 23: "w64x128", 24: "w64x64"}
 # (name, Hin, Win, [Cin], Cout, k, stride, count per forward)
 LAYERS = [
     ("l0 16->16", 384, 1280, [16], 16, 3, 1, 1),
@@ -40,6 +41,8 @@ LAYERS = [
     ("project 256->512", 12, 40, [256], 512, 1, 1, 1),
 ]
 
+if os.environ.get('TUNE_NOWS'):
+    CFG = {k: v for k, v in CFG.items() if k < 16}
 eng = Engine()
 L = lib.load()
 only = sys.argv[1:] if len(sys.argv) > 1 else None

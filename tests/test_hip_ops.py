@@ -69,6 +69,33 @@ def test_conv(eng, case):
     assert rel_err(got, ref) < TOL
 
 
+WS_SHAPES = {17: 128, 20: 64, 21: 64, 22: 32, 23: 128, 24: 64}   # id (16 + shape) -> channel tile
+
+
+@pytest.mark.parametrize("cfg", sorted(WS_SHAPES))
+def test_conv_wave_specialised_is_bit_identical(eng, cfg):
+    """the producer/consumer kernel keeps the accumulation order: bit-identical to the plain one."""
+    dev = eng.device
+    cases = [c for c in CONV_CASES if c[7] == 1]
+    try:
+        for case in cases:
+            name, B, H, W, cins, cout, k, stride, use_res, relu, affine = case
+            tile = 128 if cout >= 128 else (64 if cout > 32 else 32)
+            if ((cout + tile - 1) // tile * tile) % WS_SHAPES[cfg]:
+                continue
+            seed = 300 + CONV_CASES.index(case)
+            xs = [nhwc(rnd(seed, "x%d" % i, (B, c, H, W))).to(dev) for i, c in enumerate(cins)]
+            w = rnd(seed, "w", (cout, sum(cins), k, k), (2.0 / (k * k * sum(cins))) ** 0.5).to(dev)
+            bias = (0.1 * rnd(seed, "bi", (cout,))).to(dev)
+            eng.set_conv_cfg(cfg & 15)
+            base = eng.op_conv(xs, w, stride, None, bias, None, relu)
+            eng.set_conv_cfg(cfg)
+            got = eng.op_conv(xs, w, stride, None, bias, None, relu)
+            assert torch.equal(base, got), name
+    finally:
+        eng.set_conv_cfg(0)
+
+
 def test_conv_is_transpose_sensitive(eng):
     """asymmetric one-hot weight: output channel n must read input channel (n*7)%C at tap (0,2)."""
     B, H, W, Cc = 1, 8, 8, 64
