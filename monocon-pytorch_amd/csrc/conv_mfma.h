@@ -396,80 +396,74 @@ __global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(con
     }
     __syncthreads();
 
-    f32x16 acc[WTM][WTN];
-#pragma unroll
-    for (int tm = 0; tm < WTM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < WTN; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-
     if (producer) {
-        // ---- producer wave: element e = lane + 64*i of the [PB][NPIX][C4] tile; the input pixel of
-        //      each element does not depend on the chunk, so it is resolved once.
+        // ---- producer wave: element e = lane + 64*i of the [PB][NPIX][C4] tile (see
+        //      conv_mfma_kernel: lane offsets once per source, then loads + LDS writes only)
         constexpr int TOTAL = PB * NPIX * C4;
         constexpr int NIT = (TOTAL + 63) / 64;
-        int pidx[NIT];
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int e = lane + 64 * i;
-            const int t = e / C4;
-            const int pix = t % NPIX;
-            const int p = (t / NPIX) % PB;
-            const int iy = pix / IW, ix = pix % IW;
-            const int y = pinfo[p * 4 + 1] * S - PAD + iy;
-            const int x = pinfo[p * 4 + 2] * S - PAD + ix;
-            const bool ok = e < TOTAL && pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
-            pidx[i] = ok ? (pinfo[p * 4 + 0] * a.Hin + y) * a.Win + x : -1;
-        }
         constexpr int UB = NIT > 8 ? 8 : NIT;   // loads kept in flight per batch
+        static_assert(64 % C4 == 0, "a lane keeps one channel group across its elements");
+        const int c4 = lane % C4;
         int ci = 0;
         for (int si = 0; si < a.nsrc; ++si) {
-            const float *sp = a.src[si].p;
             const int Cs = a.src[si].C;
+            const __amdgpu_buffer_rsrc_t r_in =
+                make_rsrc(a.src[si].p + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
+            int voff[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int e = lane + 64 * i;
+                const int t = e / C4;
+                const int pix = t % NPIX;
+                const int p = (t / NPIX) % PB;
+                const int iy = pix / IW, ix = pix % IW;
+                const int y = pinfo[p * 4 + 1] * S - PAD + iy;
+                const int x = pinfo[p * 4 + 2] * S - PAD + ix;
+                const bool ok = e < TOTAL && pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
+                voff[i] = ok ? ((y * a.Win + x) * Cs + c4 * 4) * 4 : BUF_OOB;
+            }
             for (int c0 = 0; c0 < Cs; c0 += CK, ++ci) {
-                float *dst = lds + (ci & 1) * TILE;
-                const float *spc = sp + c0 + (lane % C4) * 4;
+                float *dst = lds + (ci & 1) * TILE + (lane / C4) * CKP + c4 * 4;
 #pragma unroll
                 for (int i0 = 0; i0 < NIT; i0 += UB) {
                     f32x4 v[UB];
 #pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        const int i = i0 + u;
-                        if (i < NIT) {   // unconditional load (clamped pixel) + select, see conv_mfma_kernel
-                            v[u] = *reinterpret_cast<const f32x4 *>(spc + (size_t)(pidx[i] < 0 ? 0 : pidx[i]) * Cs);
-                            if (pidx[i] < 0) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                    }
+                    for (int u = 0; u < UB; ++u)
+                        if (i0 + u < NIT) v[u] = buf_load4(r_in, voff[i0 + u], c0 * 4);
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
                         const int i = i0 + u;
-                        if (i < NIT) {
-                            const int e = lane + 64 * i;
-                            if (64 * i + 63 < TOTAL || e < TOTAL)
-                                *reinterpret_cast<f32x4 *>(&dst[(e / C4) * CKP + (e % C4) * 4]) = v[u];
-                        }
+                        if (i < NIT && (64 * (i + 1) <= TOTAL || lane + 64 * i < TOTAL))
+                            *reinterpret_cast<f32x4 *>(dst + i * (64 / C4) * CKP) = v[u];
                     }
                 }
                 __syncthreads();   // chunk ci is published; consumers are done with chunk ci-1
             }
         }
     } else {
+        f32x16 acc[WTM][WTN];
+#pragma unroll
+        for (int tm = 0; tm < WTM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < WTN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
         int a_off[WTM];
 #pragma unroll
         for (int tm = 0; tm < WTM; ++tm)
             a_off[tm] = ((wm * WTM + tm) * NPIX + ((li >> 3) * S) * IW + (li & 7) * S) * CKP + 4 * g;
 
         const int Cin4 = a.Cin >> 2;
-        const size_t colP = (size_t)a.CoutP;
-        const float *wlane = a.wpk + ((size_t)g * colP + n0 + wn * WTN * 32 + li) * 4;
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk, (unsigned)(KS * KS * a.Cin * a.CoutP) * 4u);
+        const int w_lane = (g * a.CoutP + n0 + wn * WTN * 32 + li) * 16;   // bytes
 
         constexpr int K8 = CK / 8, NS = KS * KS * K8;
         auto load_b = [&](f32x4(&dst)[WTN], int kc, int s) {
             const int tap = s / K8, k8 = s % K8;
-            const float *wp = wlane + ((size_t)(tap * Cin4 + ((kc + k8 * 8) >> 2)) * colP) * 4;
+            const int soff = (tap * Cin4 + ((kc + k8 * 8) >> 2)) * a.CoutP * 16;
 #pragma unroll
-            for (int tn = 0; tn < WTN; ++tn) dst[tn] = *reinterpret_cast<const f32x4 *>(wp + tn * 32 * 4);
+            for (int tn = 0; tn < WTN; ++tn) dst[tn] = buf_load4(r_w, w_lane + tn * 32 * 16, soff);
         };
         f32x4 bcur[WTN];
         load_b(bcur, 0, 0);
@@ -515,52 +509,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(con
             }
             if (ci + 1 < nch) __syncthreads();   // chunk ci+1 staged, chunk ci released
         }
-
-        // ---- epilogue (identical to conv_mfma_kernel)
-        float ssum[WTN], ssq[WTN];
-#pragma unroll
-        for (int tn = 0; tn < WTN; ++tn) ssum[tn] = ssq[tn] = 0.f;
-#pragma unroll
-        for (int tn = 0; tn < WTN; ++tn) {
-            const int n = n0 + (wn * WTN + tn) * 32 + li;
-            const bool nok = n < a.Cout;
-            const float sc = (a.scale && nok) ? a.scale[n] : 1.f;
-            const float bi = (a.bias && nok) ? a.bias[n] : 0.f;
-            const float sh = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
-#pragma unroll
-            for (int tm = 0; tm < WTM; ++tm) {
-                const int p = wm * WTM + tm;
-                const int pb = pinfo[p * 4 + 0], oy0 = pinfo[p * 4 + 1], ox0 = pinfo[p * 4 + 2];
-                const bool pv = pinfo[p * 4 + 3] != 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * g;
-                    const int y = oy0 + (m >> 3), x = ox0 + (m & 7);
-                    if (pv && nok && y < a.Hout && x < a.Wout) {
-                        const size_t pixel = ((size_t)pb * a.Hout + y) * a.Wout + x;
-                        float v = acc[tm][tn][r] * sc + bi;
-                        if (a.res) v += a.res[pixel * a.res_ld + n];
-                        const float d = v - sh;
-                        ssum[tn] += d;
-                        ssq[tn] += d * d;
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        a.out[pixel * a.out_ld + a.out_coff + n] = v;
-                    }
-                }
-            }
-        }
-        if (a.stats) {
-#pragma unroll
-            for (int tn = 0; tn < WTN; ++tn) {
-                ssum[tn] += __shfl_xor(ssum[tn], 32);
-                ssq[tn] += __shfl_xor(ssq[tn], 32);
-                if (g == 0) {
-                    const int nl = (wn * WTN + tn) * 32 + li;
-                    sred[(wm * BNT + nl) * 2 + 0] = ssum[tn];
-                    sred[(wm * BNT + nl) * 2 + 1] = ssq[tn];
-                }
-            }
-        }
+        conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, sred, img, n0, wm, wn, g, li);
     }
     if (a.stats) {
         __syncthreads();

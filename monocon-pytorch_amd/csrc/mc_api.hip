@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <string>
@@ -191,7 +192,7 @@ struct Builder {
         a.out = out.p; a.out_ld = out.C; a.out_coff = 0;
         a.relu = relu ? 1 : 0;
         const int ppr = (Wo + 7) / 8, ppi = ppr * ((Ho + 3) / 4);
-        a.cfg = L.cfg ? L.cfg : (h->force_cfg ? h->force_cfg : conv_pick_cfg(L.cout, L.coutp, L.ks, L.stride, s0.B, Ho, Wo));
+        a.cfg = L.cfg ? L.cfg : (ok ? mc_choose_conv_cfg(h, a, L.ks, L.stride) : CFG_128x32);
         const int pb = conv_patches_per_block(a.cfg);
         const int chunks = (ppi + pb - 1) / pb;
         if (stats_out) {
@@ -264,6 +265,45 @@ struct Builder {
     }
 };
 }  // namespace
+
+int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
+    if (h->force_cfg) return h->force_cfg;
+    const int heuristic = conv_pick_cfg(a_in.Cout, a_in.CoutP, ks, stride, a_in.B, a_in.Hout, a_in.Wout);
+    if (!h->autotune) return heuristic;
+    std::vector<int> key = {a_in.B, a_in.Hin, a_in.Win, ks, stride, a_in.Cout, a_in.CoutP, a_in.nsrc,
+                            a_in.res ? 1 : 0};
+    for (int i = 0; i < a_in.nsrc; ++i) key.push_back(a_in.src[i].C);
+    auto it = h->tuned.find(key);
+    if (it != h->tuned.end()) return it->second;
+    static const int cand[] = {CFG_128x128, CFG_128x64, CFG_128x64m, CFG_128x32, CFG_64x128, CFG_64x64,
+                               CFG_WS | CFG_128x128, CFG_WS | CFG_128x64m, CFG_WS | CFG_64x128, CFG_WS | CFG_64x64};
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return heuristic;
+    ConvArgs a = a_in;
+    a.stats = nullptr;
+    int best = heuristic;
+    float best_ms = 1e30f;
+    for (int c : cand) {
+        if (a.CoutP % conv_shape(c).BNT()) continue;
+        a.cfg = c;
+        if (launch_conv(a, ks, stride, nullptr) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm / unsupported
+        float t_min = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0, nullptr);
+            (void)launch_conv(a, ks, stride, nullptr);
+            (void)hipEventRecord(e1, nullptr);
+            if (hipEventSynchronize(e1) != hipSuccess) { t_min = 1e30f; break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            t_min = std::min(t_min, ms);
+        }
+        if (t_min < best_ms) { best_ms = t_min; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    h->tuned[key] = best;
+    return best;
+}
 
 static Plan *get_plan(mc_handle *h, int B, int H, int W) {
     auto key = std::make_tuple(B, H, W);
@@ -426,6 +466,7 @@ int mc_create(int device, mc_handle **out) {
         return fail(nullptr, "mc_create: device is %s; this library is built for gfx950 only", prop.gcnArchName);
     mc_handle *h = new mc_handle();
     h->device = device;
+    if (const char *e = std::getenv("MONOCON_HIP_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
     *out = h;
     return 0;
 }

@@ -96,6 +96,8 @@ struct mc_handle {
     float *decode_filt = nullptr;
     size_t decode_filt_n = 0;
     int force_cfg = 0;   // tuning aid (mc_bench_conv)
+    int autotune = 1;    // time the workgroup shapes of every distinct conv once (MONOCON_HIP_AUTOTUNE=0: heuristic)
+    std::map<std::vector<int>, int> tuned;   // conv signature -> shape id
     float *loss_ws = nullptr;   // focal partials + small reduction scratch
     // fused optimizer tables (device)
     mc::OptTensor *opt_tab = nullptr;
@@ -125,4 +127,11 @@ static inline int fail(mc_handle *h, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// Workgroup shape for a fused conv launch: h->force_cfg if set, else (autotune on) the fastest of the
+// candidate shapes timed on the device with these very arguments, cached per conv signature; else
+// the static heuristic.  The accumulation order of an output element does not depend on the shape,
+// so the choice never changes results (per-image statistics partials are regrouped, not reordered
+// within a partial).  `a.stats` must be null while tuning (callers attach it afterwards).
+int mc_choose_conv_cfg(mc_handle *h, const mc::ConvArgs &a, int ks, int stride);
 

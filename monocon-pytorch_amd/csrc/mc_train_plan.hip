@@ -149,7 +149,7 @@ struct TB {   // train plan builder
         if (cin != Lr.cin) { ts->ok = false; h->err = "train plan: channel mismatch at " + Lr.conv; }
         a.B = B; a.Hin = s0.H; a.Win = s0.W; a.Hout = Ho; a.Wout = Wo; a.Cin = cin; a.Cout = Lr.cout; a.CoutP = Lr.coutp;
         a.wpk = Lr.wpk; a.out = r.y.p; a.out_ld = Lr.cout;
-        a.cfg = conv_pick_cfg(Lr.cout, Lr.coutp, Lr.ks, Lr.stride, B, Ho, Wo);
+        a.cfg = ts->ok ? mc_choose_conv_cfg(h, a, Lr.ks, Lr.stride) : CFG_128x32;
         const int ppr = (Wo + 7) / 8, ppi = ppr * ((Ho + 3) / 4), pb = conv_patches_per_block(a.cfg);
         const int chunks = (ppi + pb - 1) / pb;
         float *stats = alloc((size_t)B * chunks * Lr.coutp * 2);
@@ -265,8 +265,8 @@ struct TB {   // train plan builder
         d.Cin = dy.C; d.Cout = sn.t.C; d.CoutP = csp; d.wpk = panel;
         d.out = sn.g; d.out_ld = sn.t.C;
         if (sn.ginit) { d.res = sn.g; d.res_ld = sn.t.C; }
-        d.cfg = CFG_AUTO;
         if (Hd != sn.t.H || Wd != sn.t.W) { ts->ok = false; h->err = "train plan: dgrad shape mismatch"; }
+        d.cfg = ts->ok ? mc_choose_conv_cfg(h, d, ks, 1) : CFG_128x32;
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(d, ks, 1, st)); return 0; });
         sn.ginit = true;
     }
@@ -429,7 +429,8 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
     ConvArgs c1{};
     c1.nsrc = 1; c1.src[0].p = hn.p; c1.src[0].C = CP;
     c1.B = B; c1.Hin = fh; c1.Win = fw; c1.Hout = fh; c1.Wout = fw; c1.Cin = CP; c1.Cout = NUM_OUT_ROWS; c1.CoutP = c1p;
-    c1.wpk = w1panel; c1.bias = h->head_b1; c1.out = raw.p; c1.out_ld = LD; c1.cfg = CFG_AUTO;
+    c1.wpk = w1panel; c1.bias = h->head_b1; c1.out = raw.p; c1.out_ld = LD;
+    c1.cfg = ts->ok ? mc_choose_conv_cfg(h, c1, 1, 1) : CFG_128x32;
     {
         const float *w1 = h->head_w1, *scale = at.scale, *shift = at.shift;
         ts->pack_fns.push_back([=](mc_handle *hh, hipStream_t st) {
@@ -510,7 +511,8 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
             ConvArgs d{};
             d.nsrc = 1; d.src[0].p = draw; d.src[0].C = LD;
             d.B = B; d.Hin = fh; d.Win = fw; d.Hout = fh; d.Wout = fw; d.Cin = LD; d.Cout = CP; d.CoutP = csp; d.wpk = panel;
-            d.out = dh; d.out_ld = CP; d.cfg = CFG_AUTO;
+            d.out = dh; d.out_ld = CP;
+            d.cfg = ts->ok ? mc_choose_conv_cfg(h, d, 1, 1) : CFG_128x32;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(d, 1, 1, st)); return 0; });
         }
         const int nbr = chan_reduce_blocks(B, HW), rb_per_img = nbr / B;
