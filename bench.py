@@ -3,16 +3,21 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
 
-One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
-the DLA-34 + DLAUp + dense-head forward at B=32, 3x384x1280, fp32 (BASELINE.json configs[1]).
-For N>1 the driver launches this file under torch.distributed.run; every rank runs its own
-B=32 shard (image-batch data parallelism, no data-path collective in the forward), timing is
-barrier + synchronize bracketed and the MAX over ranks is reported (weak scaling).
+BASELINE.json's metric is "images/sec (384x1280) fwd+bwd at 1/2/4/8 GPUs": one "step" is one FULL
+train step through the drop-in API (model.detector + solver) on a synthetic KITTI-shaped batch
+already resident in HBM -- train-mode forward (batch-statistics BN, AttnBN heads), target
+generation, the ten losses, backward (dgrad + wgrad), gradient all-reduce over RCCL when N > 1,
+fused clip + AdamW and the cyclic schedule -- at B=32 images per GPU, 3x384x1280, fp32 (the
+reference trains in fp32; BASELINE configs[2] asks for bf16 activations, not built yet).
+For N>1 the driver launches this file under torch.distributed.run: one process per GPU, every rank
+steps its own B=32 shard (weak scaling), one all-reduce of the flat 78 MB gradient buffer per step;
+timing is barrier + synchronize bracketed and the MAX over ranks is reported.
 
-Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel family
-(fused conv on the fp32 MFMA pipe, measured live with HIP events on the launch stream) and
-the CPU baseline (the oracle's CPU restatement of the same forward, timed on the host cores
-on a bounded sample).
+Rank 0 prints ONE JSON line: the throughput, `roofline` of the dominant kernel family of the step
+(conv_mfma_kernel: forward convolutions + data gradients on the fp32 MFMA pipe, timed live with HIP
+events around every launch on the launch stream), `forward_only` (BASELINE configs[1]: eval forward
+at B=32 with its own conv roofline) and `cpu_baseline` (the oracle's CPU restatement of the same
+forward, timed on the host cores on a bounded sample).
 """
 import argparse
 import json
@@ -41,8 +46,8 @@ def parse():
     ap.add_argument("--height", type=int, default=384)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=3,
-                    help="also time this many full train steps (fwd+targets+losses+bwd+all-reduce+clip+AdamW); 0 = skip")
+    ap.add_argument("--forward-steps", type=int, default=10,
+                    help="also time this many eval forwards (BASELINE configs[1]); 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     return ap.parse_args()
 
@@ -77,57 +82,8 @@ def cpu_baseline(sd, height, width, budget_s):
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return {"value": round(2 / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle eval forward, B=2 x 3x%dx%d fp32, median of %d runs (%.3f s/run)"
+            "sample": "oracle eval forward only (no backward), B=2 x 3x%dx%d fp32, median of %d runs (%.3f s/run)"
                       % (height, width, len(times), med)}
-
-
-def time_train_steps(args, sd, rank, world, dist_on, sync_all):
-    """Full train step through the drop-in API (model.detector + solver): train-mode forward with
-    batch-statistics BN, target generation, the ten losses, backward, gradient all-reduce (N > 1),
-    fused clip + AdamW, cyclic schedule.  fp32 throughout (BASELINE configs[2] asks for bf16
-    activations; not built yet -- this is the fp32 reference-precision step)."""
-    from hipmonocon import synth
-    from model import MonoConDetector
-    from solver import AdamW, CyclicScheduler
-    B, H, W = args.batch, args.height, args.width
-    m = MonoConDetector(34, pretrained_backbone=False)
-    m.load_state_dict(sd, strict=True)
-    m = m.cuda().train()
-    opt = AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=35.0)
-    sch = CyclicScheduler(opt, total_steps=1000)
-    nb = min(B, 8)
-    small = synth.make_batch(500 + rank, nb, H, W)
-    rep = (B + nb - 1) // nb
-    batch = {"img": small["img"].repeat(rep, 1, 1, 1)[:B].cuda().contiguous(),
-             "label": {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:B].cuda().contiguous() for k, v in small["label"].items()},
-             "img_metas": {"pad_shape": [(H, W)] * B}}
-
-    def step():
-        opt.zero_grad()
-        _, loss = m(batch)
-        total = sum(v for v in loss.values())
-        total.backward()
-        opt.step()
-        sch.step()
-        return total
-
-    step()                       # warm-up (builds the plan)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.train_steps):
-        total = step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert bool(torch.isfinite(total))
-    del m, opt
-    return {"images_per_sec": round(world * B * args.train_steps / dt, 2), "ms_per_step": round(dt / args.train_steps * 1e3, 2),
-            "steps": args.train_steps, "batch_per_gpu": B, "dtype": "f32",
-            "what": "fwd(train BN)+targets+losses+bwd+%sclip+AdamW+cyclic schedule" % ("grad all-reduce+" if world > 1 else "")}
 
 
 def main():
@@ -149,17 +105,12 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from hipmonocon import synth
-    from hipmonocon.engine import Engine
+    from model import MonoConDetector
+    from solver import AdamW, CyclicScheduler
 
     stats = np.load(os.path.join(REPO, "tests", "golden", "bn_calib_seed7.npz"))
     sd = synth.make_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
-    eng = Engine(local)
-    dsd = {k: v.cuda() for k, v in sd.items()}
-    eng.bind_state(dsd)
-
     B, H, W = args.batch, args.height, args.width
-    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    img = torch.randn((B, 3, H, W), generator=gen, device="cuda", dtype=torch.float32)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -167,60 +118,119 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.forward_infer(img)
+    def max_over_ranks(dt):
+        if not dist_on:
+            return dt
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---------------------------------------------------------------- the train step (headline)
+    m = MonoConDetector(34, pretrained_backbone=False)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    opt = AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=35.0)
+    sch = CyclicScheduler(opt, total_steps=1000)
+    nb = min(B, 8)
+    small = synth.make_batch(500 + rank, nb, H, W)
+    rep = (B + nb - 1) // nb
+    batch = {"img": small["img"].repeat(rep, 1, 1, 1)[:B].cuda().contiguous(),
+             "label": {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:B].cuda().contiguous() for k, v in small["label"].items()},
+             "img_metas": {"pad_shape": [(H, W)] * B}}
+
+    def step():
+        opt.zero_grad()
+        _, loss = m(batch)
+        total = sum(v for v in loss.values())
+        total.backward()            # includes the gradient all-reduce when N > 1
+        opt.step()                  # fused clip_grad_norm_(35) + AdamW
+        sch.step()
+        return total
+
+    for _ in range(max(args.warmup, 1)):      # the first step builds (and autotunes) the plan
+        total = step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        preds = eng.forward_infer(img)
+        total = step()
     sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert all(torch.isfinite(v).all() for v in preds.values())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    assert bool(torch.isfinite(total)), "non-finite loss in the timed region"
+    ms_step = elapsed / args.steps * 1e3
 
-    train = None
-    if args.train_steps > 0:
-        train = time_train_steps(args, sd, rank, world, dist_on, sync_all)
+    eng = m._rt.engine
+    prof = eng.profile_train(iters=2) if rank == 0 else None      # HIP events on the launch stream
+    train_ws = eng.workspace_bytes()
+
+    # ---------------------------------------------------------------- forward only (configs[1])
+    fwd = None
+    if args.forward_steps > 0:
+        m.eval()
+        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        img = torch.randn((B, 3, H, W), generator=gen, device="cuda", dtype=torch.float32)
+        eng = m._engine()           # re-binds the (updated) parameters for the eval plan
+        for _ in range(3):
+            preds = eng.forward_infer(img)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.forward_steps):
+            preds = eng.forward_infer(img)
+        sync_all()
+        fdt = max_over_ranks(time.perf_counter() - t0)
+        assert all(torch.isfinite(v).all() for v in preds.values())
+        if rank == 0:
+            cost = eng.forward_cost(B, H, W)
+            fprof = eng.profile_forward(iters=3)
+            fms = fdt / args.forward_steps * 1e3
+            ctf = cost["conv_flops"] / (fprof["conv_ms"] * 1e-3) / 1e12
+            fl = cost["conv_flops"] + cost["other_flops"]
+            by = cost["conv_bytes"] + cost["other_bytes"]
+            fwd = {"workload": "BASELINE configs[1]: eval forward only, batch=%d/GPU, fp32" % B,
+                   "images_per_sec": round(world * B * args.forward_steps / fdt, 2), "ms_per_step": round(fms, 3),
+                   "steps": args.forward_steps,
+                   "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (%d launches per forward)" % fprof["n_conv"],
+                                "achieved": round(ctf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(ctf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                "conv_ms": round(fprof["conv_ms"], 3), "other_ms": round(fprof["other_ms"], 3)},
+                   "gflop_per_image": round(fl / B / 1e9, 2), "model_hbm_mb_per_image": round(by / B / 1e6, 1),
+                   "whole_forward_tflops": round(fl / (fms * 1e-3) / 1e12, 2),
+                   "whole_forward_frac_of_hbm_peak": round(by / (fms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
 
     if rank == 0:
-        cost = eng.forward_cost(B, H, W)
-        flops = cost["conv_flops"] + cost["other_flops"]
-        fbytes = cost["conv_bytes"] + cost["other_bytes"]
-        prof = eng.profile_forward(iters=3)                     # HIP events on the launch stream
-        # conv-MFMA family: algorithmic FLOPs of the conv launches / their summed duration
-        conv_tflops = cost["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
-        ms_step = elapsed / args.steps * 1e3
+        conv, wg, oth = prof["conv"], prof["wgrad"], prof["other"]
+        conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+        wg_tf = wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0
         out = {
-            "metric": "images/sec (384x1280) fwd, DLA-34+DLAUp+MonoCon heads",
+            "metric": "images/sec (384x1280) fwd+bwd",
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
             "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DLA-34 + MonoCon dense heads forward-only, "
-                                   "batch=%d/GPU, 3x%dx%d synthetic, fp32, eval-mode BN" % (B, H, W),
+            "config": {"workload": "full train step (train-mode fwd + targets + 10 losses + bwd + %sclip + AdamW + cyclic "
+                                   "schedule), DLA-34 + DLAUp + MonoCon heads, batch=%d/GPU, 3x%dx%d synthetic KITTI-shaped, "
+                                   "fp32 (BASELINE configs[2] shape at the reference's fp32 precision)"
+                                   % ("RCCL grad all-reduce + " if world > 1 else "", B, H, W),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "roofline": {
-                "bound": "mfma", "kernel": "conv_mfma_kernel (all %d fused-conv launches of one forward)" % prof["n_conv"],
-                "achieved": round(conv_tflops, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(conv_tflops / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                "avg_launch_ms": round(prof["conv_ms"] / max(prof["n_conv"], 1), 4),
-                "conv_ms_per_forward": round(prof["conv_ms"], 3), "other_ms_per_forward": round(prof["other_ms"], 3),
-                "forward_gflop_per_image": round(flops / B / 1e9, 2),
-                "forward_model_hbm_mb_per_image": round(fbytes / B / 1e6, 1),
-                "whole_forward_tflops": round(flops / (ms_step * 1e-3) / 1e12, 2),
-                "whole_forward_frac_of_fp32_peak": round(flops / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                "whole_forward_model_gbs": round(fbytes / (ms_step * 1e-3) / 1e9, 1),
-                "whole_forward_frac_of_hbm_peak": round(fbytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "bound": "mfma",
+                "kernel": "conv_mfma_kernel: %d launches per train step (forward convs + data gradients)" % conv["launches"],
+                "achieved": round(conv_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4),
+                "conv_ms_per_step": round(conv["ms"], 2),
+                "wgrad": {"kernel": "wgrad_mfma_kernel (+ split-K reduce): %d launches" % wg["launches"],
+                          "achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                          "ms_per_step": round(wg["ms"], 2)},
+                "other_ms_per_step": round(oth["ms"], 2),
+                "step_gflop_per_image": round((conv["flops"] + wg["flops"]) / B / 1e9, 1),
+                "whole_step_tflops": round((conv["flops"] + wg["flops"]) / (ms_step * 1e-3) / 1e12, 2),
             },
-            "workspace_gb": round(eng.workspace_bytes() / 1e9, 2),
+            "workspace_gb": round(train_ws / 1e9, 2),
         }
-        if train is not None:
-            out["train_step"] = train
+        if fwd is not None:
+            out["forward_only"] = fwd
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, H, W, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -201,6 +201,13 @@ int mc_op_nchw_to_nhwc(mc_handle *h, const float *in, int B, int C, int H, int W
 int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W, float *out,
                        void *stream);
 
+/* Measurement aid for bench.py: re-runs the launches of the last mc_forward_train + mc_backward
+ * `iters` times with a HIP event pair around every launch group on `stream` and returns, per
+ * kernel family k (0 = everything else, 1 = conv_mfma_kernel: forward convs + data gradients,
+ * 2 = wgrad_mfma_kernel: weight gradients), the summed duration ms[k], the algorithmic FLOPs
+ * flops[k] and the number of launch groups, averaged per train step.  (Mutates BN running
+ * statistics like any train-mode forward.) */
+int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], int launches[3], void *stream);
 /* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
  * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel; 0 = automatic)
  * for mc_op_conv and for every layer of plans built afterwards that has no fixed shape. */

@@ -585,4 +585,9 @@ inline int conv_patches_per_block(int cfg) { return conv_shape(cfg).PB(); }
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);
 
+// Measurement aid (mc_profile_train): the last launch_conv / launch_wgrad on this host thread notes
+// its kernel family (1 = fused conv incl. dgrad, 2 = wgrad) and algorithmic FLOPs here.
+struct ProfLast { int kind; double flops; };
+extern thread_local ProfLast prof_last;
+
 }  // namespace mc

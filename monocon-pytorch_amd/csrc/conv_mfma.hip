@@ -3,6 +3,8 @@
 
 namespace mc {
 
+thread_local ProfLast prof_last = {0, 0.0};
+
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
 static hipError_t launch_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     using Cfg = ConvCfg<KS, S, CK, WM, WN, WTM, WTN>;
@@ -91,6 +93,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
     for (int i = 0; i < a.nsrc; ++i)
         if (sc[i] % ck) return hipErrorInvalidValue;
     if (a.cfg == CFG_AUTO) a.cfg = conv_pick_cfg(a.Cout, a.CoutP, ks, stride, a.B, a.Hout, a.Wout);
+    prof_last = {1, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks};
     if (ks == 3 && stride == 1) {
         return ck == 32 ? launch_shape<3, 1, 32>(a, st, resolved) : launch_shape<3, 1, 16>(a, st, resolved);
     } else if (ks == 3 && stride == 2) {

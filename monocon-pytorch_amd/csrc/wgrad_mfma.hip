@@ -178,6 +178,7 @@ void wgrad_plan(WgradArgs &a, int ks, int stride) {
 size_t wgrad_partial_floats(const WgradArgs &a, int ks) { return (size_t)a.ksplit * ks * ks * a.Cout * a.Cin; }
 
 hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st) {
+    prof_last = {2, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks};
     int WN, WC;
     wgrad_shape(a.Cout, a.Cin, &WN, &WC);
     hipError_t e = hipErrorInvalidValue;
