@@ -117,6 +117,7 @@ struct WgradArgs {
     int dy_ld;
     float *partial;           // [ksplit][k*k][Cout][Cin]
     int ksplit, n_tiles, c_tiles, ppr, ppi, groups_per_img;
+    int small;                // 1: 16-input-channel layer on the LDS-free 16x16x4 kernel (ksplit = workgroups)
 };
 void wgrad_plan(WgradArgs &a, int ks, int stride);            // fills the tiling fields
 size_t wgrad_partial_floats(const WgradArgs &a, int ks);

@@ -10,6 +10,7 @@
 // (split-K across workgroups); slices are written to a partial buffer and summed by a second,
 // deterministic pass that also converts to the OIHW layout of the master gradient.
 // Replaces autograd's conv2d weight backward for every Conv2d of the reference model.
+#include <algorithm>
 #include "conv_mfma.h"
 #include "train.h"
 
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad_mfma_kernel(const WgradArg
             pinfo[tid * 4 + 3] = pp < a.ppi;
         }
         __syncthreads();
+        // TIMER_STAGE_BEGIN
         // ---- stage X halo tile (virtual concat, zero outside image / beyond Cin)
         constexpr int XC4 = CB / 4, XTOT = PB * NPIX * XC4;
         for (int e = tid; e < XTOT; e += NT) {
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad_mfma_kernel(const WgradArg
             *reinterpret_cast<f32x4 *>(&dyt[(p * 32 + m) * NBP + n4 * 4]) = v;
         }
         __syncthreads();
+        // TIMER_STAGE_END
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
 #pragma unroll 4
@@ -111,7 +114,9 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad_mfma_kernel(const WgradArg
                 }
             }
         }
+        // TIMER_MFMA_END
     }
+    // TIMER_EPILOGUE_BEGIN
     // ---- epilogue: partial[ks][tap][n][c];  D row = n, D col (lane) = c
     const int c = c0 + wc * 32 + li;
     if (c < a.Cin) {
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad_mfma_kernel(const WgradArg
                 if (n < a.Cout) a.partial[(((size_t)ks * T + t) * a.Cout + n) * a.Cin + c] = acc[t][r];
             }
     }
+    // TIMER_KERNEL_END
 }
 
 // dW (O,I,kh,kw) = sum_ks partial[ks][tap][n][c]
@@ -135,6 +141,106 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         const int c = e % Cin, n = (e / Cin) % Cout, t = e / ((size_t)Cin * Cout);
         dw[((size_t)n * Cin + c) * T + t] = s;
     }
+}
+
+
+// ---- 16-input-channel layers (DLA level0 / level1: 16->16 s1, 16->32 s2 at full resolution) ------
+// With C = 16 a pixel is one 64-byte NHWC row, so four consecutive pixels are exactly the 64-lane
+// operand of v_mfma_f32_16x16x4_f32: A[n][k] = dY[pixel k][n] and B[k][c] = X[pixel k + tap][c] are
+// single coalesced dword loads per lane, straight from L1/L2 -- no LDS, no padding of the 16 columns
+// up to a 32-wide tile (the generic kernel wastes 3/4 of its MFMA work and all its staging on these
+// layers).  A wave walks whole output rows; one buffer descriptor per (input row, tap row) makes the
+// top / bottom halo a zero-length buffer and the left / right halo an out-of-range lane offset (only
+// in the two peeled edge groups of a row), so the main loop has no address arithmetic beyond SGPR
+// adds.  The four waves of a workgroup are summed through LDS into one split-K partial.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int S, int NTN>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
+    constexpr int CIN = 16, COUT = 16 * NTN;
+    __shared__ float red[9 * NTN * 4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = lane >> 4, j = lane & 15;
+    const int R = a.B * a.Hout;
+    const int r_begin = (int)((long long)R * blockIdx.x / gridDim.x);
+    const int r_end = (int)((long long)R * (blockIdx.x + 1) / gridDim.x);
+
+    f32x4v acc[9][NTN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) acc[t][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    const int va = (k * COUT + j) * 4;        // dY lane offset inside a group of 4 output pixels
+    const int vx = (k * S * CIN + j) * 4;     // X lane offset relative to the input pixel of output pixel 0
+    const float *xsrc = a.src[0].p;
+
+    for (int row = r_begin + wave; row < r_end; row += 4) {
+        const int img = row / a.Hout, oy = row - img * a.Hout;
+        const __amdgpu_buffer_rsrc_t r_dy = make_rsrc(a.dy + (size_t)row * a.Wout * COUT, (unsigned)(a.Wout * COUT) * 4u);
+        __amdgpu_buffer_rsrc_t r_x[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * S + r - 1;
+            const bool ok = iy >= 0 && iy < a.Hin;
+            r_x[r] = make_rsrc(xsrc + ((size_t)img * a.Hin + (ok ? iy : 0)) * a.Win * CIN, ok ? (unsigned)(a.Win * CIN) * 4u : 0u);
+        }
+        auto group = [&](int x0, bool edge) {
+            float av[NTN], bv[9];
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) av[nt] = buf_load1(r_dy, va + nt * 64, x0 * COUT * 4);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    if (!edge) {
+                        bv[r * 3 + s] = buf_load1(r_x[r], vx + s * CIN * 4, (x0 * S - 1) * CIN * 4);
+                    } else {
+                        const int px = (x0 + k) * S + s - 1;
+                        bv[r * 3 + s] = buf_load1(r_x[r], (px >= 0 && px < a.Win) ? (px * CIN + j) * 4 : BUF_OOB, 0);
+                    }
+                }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt)
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv[t], acc[t][nt], 0, 0, 0);
+        };
+        group(0, true);
+#pragma unroll 2
+        for (int x0 = 4; x0 < a.Wout - 4; x0 += 4) group(x0, false);
+        if (a.Wout > 4) group(a.Wout - 4, true);
+    }
+
+    // ---- workgroup reduction (wave after wave through one LDS image: fixed order, deterministic).
+    //      D layout of 16x16x4: row (n) = 4*(lane>>4) + q, column (c) = lane & 15
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float *dst = &red[(t * NTN + nt) * 4 + q][lane];
+                        *dst = w == 0 ? acc[t][nt][q] : *dst + acc[t][nt][q];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 9 * NTN * 4 * 64; e += 256) {
+        const int l = e & 63, idx = e >> 6;
+        const int q = idx & 3, nt = (idx >> 2) % NTN, t = (idx >> 2) / NTN;
+        const int n = nt * 16 + 4 * (l >> 4) + q, c = l & 15;
+        a.partial[(((size_t)blockIdx.x * 9 + t) * COUT + n) * CIN + c] = red[idx][l];
+    }
+}
+
+static bool wgrad_is_small(const WgradArgs &a, int ks, int stride) {
+    return ks == 3 && a.nsrc == 1 && a.Cin == 16 && (a.Cout == 16 || a.Cout == 32) && a.dy_ld == a.Cout &&
+           (stride == 1 || stride == 2) && a.Wout % 4 == 0 && a.Wout >= 8 &&
+           a.Hout == (a.Hin + 2 - 3) / stride + 1 && a.Wout == (a.Win + 2 - 3) / stride + 1;
 }
 
 template <int KS, int S, int WN, int WC>
@@ -161,7 +267,15 @@ static void wgrad_shape(int Cout, int Cin, int *WN, int *WC) {
 }
 
 void wgrad_plan(WgradArgs &a, int ks, int stride) {
-    (void)ks; (void)stride;
+    a.small = 0;
+    if (wgrad_is_small(a, ks, stride)) {
+        a.small = 1;
+        const int rows = a.B * a.Hout;
+        a.ksplit = std::min(rows / 4 > 0 ? rows / 4 : 1, 1024);   // >= 4 rows (one per wave) per workgroup
+        a.n_tiles = a.c_tiles = 1;
+        a.ppr = a.ppi = a.groups_per_img = 0;
+        return;
+    }
     int WN, WC;
     wgrad_shape(a.Cout, a.Cin, &WN, &WC);
     a.n_tiles = (a.Cout + 32 * WN - 1) / (32 * WN);
@@ -179,18 +293,26 @@ size_t wgrad_partial_floats(const WgradArgs &a, int ks) { return (size_t)a.kspli
 
 hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st) {
     prof_last = {2, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks};
-    int WN, WC;
-    wgrad_shape(a.Cout, a.Cin, &WN, &WC);
     hipError_t e = hipErrorInvalidValue;
+    if (a.small) {
+        if (stride == 1 && a.Cout == 16) hipLaunchKernelGGL((wgrad_small_kernel<1, 1>), dim3(a.ksplit), dim3(256), 0, st, a);
+        else if (stride == 1) hipLaunchKernelGGL((wgrad_small_kernel<1, 2>), dim3(a.ksplit), dim3(256), 0, st, a);
+        else if (a.Cout == 16) hipLaunchKernelGGL((wgrad_small_kernel<2, 1>), dim3(a.ksplit), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_small_kernel<2, 2>), dim3(a.ksplit), dim3(256), 0, st, a);
+        e = hipGetLastError();
+    } else {
+        int WN, WC;
+        wgrad_shape(a.Cout, a.Cin, &WN, &WC);
 #define WG_DISPATCH(KS_, S_)                                                     \
     if (WN == 4) e = launch_wg<KS_, S_, 4, 1>(a, st);                            \
     else if (WN == 2 && WC == 2) e = launch_wg<KS_, S_, 2, 2>(a, st);            \
     else if (WN == 2) e = launch_wg<KS_, S_, 2, 1>(a, st);                       \
     else e = launch_wg<KS_, S_, 1, 1>(a, st);
-    if (ks == 3 && stride == 1) { WG_DISPATCH(3, 1) }
-    else if (ks == 3 && stride == 2) { WG_DISPATCH(3, 2) }
-    else if (ks == 1 && stride == 1) { WG_DISPATCH(1, 1) }
+        if (ks == 3 && stride == 1) { WG_DISPATCH(3, 1) }
+        else if (ks == 3 && stride == 2) { WG_DISPATCH(3, 2) }
+        else if (ks == 1 && stride == 1) { WG_DISPATCH(1, 1) }
 #undef WG_DISPATCH
+    }
     if (e != hipSuccess) return e;
     const size_t total = (size_t)ks * ks * a.Cout * a.Cin;
     size_t gsz = (total + 255) / 256;
