@@ -209,7 +209,8 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
  * statistics like any train-mode forward.) */
 int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], int launches[3], void *stream);
 /* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
- * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel; 0 = automatic)
+ * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel, 32 = the LDS-free
+ * kernel for 16/32-channel 3x3 layers; 0 = automatic)
  * for mc_op_conv and for every layer of plans built afterwards that has no fixed shape. */
 int mc_set_conv_cfg(mc_handle *h, int cfg);
 /* Tuning aid: average duration (ms) of `iters` launches of one fused-conv shape on random data.

@@ -546,7 +546,8 @@ enum ConvCfgId {
     CFG_64x128 = 7,     // 1x4 waves, 2x1 tiles :  64 px x 128 ch
     CFG_64x64 = 8,      // 2x2 waves, 1x1 tiles :  64 px x  64 ch
     CFG_COUNT = 9,
-    CFG_WS = 16         // flag: wave-specialised kernel (producer wave + double-buffered LDS)
+    CFG_WS = 16,        // flag: wave-specialised kernel (producer wave + double-buffered LDS)
+    CFG_SMALL = 32      // LDS-free 16x16x4 kernel for 16/32-channel 3x3 layers (conv_small.hip)
 };
 inline ConvShape conv_shape(int cfg) {
     switch (cfg & 15) {
@@ -582,6 +583,14 @@ inline int conv_ck(int ks, int stride, const int *src_c, int nsrc) {
 int conv_pick_cfg(int Cout, int CoutP, int ks, int stride, int B, int Hout, int Wout);
 // patches per workgroup of the shape launch_conv() will use for these arguments
 inline int conv_patches_per_block(int cfg) { return conv_shape(cfg).PB(); }
+// statistics partials per image a launch with this shape writes (ConvArgs::chunks)
+inline int conv_chunks_per_image(int cfg, int Hout, int Wout) {
+    if (cfg == CFG_SMALL) return Hout;
+    const int ppi = ((Wout + 7) / 8) * ((Hout + 3) / 4), pb = conv_patches_per_block(cfg);
+    return (ppi + pb - 1) / pb;
+}
+bool conv_small_ok(const ConvArgs &a, int ks, int stride);
+hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st);
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);
 

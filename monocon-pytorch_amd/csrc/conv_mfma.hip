@@ -92,6 +92,15 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
     const int ck = conv_ck(ks, stride, sc, a.nsrc);
     for (int i = 0; i < a.nsrc; ++i)
         if (sc[i] % ck) return hipErrorInvalidValue;
+    if (a.cfg == CFG_SMALL) {
+        if (!conv_small_ok(a, ks, stride)) return hipErrorInvalidValue;
+        a.ppr = (a.Wout + 7) / 8;
+        a.ppi = a.ppr * ((a.Hout + 3) / 4);
+        a.chunks = a.Hout;
+        if (resolved) *resolved = a;
+        prof_last = {1, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks};
+        return launch_conv_small(a, stride, st);
+    }
     if (a.cfg == CFG_AUTO) a.cfg = conv_pick_cfg(a.Cout, a.CoutP, ks, stride, a.B, a.Hout, a.Wout);
     prof_last = {1, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks};
     if (ks == 3 && stride == 1) {

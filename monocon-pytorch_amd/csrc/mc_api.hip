@@ -191,10 +191,8 @@ struct Builder {
         a.res_ld = res ? res->C : 0;
         a.out = out.p; a.out_ld = out.C; a.out_coff = 0;
         a.relu = relu ? 1 : 0;
-        const int ppr = (Wo + 7) / 8, ppi = ppr * ((Ho + 3) / 4);
         a.cfg = L.cfg ? L.cfg : (ok ? mc_choose_conv_cfg(h, a, L.ks, L.stride) : CFG_128x32);
-        const int pb = conv_patches_per_block(a.cfg);
-        const int chunks = (ppi + pb - 1) / pb;
+        const int chunks = conv_chunks_per_image(a.cfg, Ho, Wo);
         if (stats_out) {
             *stats_out = alloc_raw((size_t)s0.B * chunks * L.coutp * 2);
             a.stats = *stats_out;
@@ -268,7 +266,8 @@ struct Builder {
 
 int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     if (h->force_cfg) return h->force_cfg;
-    const int heuristic = conv_pick_cfg(a_in.Cout, a_in.CoutP, ks, stride, a_in.B, a_in.Hout, a_in.Wout);
+    const bool small_ok = conv_small_ok(a_in, ks, stride);
+    const int heuristic = small_ok ? (int)CFG_SMALL : conv_pick_cfg(a_in.Cout, a_in.CoutP, ks, stride, a_in.B, a_in.Hout, a_in.Wout);
     if (!h->autotune) return heuristic;
     std::vector<int> key = {a_in.B, a_in.Hin, a_in.Win, ks, stride, a_in.Cout, a_in.CoutP, a_in.nsrc,
                             a_in.res ? 1 : 0};
@@ -276,7 +275,7 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     auto it = h->tuned.find(key);
     if (it != h->tuned.end()) return it->second;
     static const int cand[] = {CFG_128x128, CFG_128x64, CFG_128x64m, CFG_128x32, CFG_64x128, CFG_64x64,
-                               CFG_WS | CFG_128x128, CFG_WS | CFG_128x64m, CFG_WS | CFG_64x128, CFG_WS | CFG_64x64};
+                               CFG_WS | CFG_128x128, CFG_WS | CFG_128x64m, CFG_WS | CFG_64x128, CFG_WS | CFG_64x64, CFG_SMALL};
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return heuristic;
     ConvArgs a = a_in;
@@ -284,7 +283,7 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     int best = heuristic;
     float best_ms = 1e30f;
     for (int c : cand) {
-        if (a.CoutP % conv_shape(c).BNT()) continue;
+        if (c == CFG_SMALL ? !small_ok : (a.CoutP % conv_shape(c).BNT()) != 0) continue;
         a.cfg = c;
         if (launch_conv(a, ks, stride, nullptr) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm / unsupported
         float t_min = 1e30f;
@@ -900,7 +899,9 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
 
 int mc_set_conv_cfg(mc_handle *h, int cfg) {
     if (!h) return -1;
-    if (cfg < 0 || (cfg & 15) >= CFG_COUNT || (cfg & ~(15 | CFG_WS))) return fail(h, "mc_set_conv_cfg: unknown shape id");
+    if (cfg != CFG_SMALL && (cfg < 0 || (cfg & 15) >= CFG_COUNT || (cfg & ~(15 | CFG_WS))))
+        return fail(h, "mc_set_conv_cfg: unknown shape id");
+    if ((cfg & CFG_WS) && !(cfg & 15)) return fail(h, "mc_set_conv_cfg: the wave-specialised flag needs a shape");
     h->force_cfg = cfg;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());

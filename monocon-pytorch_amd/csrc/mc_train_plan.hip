@@ -150,8 +150,7 @@ struct TB {   // train plan builder
         a.B = B; a.Hin = s0.H; a.Win = s0.W; a.Hout = Ho; a.Wout = Wo; a.Cin = cin; a.Cout = Lr.cout; a.CoutP = Lr.coutp;
         a.wpk = Lr.wpk; a.out = r.y.p; a.out_ld = Lr.cout;
         a.cfg = ts->ok ? mc_choose_conv_cfg(h, a, Lr.ks, Lr.stride) : CFG_128x32;
-        const int ppr = (Wo + 7) / 8, ppi = ppr * ((Ho + 3) / 4), pb = conv_patches_per_block(a.cfg);
-        const int chunks = (ppi + pb - 1) / pb;
+        const int chunks = conv_chunks_per_image(a.cfg, Ho, Wo);
         float *stats = alloc((size_t)B * chunks * Lr.coutp * 2);
         a.stats = stats;
         a.stat_shift = P(Lr.bn + ".running_mean");

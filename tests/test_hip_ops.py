@@ -96,6 +96,44 @@ def test_conv_wave_specialised_is_bit_identical(eng, cfg):
         eng.set_conv_cfg(0)
 
 
+SMALL_CASES = [
+    # (name, B, H, W, Cin, Cout, stride, residual, relu)
+    ("small_16_16_s1", 2, 6, 32, 16, 16, 1, True, True),
+    ("small_16_16_s1_wide", 1, 5, 80, 16, 16, 1, False, False),
+    ("small_16_32_s2", 2, 8, 64, 16, 32, 2, False, True),
+    ("small_16_32_s1", 1, 4, 48, 16, 32, 1, True, True),
+    ("small_32_16_s1", 1, 7, 48, 32, 16, 1, True, False),
+    ("small_32_16_s2", 1, 6, 96, 32, 16, 2, False, True),
+]
+
+
+@pytest.mark.parametrize("case", SMALL_CASES, ids=[c[0] for c in SMALL_CASES])
+def test_conv_small_channel_kernel(eng, case):
+    """the LDS-free 16x16x4 kernel for the thin full-resolution layers (cfg 32) vs fp64 and vs the generic kernel."""
+    name, B, H, W, cin, cout, stride, use_res, relu = case
+    seed = 500 + SMALL_CASES.index(case)
+    x = rnd(seed, "x", (B, cin, H, W))
+    w = rnd(seed, "w", (cout, cin, 3, 3), (2.0 / (9 * cin)) ** 0.5)
+    scale = 1.0 + 0.1 * rnd(seed, "sc", (cout,))
+    bias = 0.1 * rnd(seed, "bi", (cout,))
+    ref = F.conv2d(x.double(), w.double(), None, stride, 1) * scale.double()[None, :, None, None] + bias.double()[None, :, None, None]
+    res = rnd(seed, "res", tuple(ref.shape)) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    dev = eng.device
+    args = ([nhwc(x).to(dev)], w.to(dev), stride, scale.to(dev), bias.to(dev), nhwc(res).to(dev) if use_res else None, relu)
+    try:
+        eng.set_conv_cfg(32)
+        got = eng.op_conv(*args)
+    finally:
+        eng.set_conv_cfg(0)
+    base = eng.op_conv(*args)
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < TOL
+    assert rel_err(got.cpu(), base.cpu()) < 1e-6
+
+
 def test_conv_is_transpose_sensitive(eng):
     """asymmetric one-hot weight: output channel n must read input channel (n*7)%C at tap (0,2)."""
     B, H, W, Cc = 1, 8, 8, 64
