@@ -301,7 +301,35 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     h->tuned[key] = best;
+    if (const char *path = std::getenv("MONOCON_HIP_TUNE_CACHE")) {   // optional: persist across processes
+        if (FILE *f = std::fopen(path, "a")) {
+            for (int v : key) std::fprintf(f, "%d ", v);
+            std::fprintf(f, ": %d\n", best);
+            std::fclose(f);
+        }
+    }
     return best;
+}
+
+static void load_tune_cache(mc_handle *h) {
+    const char *path = std::getenv("MONOCON_HIP_TUNE_CACHE");
+    if (!path) return;
+    FILE *f = std::fopen(path, "r");
+    if (!f) return;
+    char line[512];
+    while (std::fgets(line, sizeof line, f)) {
+        std::vector<int> key;
+        char *p = line;
+        int cfg = -1;
+        for (;;) {
+            while (*p == ' ') ++p;
+            if (*p == ':') { cfg = std::atoi(p + 1); break; }
+            if (!*p || *p == '\n') break;
+            key.push_back((int)std::strtol(p, &p, 10));
+        }
+        if (cfg > 0 && key.size() >= 10) h->tuned[key] = cfg;
+    }
+    std::fclose(f);
 }
 
 static Plan *get_plan(mc_handle *h, int B, int H, int W) {
@@ -466,6 +494,7 @@ int mc_create(int device, mc_handle **out) {
     mc_handle *h = new mc_handle();
     h->device = device;
     if (const char *e = std::getenv("MONOCON_HIP_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
+    load_tune_cache(h);
     *out = h;
     return 0;
 }
