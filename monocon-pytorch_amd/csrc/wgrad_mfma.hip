@@ -24,12 +24,12 @@ struct WgCfg {
     static constexpr int PAD = KS / 2;
     static constexpr int IH = 3 * S + KS, IW = 7 * S + KS, NPIX = IH * IW;
     static constexpr int CBP = CB + 4, NBP = NB + 4;
-    static constexpr int LDS_FLOATS = PB * NPIX * CBP + PB * 32 * NBP + PB * 4;
+    static constexpr int LDS_FLOATS = PB * NPIX * CBP + PB * 32 * NBP;
     static constexpr size_t LDS_BYTES = sizeof(float) * LDS_FLOATS;
 };
 
 template <int KS, int S, int WN, int WC>
-__global__ __launch_bounds__(64 * WN * WC) void wgrad_mfma_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_mfma_kernel(const WgradArgs a) {
     using Cfg = WgCfg<KS, S, WN, WC>;
     constexpr int PB = Cfg::PB, NB = Cfg::NB, CB = Cfg::CB, NT = Cfg::NT, PAD = Cfg::PAD;
     constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, CBP = Cfg::CBP, NBP = Cfg::NBP;
@@ -37,9 +37,9 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad_mfma_kernel(const WgradArg
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *xt = lds;                                   // [PB][NPIX][CBP]
     float *dyt = lds + PB * NPIX * CBP;                // [PB*32][NBP]
-    int *pinfo = reinterpret_cast<int *>(dyt + PB * 32 * NBP);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WC, wc = wave % WC;
     const int g = lane >> 5, li = lane & 31;
     const int ct = blockIdx.x % a.c_tiles;
@@ -55,58 +55,109 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad_mfma_kernel(const WgradArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    int soff[5];
-    soff[0] = 0;
-    for (int i = 0; i < 4; ++i) soff[i + 1] = soff[i] + (i < a.nsrc ? a.src[i].C : 0);
+    // ---- the c-tile lies inside ONE source of the virtual concat (wgrad_plan picks CB so)
+    int si = 0, cbase = 0;
+    while (si + 1 < a.nsrc && c0 >= cbase + a.src[si].C) { cbase += a.src[si].C; ++si; }
+    const int Cs = a.src[si].C;
+    const float *xsrc = a.src[si].p;
+    const int cs0 = c0 - cbase;                       // first channel of the tile inside the source
 
+    // ---- staging plan (see conv_mfma.h: buffer loads, lane offset = patch base (SGPR) + static part,
+    //      no per-element branches).  Per patch: X element e = tid + NT*i of [NPIX][CB/4], dY element
+    //      of [32][NB/4]; a thread keeps its channel group across i and across the patches.
+    //      Rows above / below the image fall outside the per-image buffer by themselves; columns left
+    //      / right of it would alias the neighbouring row and are masked per element (x_ix / d_mx;
+    //      statically dead elements carry a column that is never valid).
+    constexpr int XC4 = CB / 4, XP = NPIX * XC4, NIX = (XP + NT - 1) / NT;
+    constexpr int NC4 = NB / 4, DP = 32 * NC4, NID = (DP + NT - 1) / NT;
+    static_assert(NT % XC4 == 0 && NT % NC4 == 0, "static channel group per thread");
+    constexpr int DEAD = -(1 << 24);
+    const int xc4 = tid % XC4, dn4 = tid % NC4;
+    const bool xc_ok = cs0 + xc4 * 4 < Cs && c0 + xc4 * 4 < a.Cin;
+    const bool dn_ok = n0 + dn4 * 4 + 3 < a.dy_ld;
+    int x_stat[NIX], x_ix[NIX];
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+        const int e = tid + NT * i, pix = (e / XC4) % NPIX;
+        const int iy = pix / IW, ix = pix % IW;
+        x_ix[i] = (xc_ok && e < XP) ? ix - PAD : DEAD;
+        x_stat[i] = (((iy - PAD) * a.Win + ix - PAD) * Cs + cs0 + xc4 * 4) * 4;
+    }
+    int d_stat[NID], d_mx[NID];
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+        const int e = tid + NT * i, m = (e / NC4) % 32;
+        d_mx[i] = (dn_ok && e < DP) ? (m & 7) : -DEAD;
+        d_stat[i] = (((m >> 3) * a.Wout + (m & 7)) * a.dy_ld + n0 + dn4 * 4) * 4;
+    }
+    float *x_dst = xt + (tid / XC4) * CBP + xc4 * 4;
+    float *d_dst = dyt + (tid / NC4) * NBP + dn4 * 4;
+
+    f32x4 xv[PB][NIX], dv[PB][NID];   // without PF only [0] is live
+    // loads of patch p of pixel group gi into registers (with PF: in flight across the MFMA phase of
+    // group gi-1; the register-hungry shapes fetch and store patch by patch instead)
+    constexpr bool PF = S == 1 && NT >= 128;
+    auto fetch = [&](int gi, int p) {
+        const int img = gi / a.groups_per_img;
+        const int pp = (gi - img * a.groups_per_img) * PB + p;
+        const __amdgpu_buffer_rsrc_t r_x =
+            make_rsrc(xsrc + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
+        const __amdgpu_buffer_rsrc_t r_d =
+            make_rsrc(a.dy + (size_t)img * a.Hout * a.Wout * a.dy_ld, (unsigned)(a.Hout * a.Wout * a.dy_ld) * 4u);
+        const bool valid = pp < a.ppi;
+        const int oy = (pp / a.ppr) * 4, ox = valid ? (pp % a.ppr) * 8 : DEAD;   // SGPRs
+        const int xb = ((oy * S) * a.Win + ox * S) * Cs * 4;
+        const int db = (oy * a.Wout + ox) * a.dy_ld * 4;
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int xx = ox * S + x_ix[i];
+            xv[PF ? p : 0][i] = buf_load4(r_x, (xx >= 0 && xx < a.Win) ? xb + x_stat[i] : BUF_OOB, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NID; ++i) {
+            const int xx = ox + d_mx[i];
+            dv[PF ? p : 0][i] = buf_load4(r_d, (xx >= 0 && xx < a.Wout) ? db + d_stat[i] : BUF_OOB, 0);
+        }
+    };
+    auto store = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < NIX; ++i)
+            if (NT * (i + 1) <= XP || tid + NT * i < XP)
+                *reinterpret_cast<f32x4 *>(x_dst + (p * NPIX + i * (NT / XC4)) * CBP) = xv[PF ? p : 0][i];
+#pragma unroll
+        for (int i = 0; i < NID; ++i)
+            if (NT * (i + 1) <= DP || tid + NT * i < DP)
+                *reinterpret_cast<f32x4 *>(d_dst + (p * 32 + i * (NT / NC4)) * NBP) = dv[PF ? p : 0][i];
+    };
+
+    // per-lane fragment bases: pixel pair kk of a patch = pixels m = 2*kk + g
+    const float *a_base = dyt + g * NBP + wn * 32 + li;
+    const float *b_base = xt + (g * S) * CBP + wc * 32 + li;
+
+    if (PF && g_begin < g_end) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) fetch(g_begin, p);
+    }
     for (int gi = g_begin; gi < g_end; ++gi) {
-        __syncthreads();
-        if (tid < PB) {
-            const int img = gi / a.groups_per_img;
-            const int pp = (gi % a.groups_per_img) * PB + tid;
-            pinfo[tid * 4 + 0] = img;
-            pinfo[tid * 4 + 1] = (pp / a.ppr) * 4;
-            pinfo[tid * 4 + 2] = (pp % a.ppr) * 8;
-            pinfo[tid * 4 + 3] = pp < a.ppi;
-        }
-        __syncthreads();
+        __syncthreads();   // fragment reads of the previous group are done
         // TIMER_STAGE_BEGIN
-        // ---- stage X halo tile (virtual concat, zero outside image / beyond Cin)
-        constexpr int XC4 = CB / 4, XTOT = PB * NPIX * XC4;
-        for (int e = tid; e < XTOT; e += NT) {
-            const int c4 = e % XC4, t = e / XC4, pix = t % NPIX, p = t / NPIX;
-            const int iy = pix / IW, ix = pix % IW;
-            const int y = pinfo[p * 4 + 1] * S - PAD + iy, x = pinfo[p * 4 + 2] * S - PAD + ix;
-            const int cg = c0 + c4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win && cg < a.Cin) {
-                int si = 0;
-                while (si < 3 && cg >= soff[si + 1]) ++si;
-                v = *reinterpret_cast<const f32x4 *>(a.src[si].p + (((size_t)pinfo[p * 4] * a.Hin + y) * a.Win + x) * a.src[si].C +
-                                                     (cg - soff[si]));
-            }
-            *reinterpret_cast<f32x4 *>(&xt[(p * NPIX + pix) * CBP + c4 * 4]) = v;
-        }
-        // ---- stage dY tile
-        constexpr int NC4 = NB / 4, DTOT = PB * 32 * NC4;
-        for (int e = tid; e < DTOT; e += NT) {
-            const int n4 = e % NC4, t = e / NC4, m = t % 32, p = t / 32;
-            const int y = pinfo[p * 4 + 1] + (m >> 3), x = pinfo[p * 4 + 2] + (m & 7);
-            const int n = n0 + n4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pinfo[p * 4 + 3] && y < a.Hout && x < a.Wout && n + 3 < a.dy_ld)
-                v = *reinterpret_cast<const f32x4 *>(a.dy + (((size_t)pinfo[p * 4] * a.Hout + y) * a.Wout + x) * a.dy_ld + n);
-            *reinterpret_cast<f32x4 *>(&dyt[(p * 32 + m) * NBP + n4 * 4]) = v;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            if (!PF) fetch(gi, p);
+            store(p);
         }
         __syncthreads();
+        if (PF && gi + 1 < g_end) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) fetch(gi + 1, p);
+        }
         // TIMER_STAGE_END
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-#pragma unroll 4
+#pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                const int m = 2 * kk + g;
-                const float av = dyt[(p * 32 + m) * NBP + wn * 32 + li];
-                const float *xb = &xt[(p * NPIX + ((m >> 3) * S) * IW + (m & 7) * S) * CBP + wc * 32 + li];
+                const float av = a_base[(p * 32 + 2 * kk) * NBP];
+                const float *xb = b_base + (p * NPIX + ((kk >> 2) * S) * IW + (2 * (kk & 3)) * S) * CBP;
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const float bv = xb[((t / KS) * IW + (t % KS)) * CBP];
@@ -119,7 +170,7 @@ __global__ __launch_bounds__(64 * WN * WC) void wgrad_mfma_kernel(const WgradArg
     // TIMER_EPILOGUE_BEGIN
     // ---- epilogue: partial[ks][tap][n][c];  D row = n, D col (lane) = c
     const int c = c0 + wc * 32 + li;
-    if (c < a.Cin) {
+    if (c < a.Cin && c - cbase < Cs) {
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -258,12 +309,20 @@ static hipError_t launch_wg(WgradArgs a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// shape choice: n-tile 128 x c-tile 32 for wide layers, 64 x 64 for 64-column layers, single-wave tiles for <= 32
-static void wgrad_shape(int Cout, int Cin, int *WN, int *WC) {
-    if (Cout > 64) { *WN = 4; *WC = 1; }
-    else if (Cout > 32 && Cin > 32) { *WN = 2; *WC = 2; }
-    else if (Cout > 32) { *WN = 2; *WC = 1; }
+// shape choice: 64n x 64c (2x2 waves) wherever both dimensions allow, 128 x 32 for thin inputs, single-wave tiles for <= 32
+static void wgrad_shape(const WgradArgs &a, int *WN, int *WC) {
+    bool src64 = true;   // a c-tile must lie inside one source of the virtual concat
+    for (int i = 0; i < a.nsrc; ++i) src64 = src64 && (a.nsrc == 1 || a.src[i].C % 64 == 0);
+    // measured on MI355X (scratch/wgexp): the 64n x 64c workgroup beats 128n x 32c by 3-8 %
+    if (a.Cout > 32 && a.Cin > 32 && src64) { *WN = 2; *WC = 2; }
+    else if (a.Cout > 64) { *WN = 4; *WC = 1; }
+    else if (a.Cout > 32) { *WN = 2; *WC = 1; }
     else { *WN = 1; *WC = 1; }
+}
+static bool wgrad_sources_ok(const WgradArgs &a) {
+    for (int i = 0; i < a.nsrc; ++i)
+        if (a.src[i].C % 4 || (a.nsrc > 1 && a.src[i].C % 32)) return false;
+    return a.dy_ld % 4 == 0;
 }
 
 void wgrad_plan(WgradArgs &a, int ks, int stride) {
@@ -277,14 +336,14 @@ void wgrad_plan(WgradArgs &a, int ks, int stride) {
         return;
     }
     int WN, WC;
-    wgrad_shape(a.Cout, a.Cin, &WN, &WC);
+    wgrad_shape(a, &WN, &WC);
     a.n_tiles = (a.Cout + 32 * WN - 1) / (32 * WN);
     a.c_tiles = (a.Cin + 32 * WC - 1) / (32 * WC);
     a.ppr = (a.Wout + 7) / 8;
     a.ppi = a.ppr * ((a.Hout + 3) / 4);
     a.groups_per_img = (a.ppi + 1) / 2;
     const long long G = (long long)a.B * a.groups_per_img;
-    int ks_ = 1024 / (a.n_tiles * a.c_tiles);
+    int ks_ = 512 * 4 / (WN * WC) / (a.n_tiles * a.c_tiles);   // two resident 4-wave workgroups per CU
     if (ks_ < 1) ks_ = 1;
     if (ks_ > G) ks_ = (int)G;
     a.ksplit = ks_;
@@ -302,7 +361,8 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
         e = hipGetLastError();
     } else {
         int WN, WC;
-        wgrad_shape(a.Cout, a.Cin, &WN, &WC);
+        wgrad_shape(a, &WN, &WC);
+        if (!wgrad_sources_ok(a)) return hipErrorInvalidValue;
 #define WG_DISPATCH(KS_, S_)                                                     \
     if (WN == 4) e = launch_wg<KS_, S_, 4, 1>(a, st);                            \
     else if (WN == 2 && WC == 2) e = launch_wg<KS_, S_, 2, 2>(a, st);            \
