@@ -338,46 +338,54 @@ hipError_t launch_attn_train_bwd(const AttnTrainArgs &a, const float *partial, i
 // ------------------------------------------------------------------ 7x7 stem weight gradient
 // dW[o][c][r][s] = sum_{b,y,x} dY[b,y,x,o] * img[b,c,y-3+r,x-3+s].  VALU kernel: 16x64 pixel tile per WG,
 // thread t < 147 owns tap (c,r,s) and accumulates the 16 output channels; partial [tiles][147][16].
+constexpr int STEM_WG_TILES = 8;   // image tiles accumulated per workgroup (8x fewer split-K partials)
 __global__ __launch_bounds__(192) void stem_wgrad_kernel(const float *__restrict__ img, const float *__restrict__ dy, int B,
                                                          int H, int W, float *__restrict__ partial) {
     constexpr int TH = 8, TW = 32;
     __shared__ float it[3][TH + 6][TW + 6];
     __shared__ __attribute__((aligned(16))) float dt[TH * TW][16];
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int b = blockIdx.x / (tiles_x * tiles_y);
-    const int ty0 = ((blockIdx.x / tiles_x) % tiles_y) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    for (int e = threadIdx.x; e < 3 * (TH + 6) * (TW + 6); e += 192) {
-        const int lx = e % (TW + 6), ly = (e / (TW + 6)) % (TH + 6), c = e / ((TW + 6) * (TH + 6));
-        const int y = ty0 - 3 + ly, x = tx0 - 3 + lx;
-        it[c][ly][lx] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)b * 3 + c) * H + y) * W + x] : 0.f;
-    }
-    for (int e = threadIdx.x; e < TH * TW * 4; e += 192) {
-        const int q = e % 4, px = e / 4;
-        const int y = ty0 + px / TW, x = tx0 + px % TW;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (y < H && x < W) v = *reinterpret_cast<const f32x4 *>(dy + (((size_t)b * H + y) * W + x) * 16 + q * 4);
-        *reinterpret_cast<f32x4 *>(&dt[px][q * 4]) = v;
-    }
-    __syncthreads();
+    const int ntiles = B * tiles_x * tiles_y;
     const int t = threadIdx.x;
-    if (t >= 147) return;
-    const int c = t / 49, r = (t % 49) / 7, s = t % 7;
+    const int c = (t < 147 ? t : 0) / 49, r = ((t < 147 ? t : 0) % 49) / 7, s = (t < 147 ? t : 0) % 7;
     float acc[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) acc[o] = 0.f;
-    for (int py = 0; py < TH; ++py)
-        for (int px = 0; px < TW; ++px) {
-            const float v = it[c][py + r][px + s];
-            const f32x4 *d = reinterpret_cast<const f32x4 *>(&dt[py * TW + px][0]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 dv = d[q];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[q * 4 + j] = fmaf(v, dv[j], acc[q * 4 + j]);
-            }
+    for (int tile = blockIdx.x * STEM_WG_TILES; tile < ntiles && tile < (blockIdx.x + 1) * STEM_WG_TILES; ++tile) {
+        const int b = tile / (tiles_x * tiles_y);
+        const int ty0 = ((tile / tiles_x) % tiles_y) * TH, tx0 = (tile % tiles_x) * TW;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 3 * (TH + 6) * (TW + 6); e += 192) {
+            const int lx = e % (TW + 6), ly = (e / (TW + 6)) % (TH + 6), cc = e / ((TW + 6) * (TH + 6));
+            const int y = ty0 - 3 + ly, x = tx0 - 3 + lx;
+            it[cc][ly][lx] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(((size_t)b * 3 + cc) * H + y) * W + x] : 0.f;
         }
+        for (int e = threadIdx.x; e < TH * TW * 4; e += 192) {
+            const int q = e % 4, px = e / 4;
+            const int y = ty0 + px / TW, x = tx0 + px % TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y < H && x < W) v = *reinterpret_cast<const f32x4 *>(dy + (((size_t)b * H + y) * W + x) * 16 + q * 4);
+            *reinterpret_cast<f32x4 *>(&dt[px][q * 4]) = v;
+        }
+        __syncthreads();
+        if (t < 147) {
+            for (int py = 0; py < TH; ++py)
+                for (int px = 0; px < TW; ++px) {
+                    const float v = it[c][py + r][px + s];
+                    const f32x4 *d = reinterpret_cast<const f32x4 *>(&dt[py * TW + px][0]);
 #pragma unroll
-    for (int o = 0; o < 16; ++o) partial[((size_t)blockIdx.x * 147 + t) * 16 + o] = acc[o];
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 dv = d[q];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[q * 4 + j] = fmaf(v, dv[j], acc[q * 4 + j]);
+                    }
+                }
+        }
+    }
+    if (t < 147) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) partial[((size_t)blockIdx.x * 147 + t) * 16 + o] = acc[o];
+    }
 }
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float *__restrict__ partial, int nblocks,
                                                                 float *__restrict__ dw /*(16,3,7,7)*/) {
@@ -390,7 +398,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float *__r
     __syncthreads();
     if (threadIdx.x == 0) dw[o * 147 + t] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
-int stem_wgrad_blocks(int B, int H, int W) { return B * ((W + 31) / 32) * ((H + 7) / 8); }
+int stem_wgrad_blocks(int B, int H, int W) {
+    return (B * ((W + 31) / 32) * ((H + 7) / 8) + STEM_WG_TILES - 1) / STEM_WG_TILES;
+}
 hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
                              hipStream_t st) {
     const int nb = stem_wgrad_blocks(B, H, W);

@@ -35,22 +35,42 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
     f32x4 sh = {0.f, 0.f, 0.f, 0.f};
     if (active && mode == 0 && shift) sh = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
     if (active) {
-        for (int r = r0 + rg; r < r1; r += RG) {
-            const size_t o = ((size_t)b * rows_per_img + r) * C + c4 * 4;
-            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + o);
+        auto one = [&](const f32x4 yv, f32x4 d, const f32x4 zv) {
             if (mode == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = yv[j] - sh[j]; s1[j] += d; s2[j] += d * d; }
+                for (int j = 0; j < 4; ++j) { const float t = yv[j] - sh[j]; s1[j] += t; s2[j] += t * t; }
             } else {
-                f32x4 d = *reinterpret_cast<const f32x4 *>(dz + o);
-                if (relu) {
-                    const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + o);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d[j] = zv[j] > 0.f ? d[j] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    if (relu) d[j] = zv[j] > 0.f ? d[j] : 0.f;
+                    s1[j] += d[j]; s2[j] += d[j] * yv[j];
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[j] += d[j]; s2[j] += d[j] * yv[j]; }
             }
+        };
+        const f32x4 *y4 = reinterpret_cast<const f32x4 *>(y), *d4 = reinterpret_cast<const f32x4 *>(dz);
+        const f32x4 *z4 = reinterpret_cast<const f32x4 *>(z);
+        const unsigned base = ((unsigned)b * rows_per_img) * C4 + c4, step = (unsigned)RG * C4;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        int r = r0 + rg;
+        for (; r + 3 * RG < r1; r += 4 * RG) {   // four independent rows in flight
+            const unsigned e = base + (unsigned)r * C4;
+            f32x4 yv[4], dv[4], zv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) yv[u] = y4[e + u * step];
+            if (mode != 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dv[u] = d4[e + u * step];
+                if (relu) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) zv[u] = z4[e + u * step];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(yv[u], mode != 0 ? dv[u] : zero, (mode != 0 && relu) ? zv[u] : zero);
+        }
+        for (; r < r1; r += RG) {
+            const unsigned e = base + (unsigned)r * C4;
+            one(y4[e], mode != 0 ? d4[e] : zero, (mode != 0 && relu) ? z4[e] : zero);
         }
     }
     __shared__ float red[256 * 8];
@@ -123,33 +143,78 @@ hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double 
 
 // ------------------------------------------------------------------ z = act(a*y + b (+ res))
 // per_sample: coefficient index = b*C + c (AttnBN) instead of c (BatchNorm)
+// Thread layout of the element-wise passes: a thread owns ONE group of 4 channels (its coefficients
+// stay in registers) and walks rows of ONE image with 32-bit float4 indices, four independent rows
+// in flight -- no per-element div/mod, no coefficient reloads.
+struct RowSplit { int threads, rg, blocks_per_img, rows_per_block; };
+static RowSplit row_split(int B, size_t rows_per_img, int C4) {
+    RowSplit r;
+    r.rg = 256 / C4 > 0 ? 256 / C4 : 1;
+    r.threads = C4 * r.rg;
+    int want = 8192 / (B > 0 ? B : 1);                       // ~8k workgroups per launch
+    if (want < 1) want = 1;
+    size_t min_rows = (size_t)r.rg * 8;                       // at least 8 rows per thread
+    size_t bpi = (rows_per_img + min_rows - 1) / min_rows;
+    if (bpi > (size_t)want) bpi = want;
+    if (bpi < 1) bpi = 1;
+    r.blocks_per_img = (int)bpi;
+    r.rows_per_block = (int)((rows_per_img + bpi - 1) / bpi);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict__ y, const float *__restrict__ a,
                                                          const float *__restrict__ bb, const f32x4 *__restrict__ res,
-                                                         size_t total4, int C4, size_t rows_per_img, int per_sample,
-                                                         int relu, f32x4 *__restrict__ z) {
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = e % C4;
-        const size_t row = e / C4;
-        const size_t ci = (per_sample ? (row / rows_per_img) * C4 : 0) + c4;
-        const f32x4 av = reinterpret_cast<const f32x4 *>(a)[ci], bv = reinterpret_cast<const f32x4 *>(bb)[ci];
+                                                         int C4, int RG, int rows_per_img, int blocks_per_img,
+                                                         int rows_per_block, int per_sample, int relu,
+                                                         f32x4 *__restrict__ z) {
+    const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
+    const int b = blockIdx.x / blocks_per_img, rb = blockIdx.x % blocks_per_img;
+    const int r0 = rb * rows_per_block, r1 = min(rows_per_img, r0 + rows_per_block);
+    const int ci = (per_sample ? b * C4 : 0) + c4;
+    const f32x4 av = reinterpret_cast<const f32x4 *>(a)[ci], bv = reinterpret_cast<const f32x4 *>(bb)[ci];
+    const float fl = relu ? 0.f : -__builtin_inff();
+    const unsigned base = ((unsigned)b * rows_per_img) * C4 + c4;
+    const unsigned step = (unsigned)RG * C4;
+    int r = r0 + rg;
+    for (; r + 3 * RG < r1; r += 4 * RG) {
+        const unsigned e = base + (unsigned)r * C4;
+        f32x4 v[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = y[e + u * step];
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = res[e + u * step];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = fmaf(v[u][j], av[j], bv[j]);
+                if (res) t += q[u][j];
+                v[u][j] = fmaxf(t, fl);
+            }
+            z[e + u * step] = v[u];
+        }
+    }
+    for (; r < r1; r += RG) {
+        const unsigned e = base + (unsigned)r * C4;
         f32x4 v = y[e];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], av[j], bv[j]);
-        if (res) { const f32x4 r = res[e];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += r[j]; }
-        if (relu) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f); }
+        for (int j = 0; j < 4; ++j) {
+            float t = fmaf(v[j], av[j], bv[j]);
+            if (res) t += res[e][j];
+            v[j] = fmaxf(t, fl);
+        }
         z[e] = v;
     }
 }
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *z, hipStream_t st) {
-    const size_t total4 = (size_t)B * rows_per_img * (C / 4);
-    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(y),
-                       a, b, reinterpret_cast<const f32x4 *>(res), total4, C / 4, rows_per_img, per_sample, relu,
-                       reinterpret_cast<f32x4 *>(z));
+    if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
+    const RowSplit rs = row_split(B, rows_per_img, C / 4);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(B * rs.blocks_per_img), dim3(rs.threads), 0, st,
+                       reinterpret_cast<const f32x4 *>(y), a, b, reinterpret_cast<const f32x4 *>(res), C / 4, rs.rg,
+                       (int)rows_per_img, rs.blocks_per_img, rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(z));
     return hipGetLastError();
 }
 
@@ -196,38 +261,65 @@ hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, dou
 // gres_mode: 0 none, 1 gres = d, 2 gres += d (gradient of the residual input)
 __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict__ dz, const f32x4 *__restrict__ z,
                                                          const f32x4 *__restrict__ y, const float *__restrict__ coef,
-                                                         size_t total4, int C4, size_t rows_per_img, int per_sample,
-                                                         int relu, f32x4 *__restrict__ dy, f32x4 *__restrict__ gres,
-                                                         int gres_mode) {
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = e % C4;
-        const size_t row = e / C4;
-        const size_t ci = ((per_sample ? (row / rows_per_img) * C4 : 0) + c4) * 4;
-        f32x4 d = dz[e];
-        if (relu) { const f32x4 zv = z[e];
+                                                         int C4, int RG, int rows_per_img, int blocks_per_img,
+                                                         int rows_per_block, int per_sample, int relu,
+                                                         f32x4 *__restrict__ dy, f32x4 *__restrict__ gres, int gres_mode) {
+    const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
+    const int b = blockIdx.x / blocks_per_img, rb = blockIdx.x % blocks_per_img;
+    const int r0 = rb * rows_per_block, r1 = min(rows_per_img, r0 + rows_per_block);
+    const int ci = ((per_sample ? b * C4 : 0) + c4) * 4;
+    float cp[4], cq[4], cr[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = zv[j] > 0.f ? d[j] : 0.f; }
-        const f32x4 yv = y[e];
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 cf = reinterpret_cast<const f32x4 *>(coef)[ci + j];
+        cp[j] = cf[0]; cq[j] = cf[1]; cr[j] = cf[2];
+    }
+    const unsigned base = ((unsigned)b * rows_per_img) * C4 + c4;
+    const unsigned step = (unsigned)RG * C4;
+    auto one = [&](unsigned e, f32x4 d, const f32x4 zv, const f32x4 yv) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 cf = reinterpret_cast<const f32x4 *>(coef)[ci + j];
-            o[j] = fmaf(cf[0], d[j], fmaf(cf[1], yv[j], cf[2]));
+            if (relu) d[j] = zv[j] > 0.f ? d[j] : 0.f;
+            o[j] = fmaf(cp[j], d[j], fmaf(cq[j], yv[j], cr[j]));
         }
         dy[e] = o;
         if (gres_mode == 1) gres[e] = d;
-        else if (gres_mode == 2) { f32x4 g = gres[e];
+        else if (gres_mode == 2) {
+            f32x4 gv = gres[e];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] += d[j];
-            gres[e] = g; }
+            for (int j = 0; j < 4; ++j) gv[j] += d[j];
+            gres[e] = gv;
+        }
+    };
+    int r = r0 + rg;
+    for (; r + 3 * RG < r1; r += 4 * RG) {
+        const unsigned e = base + (unsigned)r * C4;
+        f32x4 d[4], zv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { d[u] = dz[e + u * step]; yv[u] = y[e + u * step]; }
+        if (relu) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) zv[u] = z[e + u * step];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(e + u * step, d[u], zv[u], yv[u]);
+    }
+    for (; r < r1; r += RG) {
+        const unsigned e = base + (unsigned)r * C4;
+        f32x4 zv = {1.f, 1.f, 1.f, 1.f};
+        if (relu) zv = z[e];
+        one(e, dz[e], zv, y[e]);
     }
 }
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st) {
-    const size_t total4 = (size_t)B * rows_per_img * (C / 4);
-    hipLaunchKernelGGL(affine_bwd_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(dz),
-                       reinterpret_cast<const f32x4 *>(z), reinterpret_cast<const f32x4 *>(y), coef, total4, C / 4,
-                       rows_per_img, per_sample, relu, reinterpret_cast<f32x4 *>(dy), reinterpret_cast<f32x4 *>(gres),
+    if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
+    const RowSplit rs = row_split(B, rows_per_img, C / 4);
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3(B * rs.blocks_per_img), dim3(rs.threads), 0, st,
+                       reinterpret_cast<const f32x4 *>(dz), reinterpret_cast<const f32x4 *>(z),
+                       reinterpret_cast<const f32x4 *>(y), coef, C / 4, rs.rg, (int)rows_per_img, rs.blocks_per_img,
+                       rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(dy), reinterpret_cast<f32x4 *>(gres),
                        gres_mode);
     return hipGetLastError();
 }
@@ -367,29 +459,53 @@ hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C
 // One workgroup per (image row-block); partial [blocks][16][C] then reduced by colsum-like pass.
 __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restrict__ in, const float *__restrict__ dout,
                                                             int B, int H, int W, int C, float *__restrict__ partial) {
-    // threads cover channels (C <= 256); each block handles one (b, iy) input row
+    // one workgroup per (b, iy) input row; a thread owns 4 channels and every XG-th column, 16-byte
+    // loads; the column groups are summed by wave shuffles + one LDS image (fixed order)
+    __shared__ float red[16][256];
+    const int C4 = C >> 2, XG = 256 / C4;
+    const int tid = threadIdx.x, c4 = tid % C4, xg = tid / C4;
     const int b = blockIdx.x / H, iy = blockIdx.x % H;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc[16];
+    const f32x4 *in4 = reinterpret_cast<const f32x4 *>(in), *do4 = reinterpret_cast<const f32x4 *>(dout);
+    f32x4 acc[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        for (int ix = 0; ix < W; ++ix) {
-            const float v = in[(((size_t)b * H + iy) * W + ix) * C + c];
+    for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ix = xg; ix < W; ix += XG) {
+        const f32x4 v = in4[(((size_t)b * H + iy) * W + ix) * C4 + c4];
 #pragma unroll
-            for (int ky = 0; ky < 4; ++ky) {
-                const int oy = 2 * iy - 1 + ky;
-                if (oy < 0 || oy >= 2 * H) continue;
+        for (int ky = 0; ky < 4; ++ky) {
+            const int oy = 2 * iy - 1 + ky;
+            if (oy < 0 || oy >= 2 * H) continue;
 #pragma unroll
-                for (int kx = 0; kx < 4; ++kx) {
-                    const int ox = 2 * ix - 1 + kx;
-                    if (ox < 0 || ox >= 2 * W) continue;
-                    acc[ky * 4 + kx] = fmaf(v, dout[(((size_t)b * 2 * H + oy) * 2 * W + ox) * C + c], acc[ky * 4 + kx]);
-                }
+            for (int kx = 0; kx < 4; ++kx) {
+                const int ox = 2 * ix - 1 + kx;
+                if (ox < 0 || ox >= 2 * W) continue;
+                const f32x4 d = do4[(((size_t)b * 2 * H + oy) * 2 * W + ox) * C4 + c4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ky * 4 + kx][j] = fmaf(v[j], d[j], acc[ky * 4 + kx][j]);
             }
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) partial[((size_t)blockIdx.x * 16 + k) * C + c] = acc[k];
     }
+    // lanes c4 + C4*j of a wave hold the same channels
+    for (int o = C4; o < 64; o <<= 1)
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] += __shfl_xor(acc[k][j], o);
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w && lane < C4 && lane < 64) {
+            // with C4 = 64 a wave covers all channel groups once; otherwise lanes < C4 hold the wave's sum
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float *dst = &red[k][(tid % C4) * 4 + j];
+                    *dst = (w == 0 ? 0.f : *dst) + acc[k][j];
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 16 * C; e += 256) partial[(size_t)blockIdx.x * 16 * C + e] = red[e / C][e % C];
 }
 __global__ __launch_bounds__(256) void deconv4_bwd_w_reduce_kernel(const float *__restrict__ partial, int nblocks, int C,
                                                                    float *__restrict__ dw /*(C,1,4,4)*/) {
@@ -405,6 +521,7 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_reduce_kernel(const float *
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C) { return (size_t)B * H * 16 * C; }
 hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
                                 hipStream_t st) {
+    if (C % 4 || C > 256 || 256 % (C / 4)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(deconv4_bwd_w_kernel, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial);
     hipLaunchKernelGGL(deconv4_bwd_w_reduce_kernel, dim3(C * 16), dim3(256), 0, st, partial, B * H, C, dw);
     return hipGetLastError();

@@ -29,21 +29,25 @@ int mc_make_targets(mc_handle *h, const mc_labels *lab, int B, int max_objs, int
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t HW = (size_t)fh * fw, R = (size_t)B * max_objs;
-    HIPCHK(h, hipMemsetAsync(t->center_heatmap_target, 0, B * 3 * HW * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->kpt_heatmap_target, 0, B * 9 * HW * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->wh_target, 0, R * 2 * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->offset_target, 0, R * 2 * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->dim_target, 0, R * 3 * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->alpha_cls_target, 0, R * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->alpha_offset_target, 0, R * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->depth_target, 0, R * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->center2kpt_offset_target, 0, R * 18 * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->kpt_heatmap_offset_target, 0, R * 18 * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->indices, 0, R * 8, st));
-    HIPCHK(h, hipMemsetAsync(t->indices_kpt, 0, R * 9 * 8, st));
-    HIPCHK(h, hipMemsetAsync(t->mask_target, 0, R, st));
-    HIPCHK(h, hipMemsetAsync(t->mask_center2kpt_offset, 0, R * 18 * 4, st));
-    HIPCHK(h, hipMemsetAsync(t->mask_kpt_heatmap_offset, 0, R * 18 * 4, st));
+    if (h->tgt_arena && t->center_heatmap_target == h->tgt_arena) {
+        HIPCHK(h, hipMemsetAsync(h->tgt_arena, 0, h->tgt_arena_bytes, st));
+    } else {
+        HIPCHK(h, hipMemsetAsync(t->center_heatmap_target, 0, B * 3 * HW * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->kpt_heatmap_target, 0, B * 9 * HW * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->wh_target, 0, R * 2 * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->offset_target, 0, R * 2 * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->dim_target, 0, R * 3 * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->alpha_cls_target, 0, R * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->alpha_offset_target, 0, R * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->depth_target, 0, R * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->center2kpt_offset_target, 0, R * 18 * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->kpt_heatmap_offset_target, 0, R * 18 * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->indices, 0, R * 8, st));
+        HIPCHK(h, hipMemsetAsync(t->indices_kpt, 0, R * 9 * 8, st));
+        HIPCHK(h, hipMemsetAsync(t->mask_target, 0, R, st));
+        HIPCHK(h, hipMemsetAsync(t->mask_center2kpt_offset, 0, R * 18 * 4, st));
+        HIPCHK(h, hipMemsetAsync(t->mask_kpt_heatmap_offset, 0, R * 18 * 4, st));
+    }
     mc::TargetArgs a{};
     a.gt_bboxes = lab->gt_bboxes; a.gt_labels = lab->gt_labels; a.gt_bboxes_3d = lab->gt_bboxes_3d;
     a.depths = lab->depths; a.gt_kpts_2d = lab->gt_kpts_2d; a.gt_kpts_valid = lab->gt_kpts_valid_mask; a.mask = lab->mask;
@@ -122,7 +126,11 @@ int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS], con
     // recompute the reductions the gradients need (npos, object count, dim compensation weight)
     HIPCHK(h, mc::launch_focal(preds[0], t->center_heatmap_target, (size_t)B * 3 * HW, h->loss_ws, scratch_losses + 0, aux + 0, st));
     HIPCHK(h, mc::launch_focal(preds[1], t->kpt_heatmap_target, (size_t)B * 9 * HW, h->loss_ws + npf, scratch_losses + 5, aux + 1, st));
-    for (int i = 2; i < 10; ++i) HIPCHK(h, hipMemsetAsync(dpreds[i], 0, (size_t)B * PC[i] * HW * 4, st));
+    if (h->dp_arena && dpreds[2] == h->dp_arena) {
+        HIPCHK(h, hipMemsetAsync(h->dp_arena, 0, h->dp_arena_bytes, st));
+    } else {
+        for (int i = 2; i < 10; ++i) HIPCHK(h, hipMemsetAsync(dpreds[i], 0, (size_t)B * PC[i] * HW * 4, st));
+    }
     HIPCHK(h, mc::launch_focal_grad(preds[0], t->center_heatmap_target, (size_t)B * 3 * HW, aux + 0, grad_losses, 0, dpreds[0], st));
     HIPCHK(h, mc::launch_focal_grad(preds[1], t->kpt_heatmap_target, (size_t)B * 9 * HW, aux + 1, grad_losses, 5, dpreds[1], st));
     mc::GatherLossArgs g{};

@@ -451,15 +451,31 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
     {
         mc_targets &T = ts->targets;
         const size_t R = (size_t)B * ts->max_objs;
-        T.center_heatmap_target = b.alloc((size_t)B * 3 * HW); T.kpt_heatmap_target = b.alloc((size_t)B * 9 * HW);
-        T.wh_target = b.alloc(R * 2); T.offset_target = b.alloc(R * 2); T.dim_target = b.alloc(R * 3);
-        T.alpha_cls_target = b.alloc(R); T.alpha_offset_target = b.alloc(R); T.depth_target = b.alloc(R);
-        T.center2kpt_offset_target = b.alloc(R * 18); T.kpt_heatmap_offset_target = b.alloc(R * 18);
-        T.indices = reinterpret_cast<int64_t *>(b.alloc(R * 2)); T.indices_kpt = reinterpret_cast<int64_t *>(b.alloc(R * 18));
-        T.mask_target = reinterpret_cast<uint8_t *>(b.alloc(R / 4 + 1));
-        T.mask_center2kpt_offset = b.alloc(R * 18); T.mask_kpt_heatmap_offset = b.alloc(R * 18);
+        // one arena for the targets, one for the regression-gradient maps (single zero fill each)
+        auto up = [](size_t n) { return (n + 63) / 64 * 64; };
+        const size_t tn[15] = {(size_t)B * 3 * HW, (size_t)B * 9 * HW, R * 2, R * 2, R * 3, R, R, R, R * 18, R * 18,
+                               R * 2, R * 18, R / 4 + 1, R * 18, R * 18};
+        size_t ttot = 0;
+        for (size_t n : tn) ttot += up(n);
+        float *ta = b.alloc(ttot);
+        float *tp[15];
+        { size_t o = 0; for (int i = 0; i < 15; ++i) { tp[i] = ta ? ta + o : nullptr; o += up(tn[i]); } }
+        T.center_heatmap_target = tp[0]; T.kpt_heatmap_target = tp[1];
+        T.wh_target = tp[2]; T.offset_target = tp[3]; T.dim_target = tp[4];
+        T.alpha_cls_target = tp[5]; T.alpha_offset_target = tp[6]; T.depth_target = tp[7];
+        T.center2kpt_offset_target = tp[8]; T.kpt_heatmap_offset_target = tp[9];
+        T.indices = reinterpret_cast<int64_t *>(tp[10]); T.indices_kpt = reinterpret_cast<int64_t *>(tp[11]);
+        T.mask_target = reinterpret_cast<uint8_t *>(tp[12]);
+        T.mask_center2kpt_offset = tp[13]; T.mask_kpt_heatmap_offset = tp[14];
+        h->tgt_arena = ta; h->tgt_arena_bytes = ttot * sizeof(float);
         static const int PC[10] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
-        for (int i = 0; i < 10; ++i) ts->dpred[i] = b.alloc((size_t)B * PC[i] * HW);
+        ts->dpred[0] = b.alloc((size_t)B * PC[0] * HW);
+        ts->dpred[1] = b.alloc((size_t)B * PC[1] * HW);
+        size_t dtot = 0;
+        for (int i = 2; i < 10; ++i) dtot += up((size_t)B * PC[i] * HW);
+        float *da = b.alloc(dtot);
+        { size_t o = 0; for (int i = 2; i < 10; ++i) { ts->dpred[i] = da ? da + o : nullptr; o += up((size_t)B * PC[i] * HW); } }
+        h->dp_arena = da; h->dp_arena_bytes = dtot * sizeof(float);
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
             if (mc_make_targets(hh, &ts->labels, B, ts->max_objs, ts->pad_h, ts->pad_w, fh, fw, &ts->targets, st)) return -1;
             if (mc_losses(hh, ts->preds, &ts->targets, B, ts->max_objs, fh, fw, ts->losses, st)) return -1;
@@ -619,6 +635,8 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
     if (!ts || ts->B != B || ts->H != H || ts->W != W || ts->bind_gen != h->bind_gen) {
         if (ts && h->train_free) h->train_free(ts);
         h->train = nullptr;
+        h->tgt_arena = h->dp_arena = nullptr;
+        h->tgt_arena_bytes = h->dp_arena_bytes = 0;
         ts = build_train(h, B, H, W);
         if (!ts) return -1;
         h->train = ts;
