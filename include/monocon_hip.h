@@ -150,7 +150,8 @@ int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS],
  * every live parameter are WRITTEN to the tensors bound as "<key>#grad" (the six parameters the
  * reference never back-propagates into -- SURVEY 8a quirk (i) -- are not touched).
  * Data parallelism: every rank runs this on its own shard; averaging the "#grad" tensors across
- * ranks (RCCL all-reduce, done by the host with torch.distributed) precedes the optimizer. */
+ * ranks (RCCL all-reduce, done by the host with torch.distributed) precedes the optimizer. * The packed weight panels are refreshed first when mc_bind_params or mc_clip_adamw_step made them
+ * stale; after any other in-place parameter update call mc_pack_params yourself. */
 int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, int B, int H, int W,
                      int max_objs, float *const preds[MC_NUM_PREDS], float *losses, void *stream);
 int mc_backward(mc_handle *h, const float *grad_losses, void *stream);

@@ -524,6 +524,7 @@ int mc_bind_params(mc_handle *h, const mc_tensor_desc *descs, int n) {
         h->bound[descs[i].name] = Bound{descs[i].ptr, descs[i].numel, descs[i].dtype};
     }
     h->packed = false;
+    h->pack_clean = false;
     h->bind_gen++;
     return 0;
 }
@@ -619,6 +620,7 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
 #undef NEEDP
     h->packed_groups = (has_bb ? 1 : 0) | (has_neck ? 2 : 0) | (has_head ? 4 : 0);
     h->packed = h->packed_groups == 7;
+    h->pack_clean = true;
     return 0;
 }
 

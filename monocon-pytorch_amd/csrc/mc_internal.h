@@ -108,6 +108,7 @@ struct mc_handle {
     TrainState *train = nullptr;
     void (*train_free)(TrainState *) = nullptr;
     unsigned long long bind_gen = 0;
+    bool pack_clean = false;   // packed panels match the bound parameters (cleared by bind / optimizer step)
     // train plan: all target tensors / all regression-gradient maps live in one arena each, so the
     // per-step zero fill is one memset instead of 17 + 8 (mc_make_targets / mc_losses_backward)
     void *tgt_arena = nullptr, *dp_arena = nullptr;

@@ -223,6 +223,7 @@ int mc_clip_adamw_step(mc_handle *h, double lr, double beta1, double beta2, doub
     float *normcoef = h->opt_ws + mc::opt_partial_floats();
     HIPCHK(h, mc::launch_clip_adamw(h->opt_tab, h->opt_chunks, h->opt_nchunks, h->opt_ws, normcoef, (float)max_norm, hp, st));
     if (out_norm) HIPCHK(h, hipMemcpyAsync(out_norm, normcoef, sizeof(float), hipMemcpyDeviceToDevice, st));
+    h->pack_clean = false;   // parameters changed: the packed panels are stale
     return 0;
 }
 

@@ -648,7 +648,7 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
         ts->preds[i] = preds[i];
     }
     // refresh derived weights: forward panels (no BN folding in train mode), dgrad panels
-    if (mc_pack_params(h, 1, stream)) return -1;
+    if (!h->pack_clean && mc_pack_params(h, 1, stream)) return -1;   // mc_pack_params / the optimizer step track staleness
     for (auto &f : ts->pack_fns)       // dense head weight copies first: some dgrad panels are cut from them
         if (f(h, st)) return -1;
     for (const PackJob &j : ts->packs)

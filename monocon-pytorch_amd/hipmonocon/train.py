@@ -92,7 +92,9 @@ class _HipTrainStep(torch.autograd.Function):
             if gb is None:
                 out.append(None)
             elif p.grad is None:
-                out.append(gb)            # becomes p.grad as a view of the flat buffer (no copy)
+                # a fresh alias (use_count 1): AccumulateGrad adopts it as p.grad -- a view of the flat
+                # buffer, no copy; returning the stored view object itself would make torch clone it
+                out.append(gb.detach())
             else:
                 out.append(gb.clone())    # caller is accumulating across backward passes: torch adds a copy
         return (None, None, None, None, None, None, *out)
