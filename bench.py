@@ -196,6 +196,14 @@ def main():
                    "whole_forward_tflops": round(fl / (fms * 1e-3) / 1e12, 2),
                    "whole_forward_frac_of_hbm_peak": round(by / (fms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
 
+    traffic, traffic_src = None, None
+    try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected in-process)
+        tj = json.load(open(os.path.join(REPO, "profiles", "latest_traffic.json")))
+        fam = tj["families"]["mc::conv_mfma_kernel"]
+        traffic = round((fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]) / 1e6, 1)
+        traffic_src = tj["source"]
+    except Exception:
+        pass
     if rank == 0:
         conv, wg, oth = prof["conv"], prof["wgrad"], prof["other"]
         conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
@@ -217,7 +225,9 @@ def main():
                 "bound": "mfma",
                 "kernel": "conv_mfma_kernel: %d launches per train step (forward convs + data gradients)" % conv["launches"],
                 "achieved": round(conv_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "MB of HBM traffic per launch (PMC)", "traffic_source": traffic_src,
+                "algorithmic_mb_per_launch": round(conv.get("bytes", 0.0) / max(conv["launches"], 1) / 1e6, 1),
                 "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4),
                 "conv_ms_per_step": round(conv["ms"], 2),
                 "wgrad": {"kernel": "wgrad_mfma_kernel (+ split-K reduce): %d launches" % wg["launches"],

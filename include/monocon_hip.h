@@ -206,9 +206,10 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
  * `iters` times with a HIP event pair around every launch group on `stream` and returns, per
  * kernel family k (0 = everything else, 1 = conv_mfma_kernel: forward convs + data gradients,
  * 2 = wgrad_mfma_kernel: weight gradients), the summed duration ms[k], the algorithmic FLOPs
- * flops[k] and the number of launch groups, averaged per train step.  (Mutates BN running
+ * flops[k] and bytes[k] (every operand once) and the number of launch groups, averaged per step.  (Mutates BN running
  * statistics like any train-mode forward.) */
-int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], int launches[3], void *stream);
+int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], double bytes[3], int launches[3],
+                     void *stream);
 /* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
  * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel, 32 = the LDS-free
  * kernel for 16/32-channel 3x3 layers; 0 = automatic)

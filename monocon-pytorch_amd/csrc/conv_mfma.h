@@ -596,7 +596,7 @@ hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, Co
 
 // Measurement aid (mc_profile_train): the last launch_conv / launch_wgrad on this host thread notes
 // its kernel family (1 = fused conv incl. dgrad, 2 = wgrad) and algorithmic FLOPs here.
-struct ProfLast { int kind; double flops; };
+struct ProfLast { int kind; double flops, bytes; };   // bytes: algorithmic (inputs + outputs + weights, each once)
 extern thread_local ProfLast prof_last;
 
 }  // namespace mc

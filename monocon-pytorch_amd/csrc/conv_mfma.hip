@@ -3,7 +3,12 @@
 
 namespace mc {
 
-thread_local ProfLast prof_last = {0, 0.0};
+thread_local ProfLast prof_last = {0, 0.0, 0.0};
+static ProfLast conv_cost(const ConvArgs &a, int ks) {
+    const double px_in = (double)a.B * a.Hin * a.Win, px_out = (double)a.B * a.Hout * a.Wout;
+    return {1, 2.0 * px_out * a.Cout * a.Cin * ks * ks,
+            4.0 * (px_in * a.Cin + px_out * a.Cout * (a.res ? 2 : 1) + (double)ks * ks * a.Cin * a.Cout)};
+}
 
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
 static hipError_t launch_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
@@ -98,11 +103,11 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
         a.ppi = a.ppr * ((a.Hout + 3) / 4);
         a.chunks = a.Hout;
         if (resolved) *resolved = a;
-        prof_last = {1, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks};
+        prof_last = conv_cost(a, ks);
         return launch_conv_small(a, stride, st);
     }
     if (a.cfg == CFG_AUTO) a.cfg = conv_pick_cfg(a.Cout, a.CoutP, ks, stride, a.B, a.Hout, a.Wout);
-    prof_last = {1, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks};
+    prof_last = conv_cost(a, ks);
     if (ks == 3 && stride == 1) {
         return ck == 32 ? launch_shape<3, 1, 32>(a, st, resolved) : launch_shape<3, 1, 16>(a, st, resolved);
     } else if (ks == 3 && stride == 2) {

@@ -686,8 +686,9 @@ int mc_backward(mc_handle *h, const float *grad_losses, void *stream) {
     return 0;
 }
 
-int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], int launches[3], void *stream) {
-    if (!h || !ms || !flops || !launches) return -1;
+int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], double bytes[3], int launches[3],
+                     void *stream) {
+    if (!h || !ms || !flops || !bytes || !launches) return -1;
     TrainState *ts = h->train;
     if (!ts || !ts->img || !ts->grad_losses) return fail(h, "mc_profile_train: run mc_forward_train + mc_backward first");
     if (iters < 1) iters = 1;
@@ -697,13 +698,13 @@ int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], int
     std::vector<hipEvent_t> ev(2 * n);
     for (auto &e : ev) HIPCHK(h, hipEventCreate(&e));
     std::vector<ProfLast> tag(n);
-    for (int k = 0; k < 3; ++k) { ms[k] = 0; flops[k] = 0; launches[k] = 0; }
+    for (int k = 0; k < 3; ++k) { ms[k] = 0; flops[k] = 0; bytes[k] = 0; launches[k] = 0; }
     int rc = 0;
     for (int it = 0; it < iters && !rc; ++it) {
         size_t i = 0;
         for (auto *list : {&ts->fwd, &ts->bwd})
             for (auto &f : *list) {
-                prof_last = {0, 0.0};
+                prof_last = {0, 0.0, 0.0};
                 (void)hipEventRecord(ev[2 * i], st);
                 if (f(h, st)) { rc = -1; break; }
                 (void)hipEventRecord(ev[2 * i + 1], st);
@@ -714,11 +715,11 @@ int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], int
             float t = 0.f;
             (void)hipEventElapsedTime(&t, ev[2 * j], ev[2 * j + 1]);
             const int k = tag[j].kind;
-            ms[k] += t; flops[k] += tag[j].flops; launches[k] += 1;
+            ms[k] += t; flops[k] += tag[j].flops; bytes[k] += tag[j].bytes; launches[k] += 1;
         }
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    for (int k = 0; k < 3; ++k) { ms[k] /= iters; flops[k] /= iters; launches[k] /= iters; }
+    for (int k = 0; k < 3; ++k) { ms[k] /= iters; flops[k] /= iters; bytes[k] /= iters; launches[k] /= iters; }
     return rc;
 }
 

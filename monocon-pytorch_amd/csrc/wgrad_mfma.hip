@@ -351,7 +351,8 @@ void wgrad_plan(WgradArgs &a, int ks, int stride) {
 size_t wgrad_partial_floats(const WgradArgs &a, int ks) { return (size_t)a.ksplit * ks * ks * a.Cout * a.Cin; }
 
 hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st) {
-    prof_last = {2, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks};
+    prof_last = {2, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks,
+                 4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.B * a.Hout * a.Wout * a.Cout + (double)ks * ks * a.Cin * a.Cout)};
     hipError_t e = hipErrorInvalidValue;
     if (a.small) {
         if (stride == 1 && a.Cout == 16) hipLaunchKernelGGL((wgrad_small_kernel<1, 1>), dim3(a.ksplit), dim3(256), 0, st, a);

@@ -167,11 +167,12 @@ class Engine:
         """per kernel family durations of the last train step (after forward_train + backward)."""
         ms = (C.c_double * 3)()
         fl = (C.c_double * 3)()
+        by = (C.c_double * 3)()
         n = (C.c_int * 3)()
         with torch.cuda.device(self.device):
-            _lib.check(self.h, self.lib.mc_profile_train(self.h, iters, ms, fl, n, _stream()), "mc_profile_train")
+            _lib.check(self.h, self.lib.mc_profile_train(self.h, iters, ms, fl, by, n, _stream()), "mc_profile_train")
         names = ("other", "conv", "wgrad")
-        return {k: {"ms": ms[i], "flops": fl[i], "launches": n[i]} for i, k in enumerate(names)}
+        return {k: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": n[i]} for i, k in enumerate(names)}
 
     def workspace_bytes(self):
         return int(self.lib.mc_workspace_bytes(self.h))

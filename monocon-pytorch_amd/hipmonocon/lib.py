@@ -91,7 +91,7 @@ def load():
     lib.mc_forward_cost.argtypes = [vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mc_profile_forward.argtypes = [vp, i, fp, C.POINTER(i), vp]
     lib.mc_bench_mfma_peak.argtypes = [vp, i, i, fp]
-    lib.mc_profile_train.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i), vp]
+    lib.mc_profile_train.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i), vp]
     lib.mc_set_conv_cfg.argtypes = [vp, i]
     lib.mc_bench_conv.argtypes = [vp, i, i, i, i, C.POINTER(i), i, i, i, i, i, fp]
     for name in EXPORTS:

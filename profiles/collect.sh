@@ -9,7 +9,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+export MONOCON_HIP_TUNE_CACHE=/tmp/monocon_tune_cache.txt
+BENCH="timeout 600 python $ROOT/bench.py --steps 2 --warmup 1 --forward-steps 2 --no-cpu-baseline $*"
+$BENCH > "$OUT/bench_plain.log" 2>&1   # warms the tune cache so the traces hold no autotuning launches
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/pmc_sq" -o p -- $BENCH > "$OUT/pmc_sq.log" 2>&1

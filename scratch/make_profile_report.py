@@ -10,8 +10,9 @@ def short(n): return re.sub(r"\(.*", "", n).replace("void ", "")
 # ---- kernel trace stats (rocprofv3 --kernel-trace --stats)
 rows = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
 with open(os.path.join(dst, tag + "_kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (B=32, 384x1280, fp32)\n")
-    f.write("# (1 warm-up + 2 timed + 3 event-profiled forwards = 6 forwards in the trace)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --forward-steps 2 --no-cpu-baseline (B=32, 384x1280, fp32)\n")
+    f.write("# trace = 1 warm-up + 2 timed + 2 event-profiled train steps, then 3 warm-up + 2 timed + 3 event-profiled eval forwards\n")
+    f.write("# (plus the one-off plan-build autotuning launches unless MONOCON_HIP_TUNE_CACHE pointed at a warm cache)\n")
     f.write("%-70s %7s %14s %12s %7s\n" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
     for r in rows[:40]:
         f.write("%-70s %7s %14s %12.0f %7s\n" % (short(r["Name"])[:70], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]), r["Percentage"]))
@@ -53,6 +54,23 @@ with open(os.path.join(dst, tag + "_pmc.txt"), "w") as f:
         rd = 2.0 * fe[k]["FETCH_SIZE"] / max(len(cf[k]), 1) / 1024.0 if k in fe else float("nan")
         wrm = wr[k]["WRITE_SIZE"] / max(len(cw[k]), 1) / 1024.0 if k in wr else float("nan")
         f.write("%-46s %7d %5d %9.1f %9.2f %9.3f %10.1f %10.1f %9.0f\n" % (k[0][:46], k[1], n, us, gui / us / 1e3, busy, rd, wrm, (rd + wrm) / us * 1e3 if us else 0))
+# ---- per-launch HBM traffic of the kernel families (bench.py reports it as roofline.traffic)
+import json
+fam = collections.defaultdict(lambda: [0.0, 0.0, 0, 0.0])
+for k in sq:
+    f_ = re.sub(r"<.*", "", k[0])
+    if k in fe and k in wr:
+        n = min(len(cf[k]), len(cw[k]))
+        fam[f_][0] += 2.0 * fe[k]["FETCH_SIZE"] * 1024.0 / max(len(cf[k]), 1) * n
+        fam[f_][1] += wr[k]["WRITE_SIZE"] * 1024.0 / max(len(cw[k]), 1) * n
+        fam[f_][2] += n
+        fam[f_][3] += dur[k] / len(cnt[k]) * n
+json.dump({"source": "profiles/%s_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
+                     "MI355X_MICROARCH.md gfx950 note, WRITE_SIZE as reported)" % tag,
+           "families": {f_: {"hbm_read_bytes_per_launch": v[0] / v[2], "hbm_write_bytes_per_launch": v[1] / v[2],
+                             "launches_sampled": v[2], "avg_us_under_pmc": v[3] / v[2]}
+                        for f_, v in fam.items() if v[2] and f_.startswith("mc::")}},
+          open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
 for extra in ("conv_shapes.txt", "mfma_peak.txt"):
     p = os.path.join(src, extra)
     if os.path.exists(p):
