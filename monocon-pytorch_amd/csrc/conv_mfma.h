@@ -54,16 +54,27 @@ struct ConvArgs {
     const float *stat_shift; // [Cout] or null
     int ppr, ppi, chunks;    // patches per row / per image, workgroup chunks per image
     int cfg;                 // ConvCfgId workgroup shape (CFG_AUTO = conv_pick_cfg)
+    // output / residual pixel mapping in floats (0 = dense NHWC: img = Hout*Wout*ld, row = Wout*ld, px = ld);
+    // the stride-2 data-gradient classes scatter to every second pixel of a larger map
+    int o_img, o_row, o_px, r_img, r_row, r_px;
 };
+
+// Filter window code KS: 3 = 3x3 (pad 1), 1 = 1x1; 12 / 21 / 22 = 1x2, 2x1, 2x2 windows without padding --
+// the four output-parity classes of a stride-2 3x3 data gradient (dX[2i+py][2j+px] only sees the taps
+// of matching parity, see mc_train_plan.hip emit_dgrad), launched with a strided output mapping.
+constexpr int win_h(int ks) { return ks >= 10 ? ks / 10 : ks; }
+constexpr int win_w(int ks) { return ks >= 10 ? ks % 10 : ks; }
+constexpr int win_pad(int ks) { return ks == 3 ? 1 : 0; }
 
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
 struct ConvCfg {
     static constexpr int PB = WM * WTM;
     static constexpr int BNT = WN * WTN * 32;
     static constexpr int NT = 64 * WM * WN;
-    static constexpr int PAD = KS / 2;
-    static constexpr int IH = 3 * S + KS;
-    static constexpr int IW = 7 * S + KS;
+    static constexpr int KH = win_h(KS), KW = win_w(KS);
+    static constexpr int PAD = win_pad(KS);
+    static constexpr int IH = 3 * S + KH;
+    static constexpr int IW = 7 * S + KW;
     static constexpr int NPIX = IH * IW;
     static constexpr int CKP = CK + 4;
     static constexpr int LDS_FLOATS = PB * NPIX * CKP + PB * 4 + 2 * WM * BNT;
@@ -100,11 +111,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
     const bool do_stats = a.stats != nullptr;
     const bool has_res = a.res != nullptr;
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
-    const __amdgpu_buffer_rsrc_t r_out =
-        make_rsrc(a.out + (size_t)img * a.Hout * a.Wout * a.out_ld, (unsigned)(a.Hout * a.Wout * a.out_ld) * 4u);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (size_t)img * a.o_img, (unsigned)a.o_img * 4u);
     const __amdgpu_buffer_rsrc_t r_res =
-        make_rsrc(has_res ? a.res + (size_t)img * a.Hout * a.Wout * a.res_ld : a.out,
-                  has_res ? (unsigned)(a.Hout * a.Wout * a.res_ld) * 4u : 0u);
+        make_rsrc(has_res ? a.res + (size_t)img * a.r_img : a.out, has_res ? (unsigned)a.r_img * 4u : 0u);
     float ssum[WTN], ssq[WTN];
 #pragma unroll
     for (int tn = 0; tn < WTN; ++tn) ssum[tn] = ssq[tn] = 0.f;
@@ -115,8 +124,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
         const float sc = (a.scale && nok) ? a.scale[n] : 1.f;
         const float bi = (a.bias && nok) ? a.bias[n] : 0.f;
         const float sh = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
-        const int v_out = nok ? (4 * g * a.out_ld + a.out_coff + n) * 4 : BUF_OOB;
-        const int v_res = nok ? (4 * g * a.res_ld + n) * 4 : BUF_OOB;
+        const int v_out = nok ? (4 * g * a.o_px + a.out_coff + n) * 4 : BUF_OOB;
+        const int v_res = nok ? (4 * g * a.r_px + n) * 4 : BUF_OOB;
 #pragma unroll
         for (int tm = 0; tm < WTM; ++tm) {
             const int p = wm * WTM + tm;
@@ -126,13 +135,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
             if (!pv) continue;
             if (oy0 + 4 <= a.Hout && ox0 + 8 <= a.Wout) {
                 // whole patch inside the image: wave-uniform offsets only
-                const int s_out = (oy0 * a.Wout + ox0) * a.out_ld * 4;
-                const int s_res = (oy0 * a.Wout + ox0) * a.res_ld * 4;
+                const int s_out = (oy0 * a.o_row + ox0 * a.o_px) * 4;
+                const int s_res = (oy0 * a.r_row + ox0 * a.r_px) * 4;
                 float rv[16];
                 if (has_res) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        rv[r] = buf_load1(r_res, v_res, s_res + ((r >> 2) * a.Wout + (r & 3)) * a.res_ld * 4);
+                        rv[r] = buf_load1(r_res, v_res, s_res + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -144,21 +153,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         ssq[tn] += d * d;
                     }
                     v = fmaxf(v, floor_v);
-                    buf_store1(v, r_out, v_out, s_out + ((r >> 2) * a.Wout + (r & 3)) * a.out_ld * 4);
+                    buf_store1(v, r_out, v_out, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int y = oy0 + (r >> 2), x = ox0 + (r & 3) + 4 * g;
                     if (nok && y < a.Hout && x < a.Wout) {
-                        const int pixel = y * a.Wout + x;
                         float v = acc[tm][tn][r] * sc + bi;
-                        if (has_res) v += buf_load1(r_res, (pixel * a.res_ld + n) * 4, 0);
+                        if (has_res) v += buf_load1(r_res, (y * a.r_row + x * a.r_px + n) * 4, 0);
                         const float d = v - sh;
                         ssum[tn] += d;
                         ssq[tn] += d * d;
                         v = fmaxf(v, floor_v);
-                        buf_store1(v, r_out, (pixel * a.out_ld + a.out_coff + n) * 4, 0);
+                        buf_store1(v, r_out, (y * a.o_row + x * a.o_px + a.out_coff + n) * 4, 0);
                     }
                 }
             }
@@ -237,11 +245,11 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvAr
         a_off[tm] = ((wm * WTM + tm) * NPIX + ((li >> 3) * S) * IW + (li & 7) * S) * CKP + 4 * g;
 
     const int Cin4 = a.Cin >> 2;
-    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk, (unsigned)(KS * KS * a.Cin * a.CoutP) * 4u);
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk, (unsigned)(Cfg::KH * Cfg::KW * a.Cin * a.CoutP) * 4u);
     const int w_lane = (g * a.CoutP + n0 + wn * WTN * 32 + li) * 16;   // bytes
 
     // B fragment of step s (= tap * CK/8 + k8) of the K-chunk starting at concat channel kc
-    constexpr int K8 = CK / 8, NS = KS * KS * K8;
+    constexpr int K8 = CK / 8, NS = Cfg::KH * Cfg::KW * K8;
     auto load_b = [&](f32x4(&dst)[WTN], int kc, int s) {
         const int tap = s / K8, k8 = s % K8;
         const int soff = (tap * Cin4 + ((kc + k8 * 8) >> 2)) * a.CoutP * 16;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvAr
 #pragma unroll
         for (int tm = 0; tm < WTM; ++tm)
             dst[tm] = *reinterpret_cast<const f32x4 *>(
-                &lds[a_off[tm] + ((tap / KS) * IW + (tap % KS)) * CKP + k8 * 8]);
+                &lds[a_off[tm] + ((tap / Cfg::KW) * IW + (tap % Cfg::KW)) * CKP + k8 * 8]);
     };
     f32x4 bcur[WTN];
     load_b(bcur, 0, 0);   // weights do not depend on the staged tile: in flight across the barriers
@@ -455,10 +463,10 @@ __global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(con
             a_off[tm] = ((wm * WTM + tm) * NPIX + ((li >> 3) * S) * IW + (li & 7) * S) * CKP + 4 * g;
 
         const int Cin4 = a.Cin >> 2;
-        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk, (unsigned)(KS * KS * a.Cin * a.CoutP) * 4u);
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk, (unsigned)(Cfg::KH * Cfg::KW * a.Cin * a.CoutP) * 4u);
         const int w_lane = (g * a.CoutP + n0 + wn * WTN * 32 + li) * 16;   // bytes
 
-        constexpr int K8 = CK / 8, NS = KS * KS * K8;
+        constexpr int K8 = CK / 8, NS = Cfg::KH * Cfg::KW * K8;
         auto load_b = [&](f32x4(&dst)[WTN], int kc, int s) {
             const int tap = s / K8, k8 = s % K8;
             const int soff = (tap * Cin4 + ((kc + k8 * 8) >> 2)) * a.CoutP * 16;
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(con
 #pragma unroll
                 for (int tm = 0; tm < WTM; ++tm)
                     dst[tm] = *reinterpret_cast<const f32x4 *>(
-                        &tile[a_off[tm] + ((tap / KS) * IW + (tap % KS)) * CKP + k8 * 8]);
+                        &tile[a_off[tm] + ((tap / Cfg::KW) * IW + (tap % Cfg::KW)) * CKP + k8 * 8]);
             };
             const int kc = ci * CK;
             const int kc_next = (ci + 1 < nch) ? kc + CK : kc;

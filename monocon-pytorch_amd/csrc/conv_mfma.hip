@@ -6,8 +6,9 @@ namespace mc {
 thread_local ProfLast prof_last = {0, 0.0, 0.0};
 static ProfLast conv_cost(const ConvArgs &a, int ks) {
     const double px_in = (double)a.B * a.Hin * a.Win, px_out = (double)a.B * a.Hout * a.Wout;
-    return {1, 2.0 * px_out * a.Cout * a.Cin * ks * ks,
-            4.0 * (px_in * a.Cin + px_out * a.Cout * (a.res ? 2 : 1) + (double)ks * ks * a.Cin * a.Cout)};
+    const double taps = win_h(ks) * win_w(ks);
+    return {1, 2.0 * px_out * a.Cout * a.Cin * taps,
+            4.0 * (px_in * a.Cin + px_out * a.Cout * (a.res ? 2 : 1) + taps * a.Cin * a.Cout)};
 }
 
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
@@ -57,7 +58,7 @@ static hipError_t launch_one_ws(ConvArgs a, hipStream_t st, ConvArgs *resolved) 
 
 template <int KS, int S, int CK>
 static hipError_t launch_shape(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
-    if (a.cfg & CFG_WS) {
+    if constexpr (KS == 3 || KS == 1) if (a.cfg & CFG_WS) {
         switch (a.cfg & ~CFG_WS) {
             case CFG_128x128: return launch_one_ws<KS, S, CK, 2, 2, 2, 2>(a, st, resolved);
             case CFG_128x64: return launch_one_ws<KS, S, CK, 2, 2, 2, 1>(a, st, resolved);
@@ -92,6 +93,10 @@ int conv_pick_cfg(int Cout, int CoutP, int ks, int stride, int B, int Hout, int 
 
 hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
     ConvArgs a = a_in;
+    const bool dense_out = a.o_px == 0;
+    if (dense_out) { a.o_px = a.out_ld; a.o_row = a.Wout * a.out_ld; a.o_img = a.Hout * a.Wout * a.out_ld; }
+    if (a.r_px == 0) { a.r_px = a.res_ld; a.r_row = a.Wout * a.res_ld; a.r_img = a.Hout * a.Wout * a.res_ld; }
+    if (a.cfg == CFG_SMALL && !dense_out) return hipErrorInvalidValue;
     int sc[4];
     for (int i = 0; i < a.nsrc; ++i) sc[i] = a.src[i].C;
     const int ck = conv_ck(ks, stride, sc, a.nsrc);
@@ -114,6 +119,11 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
         return launch_shape<3, 2, 16>(a, st, resolved);
     } else if (ks == 1 && stride == 1) {
         return ck == 32 ? launch_shape<1, 1, 32>(a, st, resolved) : launch_shape<1, 1, 16>(a, st, resolved);
+    } else if (stride == 1 && (ks == 12 || ks == 21 || ks == 22)) {   // stride-2 data-gradient parity classes
+        if (a.cfg & CFG_WS) a.cfg &= ~CFG_WS;
+        if (ks == 12) return ck == 32 ? launch_shape<12, 1, 32>(a, st, resolved) : launch_shape<12, 1, 16>(a, st, resolved);
+        if (ks == 21) return ck == 32 ? launch_shape<21, 1, 32>(a, st, resolved) : launch_shape<21, 1, 16>(a, st, resolved);
+        return ck == 32 ? launch_shape<22, 1, 32>(a, st, resolved) : launch_shape<22, 1, 16>(a, st, resolved);
     }
     return hipErrorInvalidValue;
 }

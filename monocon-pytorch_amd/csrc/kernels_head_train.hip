@@ -20,27 +20,38 @@ namespace mc {
 // forward W (Cout, CinTotal, k, k) -> panel of the transposed / flipped convolution that maps
 // dY (Cout channels) to dX of ONE source (channels [c_off, c_off + Cs)):
 //   dst[tap'][n/4][c_local (padded to CsP)][n%4] = W[n][c_off + c_local][k-1-r'][k-1-s']
+// cls < 0: the stride-1 case above.  cls = 2*py + px: output-parity class of a stride-2 3x3 data gradient,
+//   dX[2i+py][2j+px] = sum_{dr<KH, ds<KW} dY[i+dr][j+ds] . W[.][.][r(dr)][s(ds)],   KH = 1 + py, KW = 1 + px,
+//   r(dr) = 1 (py = 0) or 2 - 2*dr (py = 1), same for s: the panel keeps only those KH*KW taps, window order.
 __global__ void pack_conv_w_dgrad_kernel(const float *__restrict__ w, int Cout, int CinTotal, int k, int c_off, int Cs,
-                                         int CsP, int CoutPad, float *__restrict__ dst) {
+                                         int CsP, int CoutPad, int cls, float *__restrict__ dst) {
     const int kk = k * k;
     const size_t total = (size_t)Cout * Cs * kk;
+    const int py = cls >> 1, px = cls & 1;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int tap = e % kk;
         const int cl = (e / kk) % Cs;
         const int n = e / ((size_t)kk * Cs);
         const int r = tap / k, s = tap % k;
-        const int tapd = (k - 1 - r) * k + (k - 1 - s);
+        int tapd;
+        if (cls < 0) {
+            tapd = (k - 1 - r) * k + (k - 1 - s);
+        } else {
+            if ((py == 0) != (r == 1) || (px == 0) != (s == 1)) continue;   // tap of the other parity
+            const int dr = py ? (2 - r) / 2 : 0, ds = px ? (2 - s) / 2 : 0;
+            tapd = dr * (1 + px) + ds;
+        }
         dst[(((size_t)tapd * (CoutPad >> 2) + (n >> 2)) * CsP + cl) * 4 + (n & 3)] =
             w[(((size_t)n * CinTotal + c_off + cl) * k + r) * k + s];
     }
 }
 hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
-                                    float *dst, hipStream_t st) {
+                                    int cls, float *dst, hipStream_t st) {
     const size_t total = (size_t)Cout * Cs * k * k;
     size_t g = (total + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_conv_w_dgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, w, Cout, CinTotal, k, c_off, Cs, CsP,
-                       CoutPad, dst);
+                       CoutPad, cls, dst);
     return hipGetLastError();
 }
 

@@ -284,6 +284,7 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     float best_ms = 1e30f;
     for (int c : cand) {
         if (c == CFG_SMALL ? !small_ok : (a.CoutP % conv_shape(c).BNT()) != 0) continue;
+        if ((c & CFG_WS) && ks >= 10) continue;   // the parity-class windows have no wave-specialised build
         a.cfg = c;
         if (launch_conv(a, ks, stride, nullptr) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm / unsupported
         float t_min = 1e30f;

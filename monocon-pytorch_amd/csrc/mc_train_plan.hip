@@ -26,6 +26,7 @@ struct TNode {
 struct PackJob {           // dgrad panel refreshed from the master weights before every forward
     const float *w;
     int Cout, CinTotal, k, c_off, Cs, CsP, CoutPad;
+    int cls;           // -1: stride-1 panel; 0..3: output-parity class of a stride-2 data gradient
     float *dst;
 };
 
@@ -230,11 +231,13 @@ struct TB {   // train plan builder
     }
 
     // ---------------------------------------------------------------- backward pieces
-    void pack_job(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CoutPad, float **dst_out, int *csp_out) {
+    void pack_job(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CoutPad, float **dst_out, int *csp_out,
+                  int cls = -1) {
         PackJob j;
         j.w = w; j.Cout = Cout; j.CinTotal = CinTotal; j.k = k; j.c_off = c_off; j.Cs = Cs;
-        j.CsP = conv_coutp(Cs); j.CoutPad = CoutPad;
-        j.dst = alloc((size_t)k * k * CoutPad * j.CsP);
+        j.CsP = conv_coutp(Cs); j.CoutPad = CoutPad; j.cls = cls;
+        const int taps = cls < 0 ? k * k : (1 + (cls >> 1)) * (1 + (cls & 1));
+        j.dst = alloc((size_t)taps * CoutPad * j.CsP);
         ts->packs.push_back(j);
         *dst_out = j.dst;
         *csp_out = j.CsP;
@@ -245,18 +248,37 @@ struct TB {   // train plan builder
                     int CoutPad) {
         TNode &sn = ts->nodes[srcnode];
         if (!sn.needs_grad) return;
+        if (stride == 2 && ks == 3) {
+            // four output-parity classes, each a small stride-1 window conv over dY that scatters to every
+            // second pixel of g_src (no zero-dilated copy of dY, 9 instead of 36 tap-MACs per output quad)
+            if (2 * dy.H != sn.t.H || 2 * dy.W != sn.t.W) { ts->ok = false; h->err = "train plan: stride-2 dgrad shape mismatch"; }
+            for (int cls = 0; cls < 4; ++cls) {
+                const int py = cls >> 1, px = cls & 1;
+                float *panel;
+                int csp;
+                pack_job(w_master, Cout_fwd, CinTotal, ks, c_off, sn.t.C, CoutPad, &panel, &csp, cls);
+                ConvArgs d{};
+                d.nsrc = 1;
+                d.src[0].p = dy.p; d.src[0].C = dy.C;
+                d.B = dy.B; d.Hin = dy.H; d.Win = dy.W; d.Hout = dy.H; d.Wout = dy.W;
+                d.Cin = dy.C; d.Cout = sn.t.C; d.CoutP = csp; d.wpk = panel;
+                const int ld = sn.t.C;
+                d.out = sn.g + ((size_t)py * sn.t.W + px) * ld; d.out_ld = ld;
+                d.o_px = 2 * ld; d.o_row = 2 * sn.t.W * ld; d.o_img = sn.t.H * sn.t.W * ld;
+                if (sn.ginit) { d.res = d.out; d.res_ld = ld; d.r_px = d.o_px; d.r_row = d.o_row; d.r_img = d.o_img; }
+                const int kcode = (1 + py) * 10 + (1 + px);
+                const int kk = kcode == 11 ? 1 : kcode;
+                d.cfg = ts->ok ? mc_choose_conv_cfg(h, d, kk, 1) : CFG_128x32;
+                ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(d, kk, 1, st)); return 0; });
+            }
+            sn.ginit = true;
+            return;
+        }
         float *panel;
         int csp;
         pack_job(w_master, Cout_fwd, CinTotal, ks, c_off, sn.t.C, CoutPad, &panel, &csp);
         const float *dyp = dy.p;
         int Hd = dy.H, Wd = dy.W;
-        if (stride == 2) {
-            float *dil = alloc((size_t)dy.B * 4 * dy.H * dy.W * dy.C);
-            const float *in = dy.p;
-            const int B = dy.B, H = dy.H, W = dy.W, C = dy.C;
-            ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_dilate2(in, B, H, W, C, dil, st)); return 0; });
-            dyp = dil; Hd = 2 * dy.H; Wd = 2 * dy.W;
-        }
         ConvArgs d{};
         d.nsrc = 1;
         d.src[0].p = dyp; d.src[0].C = dy.C;
@@ -652,7 +674,7 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
     for (auto &f : ts->pack_fns)       // dense head weight copies first: some dgrad panels are cut from them
         if (f(h, st)) return -1;
     for (const PackJob &j : ts->packs)
-        HIPCHK(h, launch_pack_conv_w_dgrad(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.dst, st));
+        HIPCHK(h, launch_pack_conv_w_dgrad(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls, j.dst, st));
     for (auto &f : ts->fwd)
         if (f(h, st)) return -1;
     return 0;
