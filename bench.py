@@ -16,8 +16,8 @@ timing is barrier + synchronize bracketed and the MAX over ranks is reported.
 Rank 0 prints ONE JSON line: the throughput, `roofline` of the dominant kernel family of the step
 (conv_mfma_kernel: forward convolutions + data gradients on the fp32 MFMA pipe, timed live with HIP
 events around every launch on the launch stream), `forward_only` (BASELINE configs[1]: eval forward
-at B=32 with its own conv roofline) and `cpu_baseline` (the oracle's CPU restatement of the same
-forward, timed on the host cores on a bounded sample).
+at B=32 with its own conv roofline), `decode_only` (configs[4]: B=64, top-k 100) and `cpu_baseline`
+(the oracle's CPU restatement of the same train step, timed on the host cores on a bounded B=2 sample).
 """
 import argparse
 import json
@@ -53,37 +53,50 @@ def parse():
 
 
 def cpu_baseline(sd, height, width, budget_s):
-    """The oracle (CPU restatement of the reference forward, equality with the reference pinned
-    by tests/golden) timed on this box's host cores: eval forward at B=2, 384x1280."""
+    """The oracle (CPU restatement of the reference, equality with the reference pinned by
+    tests/golden) timed on this box's host cores on a bounded sample of the SAME workload: full train
+    steps (train-mode forward, targets, losses, autograd backward, clip + AdamW) at B=2, 384x1280."""
     from oracle import monocon_oracle as O
     from hipmonocon import synth
-    img = synth.make_batch(3, 2, height, width, with_labels=False)["img"]
+    batch = synth.make_batch(3, 2, height, width)
+    names = [k for k, v in sd.items() if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))]
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    with torch.no_grad():
-        # pick the fastest intra-op thread count the box actually sustains (a container may
-        # expose far more logical CPUs than it is allowed to run; oversubscribing MKLDNN is
-        # orders of magnitude slower), then time at that setting
-        best = None
-        for nt in sorted({n for n in (8, 16, 32, 64, avail) if n <= avail}):
-            torch.set_num_threads(nt)
-            t0 = time.perf_counter()
-            O.forward(sd, img)                   # doubles as warm-up
-            dt = time.perf_counter() - t0
-            if best is None or dt < best[1]:
-                best = (nt, dt)
-            if dt > budget_s:                    # already hopeless at this count; larger is worse
-                break
-        torch.set_num_threads(best[0])
-        times = []
-        t_end = time.perf_counter() + budget_s
-        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
-            t0 = time.perf_counter()
-            O.forward(sd, img)
-            times.append(time.perf_counter() - t0)
+
+    def one_step(state):
+        live = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in state.items()}
+        _, _, L, _ = O.train_forward(live, batch)
+        sum(L.values()).backward()
+        ps = [live[k] for k in names if live[k].grad is not None]
+        gs = [p.grad for p in ps]
+        ms = [torch.zeros_like(p) for p in ps]
+        vs = [torch.zeros_like(p) for p in ps]
+        with torch.no_grad():
+            O.clip_and_adamw([p.detach() for p in ps], gs, ms, vs, 1, 2.25e-4, 0.95)
+
+    # pick the fastest intra-op thread count the box actually sustains (a container may expose far
+    # more logical CPUs than it is allowed to run; oversubscribing MKLDNN is orders of magnitude
+    # slower), then time at that setting
+    best = None
+    for nt in sorted({n for n in (8, 16, 32, 64, avail) if n <= avail}):
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        one_step(sd)                         # doubles as warm-up
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+        if dt > budget_s:                    # already hopeless at this count; larger is worse
+            break
+    torch.set_num_threads(best[0])
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
+        t0 = time.perf_counter()
+        one_step(sd)
+        times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     return {"value": round(2 / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle eval forward only (no backward), B=2 x 3x%dx%d fp32, median of %d runs (%.3f s/run)"
-                      % (height, width, len(times), med)}
+            "sample": "oracle full train step (fwd + targets + losses + autograd bwd + clip + AdamW), B=2 x 3x%dx%d fp32, "
+                      "median of %d runs (%.3f s/run)" % (height, width, len(times), med)}
 
 
 def main():
@@ -204,6 +217,26 @@ def main():
         traffic_src = tj["source"]
     except Exception:
         pass
+    # ---------------------------------------------------------------- decode only (configs[4])
+    dec = None
+    if args.forward_steps > 0 and rank == 0:
+        K, DB = 100, 64
+        from hipmonocon.engine import p2_inverse
+        dpred = {k: torch.from_numpy(v).cuda() for k, v in synth.make_decode_inputs(77, DB, H // 4, W // 4, topk=K).items()}
+        P2np = np.stack([synth.KITTI_P2] * DB)
+        P2, P2inv = torch.from_numpy(P2np).cuda(), torch.from_numpy(p2_inverse(P2np)).cuda()
+        for _ in range(3):
+            eng.decode(dpred, P2, P2inv, (H, W), K, 0.4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.decode(dpred, P2, P2inv, (H, W), K, 0.4)
+        torch.cuda.synchronize()
+        dms = (time.perf_counter() - t0) / 20 * 1e3
+        dec = {"workload": "BASELINE configs[4]: decode of the ten maps, batch=%d, top-k=%d (local max + exact top-K + box "
+                           "assembly; indices / keep masks bit-exact vs the oracle in tests/test_hip_decode.py)" % (DB, K),
+               "images_per_sec": round(DB / (dms * 1e-3), 1), "ms_per_batch": round(dms, 3)}
+
     if rank == 0:
         conv, wg, oth = prof["conv"], prof["wgrad"], prof["other"]
         conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
@@ -241,6 +274,8 @@ def main():
         }
         if fwd is not None:
             out["forward_only"] = fwd
+        if dec is not None:
+            out["decode_only"] = dec
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, H, W, args.cpu_seconds)
         print(json.dumps(out), flush=True)

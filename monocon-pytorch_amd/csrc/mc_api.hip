@@ -946,7 +946,7 @@ int mc_set_conv_cfg(mc_handle *h, int cfg) {
 // ---------------------------------------------------------------------------- introspection
 size_t mc_workspace_bytes(mc_handle *h) {
     if (!h) return 0;
-    size_t n = h->param_bytes + h->decode_filt_n * sizeof(float);
+    size_t n = h->param_bytes + h->decode_filt_n * sizeof(float) + h->train_bytes;
     for (auto &kv : h->plans) n += kv.second->bytes;
     return n;
 }

@@ -106,6 +106,7 @@ struct mc_handle {
     float *opt_ws = nullptr;    // partials + [norm, coef]
     // train-step plan (mc_train_plan.hip)
     TrainState *train = nullptr;
+    size_t train_bytes = 0;   // device memory owned by the train plan
     void (*train_free)(TrainState *) = nullptr;
     unsigned long long bind_gen = 0;
     bool pack_clean = false;   // packed panels match the bound parameters (cleared by bind / optimizer step)

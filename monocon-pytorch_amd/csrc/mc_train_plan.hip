@@ -658,10 +658,12 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
         if (ts && h->train_free) h->train_free(ts);
         h->train = nullptr;
         h->tgt_arena = h->dp_arena = nullptr;
+        h->train_bytes = 0;
         h->tgt_arena_bytes = h->dp_arena_bytes = 0;
         ts = build_train(h, B, H, W);
         if (!ts) return -1;
         h->train = ts;
+        h->train_bytes = ts->bytes;
         h->train_free = train_free;
     }
     ts->img = img; ts->labels = *labels; ts->losses = losses; ts->pad_h = H; ts->pad_w = W; ts->max_objs = max_objs;
