@@ -22,7 +22,8 @@ constexpr int RED_ROWS = 256;
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restrict__ y, const float *__restrict__ dz,
                                                           const float *__restrict__ z, const float *__restrict__ shift,
                                                           int rows_per_img, int C, int mode, int relu,
-                                                          float *__restrict__ partial, int Cstride) {
+                                                          float *__restrict__ partial, int Cstride,
+                                                          const float *__restrict__ fa, const float *__restrict__ fb) {
     const int C4 = C >> 2;
     const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
     const int tid = threadIdx.x;
@@ -34,6 +35,10 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
     const bool active = tid < C4 * RG;
     f32x4 sh = {0.f, 0.f, 0.f, 0.f};
     if (active && mode == 0 && shift) sh = *reinterpret_cast<const f32x4 *>(shift + c4 * 4);
+    // relu == 2: the ReLU mask is recomputed from y with the forward coefficients (z = max(fma(y,a,b),0),
+    // no residual) instead of reading z -- one pass less over the activation
+    f32x4 ma = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};
+    if (active && relu == 2) { ma = *reinterpret_cast<const f32x4 *>(fa + c4 * 4); mb = *reinterpret_cast<const f32x4 *>(fb + c4 * 4); }
     if (active) {
         auto one = [&](const f32x4 yv, f32x4 d, const f32x4 zv) {
             if (mode == 0) {
@@ -42,7 +47,8 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (relu) d[j] = zv[j] > 0.f ? d[j] : 0.f;
+                    if (relu == 1) d[j] = zv[j] > 0.f ? d[j] : 0.f;
+                    else if (relu == 2) d[j] = fmaf(yv[j], ma[j], mb[j]) > 0.f ? d[j] : 0.f;
                     s1[j] += d[j]; s2[j] += d[j] * yv[j];
                 }
             }
@@ -60,17 +66,17 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
             if (mode != 0) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) dv[u] = d4[e + u * step];
-                if (relu) {
+                if (relu == 1) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) zv[u] = z4[e + u * step];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) one(yv[u], mode != 0 ? dv[u] : zero, (mode != 0 && relu) ? zv[u] : zero);
+            for (int u = 0; u < 4; ++u) one(yv[u], mode != 0 ? dv[u] : zero, (mode != 0 && relu == 1) ? zv[u] : zero);
         }
         for (; r < r1; r += RG) {
             const unsigned e = base + (unsigned)r * C4;
-            one(y4[e], mode != 0 ? d4[e] : zero, (mode != 0 && relu) ? z4[e] : zero);
+            one(y4[e], mode != 0 ? d4[e] : zero, (mode != 0 && relu == 1) ? z4[e] : zero);
         }
     }
     __shared__ float red[256 * 8];
@@ -89,10 +95,12 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
 }
 int chan_reduce_blocks(int B, int rows_per_img) { return B * ((rows_per_img + RED_ROWS - 1) / RED_ROWS); }
 hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, const float *shift, int B, int rows_per_img,
-                              int C, int mode, int relu, float *partial, int Cstride, hipStream_t st) {
-    if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
+                              int C, int mode, int relu, float *partial, int Cstride, hipStream_t st, const float *fa,
+                              const float *fb) {
+    if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
+    if (relu == 2 && (!fa || !fb)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(chan_reduce_kernel, dim3(chan_reduce_blocks(B, rows_per_img)), dim3(256), 0, st, y, dz, z, shift,
-                       rows_per_img, C, mode, relu, partial, Cstride);
+                       rows_per_img, C, mode, relu, partial, Cstride, fa, fb);
     return hipGetLastError();
 }
 
@@ -263,7 +271,8 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
                                                          const f32x4 *__restrict__ y, const float *__restrict__ coef,
                                                          int C4, int RG, int rows_per_img, int blocks_per_img,
                                                          int rows_per_block, int per_sample, int relu,
-                                                         f32x4 *__restrict__ dy, f32x4 *__restrict__ gres, int gres_mode) {
+                                                         f32x4 *__restrict__ dy, f32x4 *__restrict__ gres, int gres_mode,
+                                                         const float *__restrict__ fa, const float *__restrict__ fb) {
     const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
     const int b = blockIdx.x / blocks_per_img, rb = blockIdx.x % blocks_per_img;
     const int r0 = rb * rows_per_block, r1 = min(rows_per_img, r0 + rows_per_block);
@@ -274,13 +283,16 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
         const f32x4 cf = reinterpret_cast<const f32x4 *>(coef)[ci + j];
         cp[j] = cf[0]; cq[j] = cf[1]; cr[j] = cf[2];
     }
+    f32x4 ma = {0.f, 0.f, 0.f, 0.f}, mb = {0.f, 0.f, 0.f, 0.f};   // relu == 2: mask from y (see chan_reduce_kernel)
+    if (relu == 2) { ma = reinterpret_cast<const f32x4 *>(fa)[c4]; mb = reinterpret_cast<const f32x4 *>(fb)[c4]; }
     const unsigned base = ((unsigned)b * rows_per_img) * C4 + c4;
     const unsigned step = (unsigned)RG * C4;
     auto one = [&](unsigned e, f32x4 d, const f32x4 zv, const f32x4 yv) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (relu) d[j] = zv[j] > 0.f ? d[j] : 0.f;
+            if (relu == 1) d[j] = zv[j] > 0.f ? d[j] : 0.f;
+            else if (relu == 2) d[j] = fmaf(yv[j], ma[j], mb[j]) > 0.f ? d[j] : 0.f;
             o[j] = fmaf(cp[j], d[j], fmaf(cq[j], yv[j], cr[j]));
         }
         dy[e] = o;
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
         f32x4 d[4], zv[4], yv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { d[u] = dz[e + u * step]; yv[u] = y[e + u * step]; }
-        if (relu) {
+        if (relu == 1) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) zv[u] = z[e + u * step];
         }
@@ -308,19 +320,21 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
     for (; r < r1; r += RG) {
         const unsigned e = base + (unsigned)r * C4;
         f32x4 zv = {1.f, 1.f, 1.f, 1.f};
-        if (relu) zv = z[e];
+        if (relu == 1) zv = z[e];
         one(e, dz[e], zv, y[e]);
     }
 }
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
-                             int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st) {
+                             int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st,
+                             const float *fa, const float *fb) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
+    if (relu == 2 && (!fa || !fb || per_sample)) return hipErrorInvalidValue;
     const RowSplit rs = row_split(B, rows_per_img, C / 4);
     hipLaunchKernelGGL(affine_bwd_kernel, dim3(B * rs.blocks_per_img), dim3(rs.threads), 0, st,
                        reinterpret_cast<const f32x4 *>(dz), reinterpret_cast<const f32x4 *>(z),
                        reinterpret_cast<const f32x4 *>(y), coef, C / 4, rs.rg, (int)rows_per_img, rs.blocks_per_img,
                        rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(dy), reinterpret_cast<f32x4 *>(gres),
-                       gres_mode);
+                       gres_mode, fa, fb);
     return hipGetLastError();
 }
 

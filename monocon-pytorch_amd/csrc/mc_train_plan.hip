@@ -40,6 +40,7 @@ struct Rec {
     bool relu = true, dead = false;
     Tensor y;
     float *mean = nullptr, *rstd = nullptr;
+    float *ca = nullptr, *cb = nullptr;   // forward BN coefficients z = act(ca*y + cb (+ res))
     std::string bn;
 };
 
@@ -158,6 +159,7 @@ struct TB {   // train plan builder
         const int ks = Lr.ks, stride = Lr.stride;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(a, ks, stride, st)); return 0; });
         float *ca = alloc(Lr.cout), *cb = alloc(Lr.cout);
+        r.ca = ca; r.cb = cb;
         r.mean = alloc(Lr.cout); r.rstd = alloc(Lr.cout);
         bn_train_ops(r.y, stats, B * chunks, Lr.coutp, Lr.bn, 1e-5f, 0.1f, ca, cb, r.mean, r.rstd);
         if (!dead) {
@@ -319,7 +321,9 @@ struct TB {   // train plan builder
         float *partial = alloc((size_t)nb * C * 2), *coef = alloc((size_t)C * 4);
         const float *yp = r.y.p, *gz = zn.g, *zp = zn.t.p, *gamma = P(bn + ".weight"), *mean = r.mean, *rstd = r.rstd;
         float *dg = G(bn + ".weight"), *db = G(bn + ".bias"), *dyp = dy.p;
-        const int relu = r.relu;
+        // ReLU without residual: the mask is recomputed from y (bit-identical to z > 0), z is not read
+        const int relu = r.relu ? ((r.res < 0 && r.ca && r.cb) ? 2 : 1) : 0;
+        const float *fa = r.ca, *fb = r.cb;
         float *gres = nullptr;
         int gmode = 0;
         if (r.res >= 0 && ts->nodes[r.res].needs_grad) {
@@ -329,9 +333,9 @@ struct TB {   // train plan builder
         }
         const double n = (double)B * rows;
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_chan_reduce(yp, gz, zp, nullptr, B, rows, C, 1, relu, partial, C, st));
+            HIPCHK(hh, launch_chan_reduce(yp, gz, zp, nullptr, B, rows, C, 1, relu, partial, C, st, fa, fb));
             HIPCHK(hh, launch_bn_bwd_finalize(partial, nb, C, n, C, gamma, mean, rstd, dg, db, coef, st));
-            HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, relu, dyp, gres, gmode, st));
+            HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, relu, dyp, gres, gmode, st, fa, fb));
             return 0;
         });
         return dy;

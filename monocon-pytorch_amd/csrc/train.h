@@ -53,7 +53,8 @@ int opt_partial_floats();
 // ---- train-mode element-wise / reduction kernels (kernels_train.hip)
 int chan_reduce_blocks(int B, int rows_per_img);
 hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, const float *shift, int B, int rows_per_img,
-                              int C, int mode, int relu, float *partial, int Cstride, hipStream_t st);
+                              int C, int mode, int relu, float *partial, int Cstride, hipStream_t st, const float *fa = nullptr,
+                              const float *fb = nullptr);
 hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
                               const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
                               long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st);
@@ -63,7 +64,8 @@ hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, dou
                                   const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
                                   hipStream_t st);
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
-                             int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st);
+                             int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st,
+                             const float *fa = nullptr, const float *fb = nullptr);
 hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st);
 size_t colsum_partial_floats(size_t rows, int ld);
 hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st);
