@@ -54,6 +54,13 @@ struct TrainState {
     std::vector<TNode> nodes;
     std::vector<Rec> recs;
     std::vector<Fn> fwd, bwd;
+    // backward closures that only produce weight gradients (nothing downstream in the step reads them) run
+    // on a second stream: MFMA-bound wgrad overlaps the HBM-bound BN passes and the tails of the dgrad chain
+    std::vector<char> bwd_side;
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> side_ev;
+    hipEvent_t side_done = nullptr;
+    bool dual = true;
     std::vector<PackJob> packs;
     std::vector<Fn> pack_fns;
     // per-call external pointers
@@ -71,6 +78,9 @@ struct TrainState {
 
 static void train_free(TrainState *t) {
     if (!t) return;
+    for (hipEvent_t e : t->side_ev) (void)hipEventDestroy(e);
+    if (t->side_done) (void)hipEventDestroy(t->side_done);
+    if (t->side) (void)hipStreamDestroy(t->side);
     for (void *q : t->bufs) (void)hipFree(q);
     delete t;
 }
@@ -624,7 +634,9 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
         } else if (r.kind == REC_CONV) {
             if (r.dead || !ts->nodes[r.z].ginit) continue;
             Tensor dy = b.bn_backward(r, r.bn);
+            ts->bwd_side.resize(ts->bwd.size(), 0);
             b.emit_wgrad(r.srcs, dy, r.L->cout, r.L->cout, r.L->ks, r.L->stride, b.G(r.L->conv + ".weight"));
+            ts->bwd_side.resize(ts->bwd.size(), 1);   // the closure(s) emit_wgrad just added
             const float *wm = b.P(r.L->conv + ".weight");
             int c_off = 0;
             for (int s : r.srcs) {
@@ -636,10 +648,23 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
             Tensor dy = b.bn_backward(r, r.bn);
             float *part = b.alloc((size_t)stem_wgrad_blocks(B, H, W) * 147 * 16), *dw = b.G("backbone.base_layer.0.weight");
             const float *dyp = dy.p;
+            ts->bwd_side.resize(ts->bwd.size(), 0);
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_stem_wgrad(ts->img, dyp, B, H, W, part, dw, st)); return 0; });
+            ts->bwd_side.resize(ts->bwd.size(), 1);
         }
     }
     if (!ts->ok) return nullptr;
+    ts->bwd_side.resize(ts->bwd.size(), 0);
+    if (const char *e = std::getenv("MONOCON_HIP_DUAL_STREAM")) ts->dual = std::atoi(e) != 0;
+    if (ts->dual) {
+        size_t nside = 0;
+        for (char c : ts->bwd_side) nside += c != 0;
+        if (hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ts->side_done, hipEventDisableTiming) != hipSuccess) ts->dual = false;
+        ts->side_ev.resize(ts->dual ? nside : 0);
+        for (auto &ev : ts->side_ev)
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ts->dual = false; break; }
+    }
     if (hipDeviceSynchronize() != hipSuccess) return nullptr;
     return tsp.release();
 }
@@ -709,8 +734,25 @@ int mc_backward(mc_handle *h, const float *grad_losses, void *stream) {
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     ts->grad_losses = grad_losses;
-    for (auto &f : ts->bwd)
-        if (f(h, st)) return -1;
+    size_t k = 0;
+    bool used_side = false;
+    for (size_t i = 0; i < ts->bwd.size(); ++i) {
+        if (ts->dual && ts->bwd_side[i] && k < ts->side_ev.size()) {
+            // everything this closure reads (dY of its layer, forward activations) is ready at this point of
+            // the main stream; its outputs (the weight gradient) are first needed after mc_backward
+            HIPCHK(h, hipEventRecord(ts->side_ev[k], st));
+            HIPCHK(h, hipStreamWaitEvent(ts->side, ts->side_ev[k], 0));
+            ++k;
+            if (ts->bwd[i](h, ts->side)) return -1;
+            used_side = true;
+        } else if (ts->bwd[i](h, st)) {
+            return -1;
+        }
+    }
+    if (used_side) {
+        HIPCHK(h, hipEventRecord(ts->side_done, ts->side));
+        HIPCHK(h, hipStreamWaitEvent(st, ts->side_done, 0));
+    }
     return 0;
 }
 
