@@ -210,6 +210,11 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
  * statistics like any train-mode forward.) */
 int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], double bytes[3], int launches[3],
                      void *stream);
+/* Arithmetic of the convolutions (forward + data gradients).  0 (default): fp32 MFMA -- the parity
+ * path.  1: both MFMA operands rounded to bf16 on their way into the matrix pipe, fp32 accumulation,
+ * fp32 activations / master weights / BN statistics / losses (BASELINE config 3; not within the 1e-4
+ * parity tolerance).  Re-pack (mc_pack_params) before the next forward. */
+int mc_set_precision(mc_handle *h, int mode);
 /* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
  * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel, 32 = the LDS-free
  * kernel for 16/32-channel 3x3 layers; 0 = automatic)

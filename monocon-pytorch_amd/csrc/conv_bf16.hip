@@ -1,0 +1,306 @@
+// Mixed-precision variant of the fused convolution (BASELINE config 3: "bf16"): activations and master
+// weights stay fp32 in HBM, both MFMA operands are rounded to bf16 (RNE) on their way into the matrix
+// pipe, accumulation / scale / bias / residual / ReLU / statistics stay fp32.
+//
+//   v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate, so the kernel turns from MFMA-bound into an
+//   L2 / LDS-bound one; everything that already made the fp32 kernel lean on address arithmetic carries
+//   over (buffer descriptors, static lane offsets, SGPR chunk offsets, wave-uniform epilogue).
+//
+// Same contract, tiling and epilogue as conv_mfma_kernel (conv_mfma.h); differences:
+//   * the halo tile lives in LDS as bf16, [patch][pixel][CK + 8] (80-byte rows: the 16-byte fragment
+//     reads of eight consecutive pixels fall on disjoint banks); a thread converts the float4 it
+//     loaded with two v_cvt_pk_bf16_f32 and writes 8 bytes.
+//   * one ds_read_b128 is the whole A operand of one MFMA (pixel li, channels 8g..8g+7 of a K=16 step).
+//   * weights are pre-packed as bf16 panels [tap][Cin/8][CoutP][8] (mc_pack_params), one 16-byte load
+//     per 32 output channels and MFMA.
+// Not the parity path: results differ from the fp32 reference by bf16 operand rounding (~1e-3
+// norm-wise per layer); tests/test_hip_bf16.py states the tolerance.  Selected per handle with
+// mc_set_precision(h, 1); layers whose sources are not multiples of 32 channels stay on the fp32 kernels.
+#include "conv_mfma.h"
+
+namespace mc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int S, int WM, int WN, int WTM, int WTN>
+struct ConvCfgB16 {
+    static constexpr int CK = 32;
+    static constexpr int PB = WM * WTM, BNT = WN * WTN * 32, NT = 64 * WM * WN;
+    static constexpr int KH = win_h(KS), KW = win_w(KS), PAD = win_pad(KS);
+    static constexpr int IH = 3 * S + KH, IW = 7 * S + KW, NPIX = IH * IW;
+    static constexpr int ROWB = (CK + 8) * 2;                      // bytes per staged pixel
+    static constexpr int TILE_BYTES = PB * NPIX * ROWB;
+    static constexpr size_t LDS_BYTES = TILE_BYTES + PB * 16 + 2 * WM * BNT * sizeof(float);
+};
+
+template <int KS, int S, int WM, int WN, int WTM, int WTN>
+__global__ __launch_bounds__(64 * WM * WN, 3) void conv_bf16_kernel(const ConvArgs a) {
+    using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN>;
+    constexpr int CK = Cfg::CK, PB = Cfg::PB, BNT = Cfg::BNT, NT = Cfg::NT, PAD = Cfg::PAD;
+    constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, ROWB = Cfg::ROWB;
+    constexpr int C4 = CK / 4;
+    static_assert(NT % C4 == 0, "a thread keeps one channel group across its staging elements");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int *pinfo = reinterpret_cast<int *>(lds_raw + Cfg::TILE_BYTES);   // [PB][4] = b, oy0, ox0, valid
+    float *sred = reinterpret_cast<float *>(lds_raw + Cfg::TILE_BYTES + PB * 16);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = lane >> 5, li = lane & 31;
+
+    const int ntiles = a.CoutP / BNT;
+    const int nt = blockIdx.x % ntiles;
+    const int mchunk = blockIdx.x / ntiles;
+    const int img = mchunk / a.chunks, chunk = mchunk % a.chunks;
+    const int n0 = nt * BNT;
+
+    if (tid < PB) {
+        const int pp = chunk * PB + tid;
+        const int valid = pp < a.ppi;
+        const int py = pp / a.ppr, px = pp % a.ppr;
+        pinfo[tid * 4 + 0] = img;
+        pinfo[tid * 4 + 1] = py * 4;
+        pinfo[tid * 4 + 2] = px * 8;
+        pinfo[tid * 4 + 3] = valid;
+    }
+    __syncthreads();
+
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int tm = 0; tm < WTM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < WTN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    constexpr int TOTAL = PB * NPIX * C4;
+    constexpr int NIT = (TOTAL + NT - 1) / NT;
+    const int c4 = tid % C4;
+    unsigned char *stage_dst = lds_raw + (tid / C4) * ROWB + c4 * 8;
+
+    int a_off[WTM];   // byte offsets of this lane's fragment rows
+#pragma unroll
+    for (int tm = 0; tm < WTM; ++tm)
+        a_off[tm] = ((wm * WTM + tm) * NPIX + ((li >> 3) * S) * IW + (li & 7) * S) * ROWB + g * 16;
+
+    const int Cin8 = a.Cin >> 3;
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk16, (unsigned)(Cfg::KH * Cfg::KW * a.Cin * a.CoutP) * 2u);
+    const int w_lane = (g * a.CoutP + n0 + wn * WTN * 32 + li) * 16;   // bytes
+
+    constexpr int KSTEPS = CK / 16, NS = Cfg::KH * Cfg::KW * KSTEPS;
+    auto load_b = [&](bf16x8(&dst)[WTN], int kc, int s) {
+        const int tap = s / KSTEPS, m = s % KSTEPS;
+        const int soff = (tap * Cin8 + ((kc + m * 16) >> 3)) * a.CoutP * 16;
+#pragma unroll
+        for (int tn = 0; tn < WTN; ++tn)
+            dst[tn] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, w_lane + tn * 32 * 16, soff, 0));
+    };
+    auto load_a = [&](bf16x8(&dst)[WTM], int s) {
+        const int tap = s / KSTEPS, m = s % KSTEPS;
+#pragma unroll
+        for (int tm = 0; tm < WTM; ++tm)
+            dst[tm] = *reinterpret_cast<const bf16x8 *>(
+                lds_raw + a_off[tm] + ((tap / Cfg::KW) * IW + (tap % Cfg::KW)) * ROWB + m * 32);
+    };
+    bf16x8 bcur[WTN];
+    load_b(bcur, 0, 0);
+
+    int kbase = 0;
+    for (int si = 0; si < a.nsrc; ++si) {
+        const int Cs = a.src[si].C;
+        const __amdgpu_buffer_rsrc_t r_in =
+            make_rsrc(a.src[si].p + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
+        int voff[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + NT * i;
+            const int t = e / C4;
+            const int pix = t % NPIX;
+            const int p = (t / NPIX) % PB;
+            const int iy = pix / IW, ix = pix % IW;
+            const int y = pinfo[p * 4 + 1] * S - PAD + iy;
+            const int x = pinfo[p * 4 + 2] * S - PAD + ix;
+            const bool ok = e < TOTAL && pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
+            voff[i] = ok ? ((y * a.Win + x) * Cs + c4 * 4) * 4 : BUF_OOB;
+        }
+        for (int c0 = 0; c0 < Cs; c0 += CK) {
+            if (kbase + c0 > 0) __syncthreads();
+            constexpr int UB = NIT > 8 ? 8 : NIT;
+#pragma unroll
+            for (int i0 = 0; i0 < NIT; i0 += UB) {
+                f32x4 v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (i0 + u < NIT) v[u] = buf_load4(r_in, voff[i0 + u], c0 * 4);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int i = i0 + u;
+                    if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL)) {
+                        bf16x4 q;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) q[j] = (__bf16)v[u][j];
+                        *reinterpret_cast<bf16x4 *>(stage_dst + i * (NT / C4) * ROWB) = q;
+                    }
+                }
+            }
+            __syncthreads();
+            const int kc = kbase + c0;
+            const int kc_next = (kc + CK < a.Cin) ? kc + CK : kc;
+            bf16x8 acur[WTM];
+            load_a(acur, 0);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                bf16x8 anext[WTM], bnext[WTN];
+                if (s + 1 < NS) {
+                    load_a(anext, s + 1);
+                    load_b(bnext, kc, s + 1);
+                } else {
+                    load_b(bnext, kc_next, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < WTM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < WTN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[tm], bcur[tn], acc[tm][tn], 0, 0, 0);
+                if (s + 1 < NS) {
+#pragma unroll
+                    for (int tm = 0; tm < WTM; ++tm) acur[tm] = anext[tm];
+                }
+#pragma unroll
+                for (int tn = 0; tn < WTN; ++tn) bcur[tn] = bnext[tn];
+            }
+        }
+        kbase += Cs;
+    }
+
+    conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, sred, img, n0, wm, wn, g, li);
+    if (a.stats) {
+        __syncthreads();
+        for (int nl = tid; nl < BNT; nl += NT) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s1 += sred[(w * BNT + nl) * 2 + 0];
+                s2 += sred[(w * BNT + nl) * 2 + 1];
+            }
+            float *dst = a.stats + (((size_t)img * a.chunks + chunk) * a.CoutP + n0 + nl) * 2;
+            dst[0] = s1;
+            dst[1] = s2;
+        }
+    }
+}
+
+// ---- weight packing: OIHW fp32 -> [tap][Cin/8][CoutP][8] bf16 (forward) and the dgrad variants
+// (transposed + flipped per source, or one output-parity class of a stride-2 data gradient; same tap
+// conventions as pack_conv_w_kernel / pack_conv_w_dgrad_kernel)
+__global__ void pack_conv_w_bf16_kernel(const float *__restrict__ w, int Cout, int Cin, int k, __bf16 *__restrict__ dst,
+                                        int CinPanel, int CoutP, int n_off, int c_off) {
+    const int kk = k * k;
+    const size_t total = (size_t)Cout * Cin * kk;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int tap = e % kk;
+        const int c = (e / kk) % Cin;
+        const int n = e / ((size_t)kk * Cin);
+        const int cc = c + c_off, nn = n + n_off;
+        dst[(((size_t)tap * (CinPanel >> 3) + (cc >> 3)) * CoutP + nn) * 8 + (cc & 7)] = (__bf16)w[e];
+    }
+}
+hipError_t launch_pack_conv_w_bf16(const float *w, int Cout, int Cin, int k, void *dst, int CinPanel, int CoutP, int n_off,
+                                   int c_off, hipStream_t st) {
+    const size_t total = (size_t)Cout * Cin * k * k;
+    size_t gsz = (total + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(pack_conv_w_bf16_kernel, dim3((unsigned)gsz), dim3(256), 0, st, w, Cout, Cin, k,
+                       static_cast<__bf16 *>(dst), CinPanel, CoutP, n_off, c_off);
+    return hipGetLastError();
+}
+__global__ void pack_conv_w_dgrad_bf16_kernel(const float *__restrict__ w, int Cout, int CinTotal, int k, int c_off, int Cs,
+                                              int CsP, int CoutPad, int cls, __bf16 *__restrict__ dst) {
+    const int kk = k * k;
+    const size_t total = (size_t)Cout * Cs * kk;
+    const int py = cls >> 1, px = cls & 1;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int tap = e % kk;
+        const int cl = (e / kk) % Cs;
+        const int n = e / ((size_t)kk * Cs);
+        const int r = tap / k, s = tap % k;
+        int tapd;
+        if (cls < 0) {
+            tapd = (k - 1 - r) * k + (k - 1 - s);
+        } else {
+            if ((py == 0) != (r == 1) || (px == 0) != (s == 1)) continue;
+            const int dr = py ? (2 - r) / 2 : 0, ds = px ? (2 - s) / 2 : 0;
+            tapd = dr * (1 + px) + ds;
+        }
+        dst[(((size_t)tapd * (CoutPad >> 3) + (n >> 3)) * CsP + cl) * 8 + (n & 7)] =
+            (__bf16)w[(((size_t)n * CinTotal + c_off + cl) * k + r) * k + s];
+    }
+}
+hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
+                                         int cls, void *dst, hipStream_t st) {
+    const size_t total = (size_t)Cout * Cs * k * k;
+    size_t gsz = (total + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(pack_conv_w_dgrad_bf16_kernel, dim3((unsigned)gsz), dim3(256), 0, st, w, Cout, CinTotal, k, c_off, Cs,
+                       CsP, CoutPad, cls, static_cast<__bf16 *>(dst));
+    return hipGetLastError();
+}
+
+// ---- dispatch
+template <int KS, int S, int WM, int WN, int WTM, int WTN>
+static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
+    using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN>;
+    a.ppr = (a.Wout + 7) / 8;
+    a.ppi = a.ppr * ((a.Hout + 3) / 4);
+    a.chunks = (a.ppi + Cfg::PB - 1) / Cfg::PB;
+    if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
+    if (resolved) *resolved = a;
+    static bool attr_set = false;
+    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntiles = a.CoutP / Cfg::BNT;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * a.chunks * ntiles)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+template <int KS, int S>
+static hipError_t launch_b16_shape(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
+    switch (a.cfg & 15) {
+        case CFG_128x128: return launch_b16_one<KS, S, 2, 2, 2, 2>(a, st, resolved);
+        case CFG_128x64: return launch_b16_one<KS, S, 2, 2, 2, 1>(a, st, resolved);
+        case CFG_128x64m: return launch_b16_one<KS, S, 4, 1, 1, 2>(a, st, resolved);
+        case CFG_128x32: return launch_b16_one<KS, S, 4, 1, 1, 1>(a, st, resolved);
+        case CFG_64x128: return launch_b16_one<KS, S, 1, 4, 2, 1>(a, st, resolved);
+        case CFG_64x64: return launch_b16_one<KS, S, 2, 2, 1, 1>(a, st, resolved);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bool conv_bf16_ok(const ConvArgs &a, int ks, int stride) {
+    if (!a.wpk16) return false;
+    for (int i = 0; i < a.nsrc; ++i)
+        if (a.src[i].C % 32) return false;
+    if (ks == 3) return stride == 1 || stride == 2;
+    return stride == 1 && (ks == 1 || ks == 12 || ks == 21 || ks == 22);
+}
+
+hipError_t launch_conv_bf16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
+    if (!conv_bf16_ok(a, ks, stride)) return hipErrorInvalidValue;
+    if (ks == 3 && stride == 1) return launch_b16_shape<3, 1>(a, st, resolved);
+    if (ks == 3 && stride == 2) return launch_b16_shape<3, 2>(a, st, resolved);
+    if (ks == 1) return launch_b16_shape<1, 1>(a, st, resolved);
+    if (ks == 12) return launch_b16_shape<12, 1>(a, st, resolved);
+    if (ks == 21) return launch_b16_shape<21, 1>(a, st, resolved);
+    return launch_b16_shape<22, 1>(a, st, resolved);
+}
+
+}  // namespace mc

@@ -57,6 +57,9 @@ struct ConvArgs {
     // output / residual pixel mapping in floats (0 = dense NHWC: img = Hout*Wout*ld, row = Wout*ld, px = ld);
     // the stride-2 data-gradient classes scatter to every second pixel of a larger map
     int o_img, o_row, o_px, r_img, r_row, r_px;
+    // mixed precision (conv_bf16.hip): prec 1 = bf16 MFMA operands from the bf16 panel wpk16, fp32 everything else
+    const void *wpk16;       // [k*k][Cin/8][CoutP][8] bf16 or null
+    int prec;
 };
 
 // Filter window code KS: 3 = 3x3 (pad 1), 1 = 1x1; 12 / 21 / 22 = 1x2, 2x1, 2x2 windows without padding --
@@ -598,6 +601,12 @@ inline int conv_chunks_per_image(int cfg, int Hout, int Wout) {
     return (ppi + pb - 1) / pb;
 }
 bool conv_small_ok(const ConvArgs &a, int ks, int stride);
+bool conv_bf16_ok(const ConvArgs &a, int ks, int stride);
+hipError_t launch_conv_bf16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved);
+hipError_t launch_pack_conv_w_bf16(const float *w, int Cout, int Cin, int k, void *dst, int CinPanel, int CoutP, int n_off,
+                                   int c_off, hipStream_t st);
+hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
+                                         int cls, void *dst, hipStream_t st);
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st);
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);

@@ -37,6 +37,7 @@ struct ConvLayer {
     int ks = 1, stride = 1, cin = 0, cout = 0, coutp = 0, cfg = 0;
     float bn_eps = 1e-5f;
     float *wpk = nullptr, *scale = nullptr, *shift = nullptr;
+    void *wpk16 = nullptr;   // bf16 panel (mixed-precision mode)
 };
 
 struct DeconvLayer {
@@ -96,6 +97,7 @@ struct mc_handle {
     float *decode_filt = nullptr;
     size_t decode_filt_n = 0;
     int force_cfg = 0;   // tuning aid (mc_bench_conv)
+    int prec = 0;        // 0 fp32 (parity path), 1 bf16 MFMA operands (mc_set_precision)
     int autotune = 1;    // time the workgroup shapes of every distinct conv once (MONOCON_HIP_AUTOTUNE=0: heuristic)
     std::map<std::vector<int>, int> tuned;   // conv signature -> shape id
     float *loss_ws = nullptr;   // focal partials + small reduction scratch

@@ -28,6 +28,7 @@ struct PackJob {           // dgrad panel refreshed from the master weights befo
     int Cout, CinTotal, k, c_off, Cs, CsP, CoutPad;
     int cls;           // -1: stride-1 panel; 0..3: output-parity class of a stride-2 data gradient
     float *dst;
+    void *dst16;       // bf16 twin of the panel (mixed-precision mode) or null
 };
 
 enum RecKind { REC_STEM, REC_CONV, REC_POOL, REC_DECONV, REC_HEAD };
@@ -91,6 +92,7 @@ struct TB {   // train plan builder
     mc_handle *h;
     TrainState *ts;
     std::map<const float *, int> pooled;
+    void *last_panel16 = nullptr;   // bf16 twin of the panel the last pack_job() made
 
     float *alloc(size_t n) {
         float *p = nullptr;
@@ -161,6 +163,7 @@ struct TB {   // train plan builder
         if (cin != Lr.cin) { ts->ok = false; h->err = "train plan: channel mismatch at " + Lr.conv; }
         a.B = B; a.Hin = s0.H; a.Win = s0.W; a.Hout = Ho; a.Wout = Wo; a.Cin = cin; a.Cout = Lr.cout; a.CoutP = Lr.coutp;
         a.wpk = Lr.wpk; a.out = r.y.p; a.out_ld = Lr.cout;
+        a.wpk16 = Lr.wpk16; a.prec = h->prec;
         a.cfg = ts->ok ? mc_choose_conv_cfg(h, a, Lr.ks, Lr.stride) : CFG_128x32;
         const int chunks = conv_chunks_per_image(a.cfg, Ho, Wo);
         float *stats = alloc((size_t)B * chunks * Lr.coutp * 2);
@@ -250,6 +253,8 @@ struct TB {   // train plan builder
         j.CsP = conv_coutp(Cs); j.CoutPad = CoutPad; j.cls = cls;
         const int taps = cls < 0 ? k * k : (1 + (cls >> 1)) * (1 + (cls & 1));
         j.dst = alloc((size_t)taps * CoutPad * j.CsP);
+        j.dst16 = (h->prec == 1 && CoutPad % 8 == 0) ? alloc(((size_t)taps * CoutPad * j.CsP + 1) / 2) : nullptr;
+        last_panel16 = j.dst16;
         ts->packs.push_back(j);
         *dst_out = j.dst;
         *csp_out = j.CsP;
@@ -274,6 +279,7 @@ struct TB {   // train plan builder
                 d.src[0].p = dy.p; d.src[0].C = dy.C;
                 d.B = dy.B; d.Hin = dy.H; d.Win = dy.W; d.Hout = dy.H; d.Wout = dy.W;
                 d.Cin = dy.C; d.Cout = sn.t.C; d.CoutP = csp; d.wpk = panel;
+                d.wpk16 = last_panel16; d.prec = last_panel16 ? h->prec : 0;
                 const int ld = sn.t.C;
                 d.out = sn.g + ((size_t)py * sn.t.W + px) * ld; d.out_ld = ld;
                 d.o_px = 2 * ld; d.o_row = 2 * sn.t.W * ld; d.o_img = sn.t.H * sn.t.W * ld;
@@ -296,6 +302,7 @@ struct TB {   // train plan builder
         d.src[0].p = dyp; d.src[0].C = dy.C;
         d.B = dy.B; d.Hin = Hd; d.Win = Wd; d.Hout = Hd; d.Wout = Wd;
         d.Cin = dy.C; d.Cout = sn.t.C; d.CoutP = csp; d.wpk = panel;
+        d.wpk16 = last_panel16; d.prec = last_panel16 ? h->prec : 0;
         d.out = sn.g; d.out_ld = sn.t.C;
         if (sn.ginit) { d.res = sn.g; d.res_ld = sn.t.C; }
         if (Hd != sn.t.H || Wd != sn.t.W) { ts->ok = false; h->err = "train plan: dgrad shape mismatch"; }
@@ -439,6 +446,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
         c3.nsrc = 1; c3.src[0].p = fn.t.p; c3.src[0].C = 64;
         c3.B = B; c3.Hin = fh; c3.Win = fw; c3.Hout = fh; c3.Wout = fw; c3.Cin = 64; c3.Cout = CP; c3.CoutP = h->head3.coutp;
         c3.wpk = h->head3.wpk; c3.bias = h->head_bias; c3.out = xh.p; c3.out_ld = CP; c3.cfg = h->head3.cfg;
+        c3.wpk16 = h->head3.wpk16; c3.prec = h->prec;
         const int ppr = (fw + 7) / 8, ppi = ppr * ((fh + 3) / 4), pb = conv_patches_per_block(c3.cfg);
         at.chunks = (ppi + pb - 1) / pb;
         at.stat_ld = h->head3.coutp;
@@ -704,8 +712,11 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
     if (!h->pack_clean && mc_pack_params(h, 1, stream)) return -1;   // mc_pack_params / the optimizer step track staleness
     for (auto &f : ts->pack_fns)       // dense head weight copies first: some dgrad panels are cut from them
         if (f(h, st)) return -1;
-    for (const PackJob &j : ts->packs)
+    for (const PackJob &j : ts->packs) {
         HIPCHK(h, launch_pack_conv_w_dgrad(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls, j.dst, st));
+        if (j.dst16)
+            HIPCHK(h, launch_pack_conv_w_dgrad_bf16(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls, j.dst16, st));
+    }
     for (auto &f : ts->fwd)
         if (f(h, st)) return -1;
     return 0;

@@ -279,6 +279,12 @@ class Engine:
         return dict(zip(PRED_KEYS, d))
 
     # ------------------------------------------------------------------ op level (tests)
+    def set_precision(self, mode):
+        """0 = fp32 (parity path), 1 = bf16 MFMA operands with fp32 accumulation (config 3)."""
+        _lib.check(self.h, self.lib.mc_set_precision(self.h, int(mode)), "mc_set_precision")
+        self._sig = None          # panels must be re-packed
+        self.precision = int(mode)
+
     def set_conv_cfg(self, cfg):
         """force a workgroup shape of the fused conv (tuning / tests); 0 = automatic."""
         _lib.check(self.h, self.lib.mc_set_conv_cfg(self.h, int(cfg)), "mc_set_conv_cfg")

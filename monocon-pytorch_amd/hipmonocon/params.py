@@ -107,6 +107,12 @@ class HipRuntime:
 
     def __init__(self):
         self.engine = None
+        self.precision = 0     # 0 fp32 (parity path), 1 bf16 MFMA operands (BASELINE config 3)
+
+    def set_precision(self, mode):
+        self.precision = {"fp32": 0, "f32": 0, "bf16": 1}.get(mode, mode)
+        if self.engine is not None:
+            self.engine.set_precision(self.precision)
 
     def get(self, state):
         from .engine import Engine
@@ -118,5 +124,7 @@ class HipRuntime:
                 "CPU path" % dev)
         if self.engine is None or self.engine.device != dev:
             self.engine = Engine(dev.index if dev.index is not None else torch.cuda.current_device())
+            if self.precision:
+                self.engine.set_precision(self.precision)
         self.engine.bind_state(state)   # Parameters are passed as-is: their _version tracks in-place updates
         return self.engine

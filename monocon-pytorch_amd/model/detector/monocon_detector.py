@@ -31,6 +31,12 @@ class MonoConDetector(nn.Module):
         self.head = MonoConDenseHeads(in_ch=64, test_config=test_config, **head_config)
         self._rt = HipRuntime()
 
+    def set_precision(self, mode: str = "fp32"):
+        """'fp32' (default, the parity path) or 'bf16': bf16 MFMA operands with fp32 accumulation,
+        activations, master weights, BN statistics and losses (no reference counterpart)."""
+        self._rt.set_precision(mode)
+        return self
+
     def _engine(self):
         return self._rt.get(self.state_dict(keep_vars=True))
 

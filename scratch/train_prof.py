@@ -8,6 +8,7 @@ B = int(os.environ.get("TB", "32")); H, W = 384, 1280
 stats = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "bn_calib_seed7.npz"))
 sd = synth.make_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
 m = MonoConDetector(34, pretrained_backbone=False); m.load_state_dict(sd); m = m.cuda().train()
+if os.environ.get('PREC'): m.set_precision(os.environ['PREC'])
 opt = AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=35.0)
 sch = CyclicScheduler(opt, total_steps=1000)
 small = synth.make_batch(500, 8, H, W); rep = (B + 7) // 8

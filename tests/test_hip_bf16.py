@@ -1,0 +1,134 @@
+"""Mixed-precision mode (BASELINE config 3): bf16 MFMA operands, fp32 accumulation / activations / weights.
+NOT the parity path -- there is no reference counterpart (the reference forces fp32); the
+tolerance here is the bf16 operand rounding (2^-9 relative per operand) carried through the network,
+stated per test, against the fp64 reference / the fp32 HIP path on identical inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err, GOLDEN_SEED
+from hipmonocon import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def eng16():
+    from hipmonocon.engine import Engine
+    e = Engine()
+    e.set_precision(1)
+    yield e
+    e.set_precision(0)
+
+
+def rnd(seed, name, shape, scale=1.0):
+    return torch.from_numpy((synth.normalish(seed, name, shape) * scale).astype(np.float32))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # (name, B, H, W, [Cin...], Cout, k, stride, residual, relu)
+    ("b16_s1_64_64", 2, 16, 24, [64], 64, 3, 1, True, True),
+    ("b16_s1_128_128", 1, 12, 40, [128], 128, 3, 1, True, True),
+    ("b16_s1_cat", 2, 8, 16, [64, 64], 64, 3, 1, False, True),
+    ("b16_s1_odd_edges", 1, 6, 10, [32], 64, 3, 1, False, False),
+    ("b16_s2_32_64", 2, 16, 32, [32], 64, 3, 2, False, True),
+    ("b16_s2_256_512", 1, 8, 8, [256], 512, 3, 2, False, True),
+    ("b16_k1_root4", 1, 12, 16, [128, 128, 64, 128], 128, 1, 1, False, True),
+    ("b16_head_576", 1, 8, 16, [64], 576, 3, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16_operands(eng16, case):
+    name, B, H, W, cins, cout, k, stride, use_res, relu = case
+    seed = 700 + CASES.index(case)
+    xs = [rnd(seed, "x%d" % i, (B, c, H, W)) for i, c in enumerate(cins)]
+    w = rnd(seed, "w", (cout, sum(cins), k, k), (2.0 / (k * k * sum(cins))) ** 0.5)
+    bias = 0.1 * rnd(seed, "bi", (cout,))
+    res = rnd(seed, "res", (B, cout, (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1)) if use_res else None
+
+    def ref(xcat, ww):
+        r = F.conv2d(xcat, ww, None, stride, k // 2) + bias.double()[None, :, None, None]
+        if use_res:
+            r = r + res.double()
+        return F.relu(r) if relu else r
+    exact = ref(torch.cat(xs, 1).double(), w.double())
+    # the same computation with both operands rounded to bf16 first: what the kernel is specified to do
+    rounded = ref(torch.cat(xs, 1).bfloat16().double(), w.bfloat16().double())
+    dev = eng16.device
+    got = eng16.op_conv([nhwc(x).to(dev) for x in xs], w.to(dev), stride, None, bias.to(dev),
+                        nhwc(res).to(dev) if use_res else None, relu).cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, rounded) < 2e-5          # fp32 accumulation of exactly-rounded operands
+    e = rel_err(got, exact)
+    assert 1e-5 < e < 1e-2, e                    # bf16 rounding is there, and only that
+
+
+def l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def test_forward_bf16_close_to_fp32(golden_sd):
+    """eval forward at 64x128 against the fp32 HIP path on the same inputs.  Every conv contributes ~0.3 %
+    relative-L2 of operand rounding and this synthetic (untrained, BN-calibrated) network amplifies a
+    perturbation roughly 1.4x per DLA level (the same conditioning shows in the fp32 parity numbers, see
+    DESIGN.md section 4), so the bounds are stated per depth: level2 < 2e-2, predictions < 0.3 relative L2."""
+    from hipmonocon.engine import Engine
+    eng = Engine()
+    dsd = {k: v.cuda() for k, v in golden_sd.items()}
+    img = synth.make_batch(GOLDEN_SEED + 1, 2, 64, 128, with_labels=False)["img"].cuda()
+    eng.bind_state(dsd)
+    lv32 = [t.clone() for t in eng.backbone_forward(img)]
+    p32 = {k: v.clone() for k, v in eng.forward_infer(img).items()}
+    eng.set_precision(1)
+    eng.bind_state(dsd)
+    lv16 = eng.backbone_forward(img)
+    assert torch.equal(lv16[0], lv32[0]) and torch.equal(lv16[1], lv32[1])   # 16-channel layers stay fp32
+    e2 = l2(lv16[2], lv32[2])
+    assert 1e-4 < e2 < 2e-2, e2
+    p16 = eng.forward_infer(img)
+    worst = max(l2(p16[k], p32[k]) for k in p32)
+    assert 1e-4 < worst < 0.3, worst
+    eng.set_precision(0)
+    eng.bind_state(dsd)
+    back = eng.forward_infer(img)
+    for k in p32:
+        assert torch.equal(back[k], p32[k]), k     # switching back restores the fp32 path bit for bit
+
+
+def test_train_step_bf16_runs_and_tracks_fp32(golden_sd):
+    """full train step with bf16 conv operands: finite; losses within 25 % of the fp32 step (depth: factor 4)."""
+    from model import MonoConDetector
+    batch = synth.make_batch(GOLDEN_SEED + 3, 2, 96, 160)
+    batch = {"img": batch["img"].cuda(), "label": {k: v.cuda() for k, v in batch["label"].items()},
+             "img_metas": batch["img_metas"]}
+    out = {}
+    for mode in ("fp32", "bf16"):
+        m = MonoConDetector(34, pretrained_backbone=False)
+        m.load_state_dict(golden_sd, strict=True)
+        m = m.cuda().train().set_precision(mode)
+        _, loss = m(batch)
+        total = sum(v for k, v in loss.items() if k != "loss_depth")   # see below: the depth term is chaotic here
+        total.backward()
+        g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+        assert bool(torch.isfinite(total)) and bool(torch.isfinite(g).all())
+        out[mode] = ({k: float(v.detach()) for k, v in loss.items()}, g.clone())
+    print({k: (round(v, 4), round(out["bf16"][0][k], 4)) for k, v in out["fp32"][0].items()})
+    for k, v in out["fp32"][0].items():
+        w = out["bf16"][0][k]
+        if k == "loss_depth":      # exp(-log_var)-weighted: the synthetic depth head is the worst-conditioned output
+            assert v / 4 < w < v * 4, (k, v, w)
+        else:
+            assert abs(w - v) <= 0.25 * abs(v) + 1e-3, (k, v, w)
+    cos = float(torch.dot(out["bf16"][1].double(), out["fp32"][1].double()) /
+                (out["bf16"][1].double().norm() * out["fp32"][1].double().norm()))
+    print("gradient cosine", cos)
+    # B=2 train-mode BN on an untrained network is chaotic (fp32-vs-fp64 already moves backbone gradients by
+    # 1e-3 for a 1e-7 perturbation): a 4e-3 operand rounding decorrelates the gradient
+    # to cos 0.65 (heads 0.75-0.95, neck 0.8-0.87, backbone 0.63-0.77, norms within 10 %); a wrong tap or
+    # panel in the bf16 data-gradient path would drive everything upstream of it to ~0
+    assert cos > 0.5, cos
