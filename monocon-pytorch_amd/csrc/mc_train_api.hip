@@ -159,6 +159,7 @@ int mc_op_conv_wgrad(mc_handle *h, const float *const src[], const int src_chann
     a.Hout = (Hin + 2 * (ksize / 2) - ksize) / stride + 1;
     a.Wout = (Win + 2 * (ksize / 2) - ksize) / stride + 1;
     a.Cin = cin; a.Cout = Cout; a.dy = dy; a.dy_ld = Cout;
+    a.prec = h->prec;
     mc::wgrad_plan(a, ksize, stride);
     void *part = nullptr;
     HIPCHK(h, hipMalloc(&part, mc::wgrad_partial_floats(a, ksize) * sizeof(float)));

@@ -323,6 +323,7 @@ struct TB {   // train plan builder
         const Tensor &s0 = ts->nodes[srcs[0]].t;
         a.B = s0.B; a.Hin = s0.H; a.Win = s0.W; a.Hout = dy.H; a.Wout = dy.W; a.Cin = cin; a.Cout = Cout;
         a.dy = dy.p; a.dy_ld = dy_ld;
+        a.prec = h->prec;
         wgrad_plan(a, ks, stride);
         a.partial = alloc(wgrad_partial_floats(a, ks));
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_wgrad(a, ks, stride, dw, st)); return 0; });

@@ -120,9 +120,12 @@ struct WgradArgs {
     float *partial;           // [ksplit][k*k][Cout][Cin]
     int ksplit, n_tiles, c_tiles, ppr, ppi, groups_per_img;
     int small;                // 1: 16-input-channel layer on the LDS-free 16x16x4 kernel (ksplit = workgroups)
+    int prec;                 // 1: bf16 MFMA operands where wgrad_bf16_ok() (wgrad_bf16.hip)
 };
 void wgrad_plan(WgradArgs &a, int ks, int stride);            // fills the tiling fields
 size_t wgrad_partial_floats(const WgradArgs &a, int ks);
 hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st);
+bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride);
+hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st);
 
 }  // namespace mc

@@ -1,0 +1,243 @@
+// Mixed-precision weight gradient (BASELINE config 3; see conv_bf16.hip for the mode):
+//
+//   dW[n, c, r, s] = sum_{b, y, x} dY[b, y, x, n] * X[b, y - 1 + r, x - 1 + s, c]        (3x3, stride 1;  1x1: r = s = 0)
+//
+// on v_mfma_f32_32x32x16_bf16.  The reduction dimension K of the MFMA is the PIXEL index, and a lane
+// supplies 8 consecutive k from one 16-byte register group -- so both operands must sit in LDS
+// channel-major, 8 pixels of one row contiguous: the staging transposes.
+//   * A[n][k]: dYt[n][patch row][8 px] bf16.  One ds_read_b128 = row 2q+g of channel n = 8 of the 16 k.
+//   * B[k][c]: Xt[c][halo row][16 px] bf16 (10 used).  For tap column s the 8 pixels x+s..x+s+7 start at a
+//     2-byte offset, which LDS cannot serve in one aligned read; instead a lane reads pixels 0..7 (b128) and
+//     8..9 (b32) once per halo row and builds the three operands in registers: s = 0 as read, s = 2 is the
+//     same registers shifted by one dword (free), s = 1 is four v_alignbit.
+//   * staging: a thread loads the float4 (4 channels) of TWO horizontally adjacent pixels, rounds to bf16
+//     (RNE) and writes one packed dword per channel -- the transpose costs ds_write_b32, not ds_write_b16.
+//     Offsets, zero fill and the register prefetch across the MFMA phase are as in wgrad_mfma_kernel.
+// Accumulation, split-K partials and the deterministic reduce stay fp32 (wgrad_reduce_kernel).
+// Stride-2 layers (five in DLA-34) and the 16-channel layers keep their fp32 kernels.
+#include <algorithm>
+#include "conv_mfma.h"
+#include "train.h"
+
+namespace mc {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int WN, int WC>
+struct WgB16Cfg {
+    static constexpr int PB = 2;
+    static constexpr int NB = 32 * WN, CB = 32 * WC, NT = 64 * WN * WC;
+    static constexpr int PAD = KS / 2;
+    static constexpr int IH = 3 + KS, IW = 7 + KS;              // 6 x 10 (3x3) or 4 x 8 (1x1)
+    static constexpr int XROW = KS == 3 ? 32 : 16;              // bytes per staged halo row (16 / 8 pixels)
+    static constexpr int XCH = IH * XROW + 16;                  // bytes per channel (+16: spreads the b128 reads over banks)
+    static constexpr int DCH = 4 * 16 + 16;                     // bytes per dY channel
+    static constexpr int X_BYTES = PB * CB * XCH, D_BYTES = PB * NB * DCH;
+    static constexpr size_t LDS_BYTES = X_BYTES + D_BYTES;
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int KS, int WN, int WC>
+__global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const WgradArgs a) {
+    using Cfg = WgB16Cfg<KS, WN, WC>;
+    constexpr int PB = Cfg::PB, NB = Cfg::NB, CB = Cfg::CB, NT = Cfg::NT, PAD = Cfg::PAD;
+    constexpr int IH = Cfg::IH, IW = Cfg::IW, XROW = Cfg::XROW, XCH = Cfg::XCH, DCH = Cfg::DCH;
+    constexpr int T = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char *xt = lds_raw;                       // [PB][CB] x XCH
+    unsigned char *dyt = lds_raw + Cfg::X_BYTES;       // [PB][NB] x DCH
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave / WC, wc = wave % WC;
+    const int g = lane >> 5, li = lane & 31;
+    const int ct = blockIdx.x % a.c_tiles;
+    const int nt = (blockIdx.x / a.c_tiles) % a.n_tiles;
+    const int ks = blockIdx.x / (a.c_tiles * a.n_tiles);
+    const int n0 = nt * NB, c0 = ct * CB;
+    const long long G = (long long)a.B * a.groups_per_img;
+    const int g_begin = (int)(G * ks / a.ksplit), g_end = (int)(G * (ks + 1) / a.ksplit);
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int si = 0, cbase = 0;
+    while (si + 1 < a.nsrc && c0 >= cbase + a.src[si].C) { cbase += a.src[si].C; ++si; }
+    const int Cs = a.src[si].C;
+    const float *xsrc = a.src[si].p;
+    const int cs0 = c0 - cbase;
+
+    // ---- staging plan.  X item = (halo row, pixel pair, channel group) of a patch, channel group fastest;
+    //      dY item = (patch row, pixel pair, channel group).
+    constexpr int XC4 = CB / 4, XPAIRS = IW / 2, XP = IH * XPAIRS * XC4, NIX = (XP + NT - 1) / NT;
+    constexpr int NC4 = NB / 4, DP = 4 * 4 * NC4, NID = (DP + NT - 1) / NT;
+    static_assert(NT % XC4 == 0 && NT % NC4 == 0 && IW % 2 == 0, "static channel group per thread");
+    constexpr int DEAD = -(1 << 24);
+    const int xc4 = tid % XC4, dn4 = tid % NC4;
+    const bool xc_ok = cs0 + xc4 * 4 < Cs && c0 + xc4 * 4 < a.Cin;
+    const bool dn_ok = n0 + dn4 * 4 + 3 < a.dy_ld;
+    int x_stat[NIX], x_ix[NIX], x_dst[NIX];
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+        const int e = tid + NT * i, item = (e / XC4) % (IH * XPAIRS);
+        const int iy = item / XPAIRS, ix = (item % XPAIRS) * 2;
+        x_ix[i] = (xc_ok && e < XP) ? ix - PAD : DEAD;
+        x_stat[i] = (((iy - PAD) * a.Win + ix - PAD) * Cs + cs0 + xc4 * 4) * 4;
+        x_dst[i] = (xc4 * 4) * XCH + iy * XROW + ix * 2;
+    }
+    int d_stat[NID], d_mx[NID], d_dst[NID];
+#pragma unroll
+    for (int i = 0; i < NID; ++i) {
+        const int e = tid + NT * i, item = (e / NC4) % 16;
+        const int my = item / 4, mx = (item % 4) * 2;
+        d_mx[i] = (dn_ok && e < DP) ? mx : -DEAD;
+        d_stat[i] = ((my * a.Wout + mx) * a.dy_ld + n0 + dn4 * 4) * 4;
+        d_dst[i] = (dn4 * 4) * DCH + my * 16 + mx * 2;
+    }
+
+    f32x4 xv[PB][NIX][2], dv[PB][NID][2];
+    auto fetch = [&](int gi, int p) {
+        const int img = gi / a.groups_per_img;
+        const int pp = (gi - img * a.groups_per_img) * PB + p;
+        const __amdgpu_buffer_rsrc_t r_x =
+            make_rsrc(xsrc + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
+        const __amdgpu_buffer_rsrc_t r_d =
+            make_rsrc(a.dy + (size_t)img * a.Hout * a.Wout * a.dy_ld, (unsigned)(a.Hout * a.Wout * a.dy_ld) * 4u);
+        const bool valid = pp < a.ppi;
+        const int oy = (pp / a.ppr) * 4, ox = valid ? (pp % a.ppr) * 8 : DEAD;
+        const int xb = (oy * a.Win + ox) * Cs * 4;
+        const int db = (oy * a.Wout + ox) * a.dy_ld * 4;
+#pragma unroll
+        for (int i = 0; i < NIX; ++i) {
+            const int xx = ox + x_ix[i];
+            xv[p][i][0] = buf_load4(r_x, (xx >= 0 && xx < a.Win) ? xb + x_stat[i] : BUF_OOB, 0);
+            xv[p][i][1] = buf_load4(r_x, (xx + 1 >= 0 && xx + 1 < a.Win) ? xb + x_stat[i] + Cs * 4 : BUF_OOB, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NID; ++i) {
+            const int xx = ox + d_mx[i];
+            dv[p][i][0] = buf_load4(r_d, (xx >= 0 && xx < a.Wout) ? db + d_stat[i] : BUF_OOB, 0);
+            dv[p][i][1] = buf_load4(r_d, (xx >= 0 && xx + 1 < a.Wout) ? db + d_stat[i] + a.dy_ld * 4 : BUF_OOB, 0);
+        }
+    };
+    auto store = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < NIX; ++i)
+            if (NT * (i + 1) <= XP || tid + NT * i < XP) {
+                unsigned char *dst = xt + p * CB * XCH + x_dst[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<unsigned *>(dst + j * XCH) = pack_bf16x2(xv[p][i][0][j], xv[p][i][1][j]);
+            }
+#pragma unroll
+        for (int i = 0; i < NID; ++i)
+            if (NT * (i + 1) <= DP || tid + NT * i < DP) {
+                unsigned char *dst = dyt + p * NB * DCH + d_dst[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<unsigned *>(dst + j * DCH) = pack_bf16x2(dv[p][i][0][j], dv[p][i][1][j]);
+            }
+    };
+
+    const unsigned char *a_base = dyt + (wn * 32 + li) * DCH + g * 16;
+    const unsigned char *b_base = xt + (wc * 32 + li) * XCH + g * XROW;
+
+    if (g_begin < g_end) {
+#pragma unroll
+        for (int p = 0; p < PB; ++p) fetch(g_begin, p);
+    }
+    for (int gi = g_begin; gi < g_end; ++gi) {
+        __syncthreads();   // fragment reads of the previous group are done
+#pragma unroll
+        for (int p = 0; p < PB; ++p) store(p);
+        __syncthreads();
+        if (gi + 1 < g_end) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) fetch(gi + 1, p);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {   // 16 pixels per MFMA: patch rows 2q (g = 0) and 2q + 1 (g = 1)
+                const bf16x8 av = *reinterpret_cast<const bf16x8 *>(a_base + p * NB * DCH + (2 * q) * 16);
+#pragma unroll
+                for (int r = 0; r < KS; ++r) {
+                    const unsigned char *row = b_base + p * CB * XCH + (2 * q + r) * XROW;
+                    const u32x4 lo = *reinterpret_cast<const u32x4 *>(row);
+                    if (KS == 1) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, lo), acc[0], 0, 0, 0);
+                    } else {
+                        const unsigned hi = *reinterpret_cast<const unsigned *>(row + 16);
+                        u32x4 s1, s2;
+                        s1[0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
+                        s1[1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
+                        s1[2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16);
+                        s1[3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
+                        s2[0] = lo[1]; s2[1] = lo[2]; s2[2] = lo[3]; s2[3] = hi;
+                        acc[r * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, lo), acc[r * 3 + 0], 0, 0, 0);
+                        acc[r * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s1), acc[r * 3 + 1], 0, 0, 0);
+                        acc[r * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s2), acc[r * 3 + 2], 0, 0, 0);
+                    }
+                }
+            }
+    }
+    // ---- epilogue: partial[ks][tap][n][c];  D row = n, D col (lane) = c
+    const int c = c0 + wc * 32 + li;
+    if (c < a.Cin && c - cbase < Cs) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (n < a.Cout) a.partial[(((size_t)ks * T + t) * a.Cout + n) * a.Cin + c] = acc[t][r];
+            }
+    }
+}
+
+template <int KS, int WN, int WC>
+static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
+    using Cfg = WgB16Cfg<KS, WN, WC>;
+    auto kern = wgrad_bf16_kernel<KS, WN, WC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)Cfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.ksplit * a.n_tiles * a.c_tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+
+bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride) {
+    if (a.small || stride != 1 || (ks != 3 && ks != 1)) return false;
+    if (a.Wout != a.Win || a.Hout != a.Hin) return false;
+    for (int i = 0; i < a.nsrc; ++i)
+        if (a.src[i].C % 4) return false;
+    return a.dy_ld % 4 == 0;
+}
+
+// the main kernel of launch_wgrad in mixed-precision mode (the split-K reduce is shared); WN / WC as planned
+hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st) {
+#define WG16(KS_)                                                   \
+    if (WN == 2 && WC == 2) return launch_wg16<KS_, 2, 2>(a, st);   \
+    if (WN == 4) return launch_wg16<KS_, 4, 1>(a, st);              \
+    if (WN == 2) return launch_wg16<KS_, 2, 1>(a, st);              \
+    return launch_wg16<KS_, 1, 1>(a, st);
+    if (ks == 3) { WG16(3) }
+    WG16(1)
+#undef WG16
+}
+
+}  // namespace mc

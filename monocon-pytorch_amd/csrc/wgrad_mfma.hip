@@ -364,6 +364,9 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
         int WN, WC;
         wgrad_shape(a, &WN, &WC);
         if (!wgrad_sources_ok(a)) return hipErrorInvalidValue;
+        if (a.prec == 1 && wgrad_bf16_ok(a, ks, stride)) {
+            e = launch_wgrad_bf16(a, ks, WN, WC, st);
+        } else {
 #define WG_DISPATCH(KS_, S_)                                                     \
     if (WN == 4) e = launch_wg<KS_, S_, 4, 1>(a, st);                            \
     else if (WN == 2 && WC == 2) e = launch_wg<KS_, S_, 2, 2>(a, st);            \
@@ -373,6 +376,7 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
         else if (ks == 3 && stride == 2) { WG_DISPATCH(3, 2) }
         else if (ks == 1 && stride == 1) { WG_DISPATCH(1, 1) }
 #undef WG_DISPATCH
+        }
     }
     if (e != hipSuccess) return e;
     const size_t total = (size_t)ks * ks * a.Cout * a.Cin;

@@ -132,3 +132,38 @@ def test_train_step_bf16_runs_and_tracks_fp32(golden_sd):
     # to cos 0.65 (heads 0.75-0.95, neck 0.8-0.87, backbone 0.63-0.77, norms within 10 %); a wrong tap or
     # panel in the bf16 data-gradient path would drive everything upstream of it to ~0
     assert cos > 0.5, cos
+
+
+WG_CASES = [
+    # (name, B, H, W, [Cin...], Cout, k)
+    ("b16wg_64_64", 2, 16, 24, [64], 64, 3),
+    ("b16wg_128_128", 2, 12, 40, [128], 128, 3),
+    ("b16wg_cat_64_64", 2, 8, 16, [64, 64], 64, 3),
+    ("b16wg_odd_edges", 1, 6, 10, [32], 64, 3),
+    ("b16wg_head_64_576", 1, 8, 16, [64], 576, 3),
+    ("b16wg_k1_root4", 1, 12, 16, [128, 128, 64, 128], 128, 1),
+    ("b16wg_k1_32_64", 2, 8, 8, [32], 64, 1),
+    ("b16wg_256_256_12x24", 2, 12, 24, [256], 256, 3),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_wgrad_bf16_operands(eng16, case):
+    """weight gradient with both operands (dY, X) rounded to bf16, fp32 accumulation over the pixels."""
+    name, B, H, W, cins, cout, k = case
+    seed = 800 + WG_CASES.index(case)
+    xs = [rnd(seed, "x%d" % i, (B, c, H, W)) for i, c in enumerate(cins)]
+    dy = rnd(seed, "dy", (B, cout, H, W))
+
+    def ref(xcat, d):
+        w = torch.zeros(cout, sum(cins), k, k, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xcat, w, None, 1, k // 2).backward(d)
+        return w.grad
+    exact = ref(torch.cat(xs, 1).double(), dy.double())
+    rounded = ref(torch.cat(xs, 1).bfloat16().double(), dy.bfloat16().double())
+    dev = eng16.device
+    got = eng16.op_conv_wgrad([nhwc(x).to(dev) for x in xs], nhwc(dy).to(dev), k, 1).cpu()
+    assert got.shape == exact.shape
+    assert rel_err(got, rounded) < 2e-5
+    e = rel_err(got, exact)
+    assert 1e-5 < e < 2e-2, e
