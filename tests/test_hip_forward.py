@@ -58,6 +58,23 @@ def test_forward_vs_oracle_other_shape(eng):
         assert rel_err(v.cpu(), ref[k]) < TOL, k
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 128), (2, 128, 512), (5, 64, 64), (2, 32, 2048), (1, 160, 1280)],
+                         ids=lambda s: "B%d_%dx%d" % s)
+def test_forward_shape_sweep_vs_oracle(eng, shape):
+    """batch 1 / odd batches / widths that do and do not qualify for the 16-channel row kernels (Wout % 16),
+    a single patch row, the full KITTI width: every shape goes through plan build + autotuning and must match
+    the CPU oracle (TOL_F32: the oracle runs in fp32 here, see TOL comment above)."""
+    from oracle import monocon_oracle as O
+    B, H, W = shape
+    img = synth.make_batch(1000 + B + H + W, B, H, W, with_labels=False)["img"]
+    sd = {k: v.cpu() for k, v in eng.state.items()}
+    with torch.no_grad():
+        ref, _, _ = O.forward(sd, img)
+    preds = eng.forward_infer(img.to(eng.device))
+    for k, v in preds.items():
+        assert rel_err(v.cpu(), ref[k]) < TOL_F32, (k, shape)
+
+
 def test_repack_follows_parameter_update(eng):
     """in-place update of a master weight must be picked up (``_version`` tracking)."""
     img = synth.make_batch(5, 1, 64, 64, with_labels=False)["img"].to(eng.device)

@@ -124,3 +124,30 @@ def test_train_step_with_fused_optimizer_reduces_loss(golden_sd):
     m.eval()
     out = m({"img": batch["img"]})
     assert all(torch.isfinite(v).all() for v in out.values())
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 128), (2, 128, 512), (5, 96, 160)], ids=lambda s: "B%d_%dx%d" % s)
+def test_train_forward_shape_sweep_vs_oracle(golden_sd, shape):
+    """odd batches / other resolutions through the train plan (autotuned conv shapes, 16-channel row kernels
+    where the width allows, parity-class stride-2 data gradients): losses vs the CPU oracle's train forward,
+    gradients finite and of the oracle's total norm."""
+    from model import MonoConDetector
+    from oracle import monocon_oracle as O
+    B, H, W = shape
+    batch = synth.make_batch(2000 + B + H + W, B, H, W)
+    live = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+            for k, v in golden_sd.items()}
+    _, _, L, _ = O.train_forward(live, batch)
+    sum(L.values()).backward()
+    ref_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in live.values()
+                                    if getattr(p, "grad", None) is not None)))
+    m = MonoConDetector(34, pretrained_backbone=False)
+    m.load_state_dict(golden_sd, strict=True)
+    m = m.cuda().train()
+    _, loss = m(to_cuda(batch))
+    sum(loss.values()).backward()
+    for k, v in loss.items():
+        assert abs(float(v) - float(L[k])) <= 2e-3 * abs(float(L[k])) + 1e-4, (k, float(v), float(L[k]))
+    g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+    assert bool(torch.isfinite(g).all())
+    assert abs(float(g.double().norm()) - ref_norm) <= 0.05 * ref_norm, (float(g.double().norm()), ref_norm)
