@@ -1,7 +1,7 @@
 // Train-mode element-wise / reduction kernels (NHWC fp32, 16-byte accesses, all HBM-bound):
 // BatchNorm batch statistics + running-stat update, normalise(+residual)+ReLU, the masked
 // reductions and the affine back-substitution of BatchNorm / AttnBN backward, max-pool and
-// depthwise-deconv backward, gradient dilation for stride-2 dgrad, layout packing.
+// depthwise-deconv backward, layout packing.
 //
 // Replaces the autograd graph torch builds for nn.BatchNorm2d / ReLU / residual add / MaxPool2d /
 // ConvTranspose2d in the reference's BasicBlock, Root, Tree, Conv2dBlock, IDAUp
@@ -372,26 +372,6 @@ hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *part
     hipError_t e = launch_chan_reduce(x, nullptr, nullptr, nullptr, 1, (int)rows, ld, 0, 0, partial, ld, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, st, partial, chan_reduce_blocks(1, (int)rows), ld, out);
-    return hipGetLastError();
-}
-
-// stride-2 dgrad helper: out (B,2H,2W,C) = zeros with out[2y,2x] = in[y,x]
-__global__ void dilate2_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4, f32x4 *__restrict__ out) {
-    const size_t total = (size_t)B * 4 * H * W * C4;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int c = e % C4;
-        const size_t p = e / C4;
-        const int ox = p % (2 * W), oy = (p / (2 * W)) % (2 * H);
-        const size_t b = p / ((size_t)4 * W * H);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!(ox & 1) && !(oy & 1)) v = in[((b * H + (oy >> 1)) * W + (ox >> 1)) * C4 + c];
-        out[e] = v;
-    }
-}
-hipError_t launch_dilate2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st) {
-    const size_t total = (size_t)B * 4 * H * W * (C / 4);
-    hipLaunchKernelGGL(dilate2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(in), B,
-                       H, W, C / 4, reinterpret_cast<f32x4 *>(out));
     return hipGetLastError();
 }
 

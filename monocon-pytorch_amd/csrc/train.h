@@ -69,7 +69,6 @@ hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, co
 hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st);
 size_t colsum_partial_floats(size_t rows, int ld);
 hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st);
-hipError_t launch_dilate2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
 hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
                                hipStream_t st);
 hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C, const float *wpk, float *din,
