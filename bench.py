@@ -112,11 +112,19 @@ def main():
         raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
                          % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # test hook (1-GPU box): MONOCON_BENCH_BACKEND=gloo runs all ranks on device 0 over gloo, to exercise the
+    # N > 1 control flow (barriers, max over ranks, gradient all-reduce) where RCCL refuses a shared device
+    backend = os.environ.get("MONOCON_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
     torch.cuda.set_device(local)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from hipmonocon import synth
     from model import MonoConDetector
