@@ -483,14 +483,15 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
             return 0;
         });
         float *xp = xh.p, *hp = hn.p, *rawp = raw.p;
+        // one closure per kernel family so that mc_profile_train attributes the durations correctly
+        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(c3, 3, 1, st)); return 0; });
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_conv(c3, 3, 1, st));
             HIPCHK(hh, launch_attn_train_fwd(at, st));
             HIPCHK(hh, launch_affine_act(xp, scale, shift, nullptr, B, (size_t)HW, CP, 1, 1, hp, st));
-            HIPCHK(hh, launch_conv(c1, 1, 1, st));
-            HIPCHK(hh, launch_head_act(rawp, LD, B, HW, ts->preds, st));
             return 0;
         });
+        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(c1, 1, 1, st)); return 0; });
+        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_head_act(rawp, LD, B, HW, ts->preds, st)); return 0; });
     }
     // targets + losses
     {
@@ -798,6 +799,9 @@ int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], dou
             (void)hipEventElapsedTime(&t, ev[2 * j], ev[2 * j + 1]);
             const int k = tag[j].kind;
             ms[k] += t; flops[k] += tag[j].flops; bytes[k] += tag[j].bytes; launches[k] += 1;
+            if (it == 0 && std::getenv("MONOCON_HIP_PROFILE_DUMP"))
+                std::fprintf(stderr, "prof %zu %s kind %d ms %.4f gflop %.3f mb %.2f\n", j, j < ts->fwd.size() ? "fwd" : "bwd", k, t,
+                             tag[j].flops * 1e-9, tag[j].bytes * 1e-6);
         }
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
