@@ -202,6 +202,16 @@ int mc_op_nchw_to_nhwc(mc_handle *h, const float *in, int B, int C, int H, int W
 int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W, float *out,
                        void *stream);
 
+/* ---- input pipeline -----------------------------------------------------
+ * Replaces Normalize + Pad + ToTensor of the reference's test / train transform lists
+ * (transforms/default_transforms.py:375-452, dataset/monocon_dataset.py:32-33,39-40) for one image that is
+ * already on the device: HWC (dtype 0 = float32, 2 = uint8; 3 channels) -> CHW float32 of shape
+ * (3, pad_h, pad_w), value (x - mean[c]) / std[c] evaluated in float64 and rounded once to float32 exactly as
+ * numpy + torch.Tensor() do, zeros outside (H, W).  Write B images into one (B,3,pad_h,pad_w) batch by calling
+ * it B times with out_chw advanced by 3*pad_h*pad_w. */
+int mc_preprocess(mc_handle *h, const void *img_hwc, int dtype, int H, int W, const double mean[3],
+                  const double std[3], int pad_h, int pad_w, float *out_chw, void *stream);
+
 /* Measurement aid for bench.py: re-runs the launches of the last mc_forward_train + mc_backward
  * `iters` times with a HIP event pair around every launch group on `stream` and returns, per
  * kernel family k (0 = everything else, 1 = conv_mfma_kernel: forward convs + data gradients,

@@ -83,4 +83,7 @@ struct DecodeArgs {
 };
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t st);
 
+hipError_t launch_preprocess(const void *img_hwc, int is_u8, int H, int W, const double mean[3], const double std[3], int Hp,
+                             int Wp, float *out_chw, hipStream_t st);
+
 }  // namespace mc

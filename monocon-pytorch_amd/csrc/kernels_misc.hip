@@ -435,4 +435,39 @@ hipError_t launch_head_apply(const HeadApplyArgs &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ============================================================================ input pipeline
+// Normalize + Pad + ToTensor of the reference's default transforms (transforms/default_transforms.py:375-433,
+// 436-452) for one image already in HBM: HWC (uint8 or float32) -> CHW float32, (x - mean[c]) / std[c] evaluated
+// in float64 and rounded once (numpy broadcasts the float64 mean / std arrays, torch.Tensor() then rounds to
+// float32), zero padding to (Hp, Wp).  One thread per output pixel; HBM-bound (3 B or 12 B in, 12 B out).
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const T *__restrict__ in, int H, int W, double m0, double m1,
+                                                         double m2, double s0, double s1, double s2, int Hp, int Wp,
+                                                         float *__restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= Wp) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if (y < H && x < W) {
+        const T *p = in + ((size_t)y * W + x) * 3;
+        v0 = (float)(((double)p[0] - m0) / s0);
+        v1 = (float)(((double)p[1] - m1) / s1);
+        v2 = (float)(((double)p[2] - m2) / s2);
+    }
+    const size_t plane = (size_t)Hp * Wp, o = (size_t)y * Wp + x;
+    out[o] = v0;
+    out[plane + o] = v1;
+    out[2 * plane + o] = v2;
+}
+hipError_t launch_preprocess(const void *img_hwc, int is_u8, int H, int W, const double mean[3], const double std[3], int Hp,
+                             int Wp, float *out_chw, hipStream_t st) {
+    dim3 grid((Wp + 255) / 256, Hp);
+    if (is_u8)
+        hipLaunchKernelGGL(preprocess_kernel<unsigned char>, grid, dim3(256), 0, st, static_cast<const unsigned char *>(img_hwc),
+                           H, W, mean[0], mean[1], mean[2], std[0], std[1], std[2], Hp, Wp, out_chw);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<float>, grid, dim3(256), 0, st, static_cast<const float *>(img_hwc), H, W, mean[0],
+                           mean[1], mean[2], std[0], std[1], std[2], Hp, Wp, out_chw);
+    return hipGetLastError();
+}
+
 }  // namespace mc

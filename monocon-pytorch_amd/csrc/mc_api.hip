@@ -864,6 +864,19 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
     return 0;
 }
 
+int mc_preprocess(mc_handle *h, const void *img_hwc, int dtype, int H, int W, const double mean[3], const double std[3],
+                  int pad_h, int pad_w, float *out_chw, void *stream) {
+    if (!h) return -1;
+    if (!img_hwc || !mean || !std || !out_chw) return fail(h, "mc_preprocess: null argument");
+    if (dtype != 0 && dtype != 2) return fail(h, "mc_preprocess: dtype must be 0 (float32) or 2 (uint8)");
+    if (H < 1 || W < 1 || pad_h < H || pad_w < W) return fail(h, "mc_preprocess: bad shape %dx%d -> %dx%d", H, W, pad_h, pad_w);
+    for (int c = 0; c < 3; ++c)
+        if (std[c] == 0.0) return fail(h, "mc_preprocess: std[%d] is zero", c);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_preprocess(img_hwc, dtype == 2, H, W, mean, std, pad_h, pad_w, out_chw, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int mc_bench_mfma_peak(mc_handle *h, int waves_per_simd, int iters, float *tflops) {
     if (!h || !tflops) return fail(h, "mc_bench_mfma_peak: null argument");
     HIPCHK(h, hipSetDevice(h->device));

@@ -279,6 +279,30 @@ class Engine:
         return dict(zip(PRED_KEYS, d))
 
     # ------------------------------------------------------------------ op level (tests)
+    # ------------------------------------------------------------------ input pipeline
+    def preprocess(self, images, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), size_divisor=32):
+        """Normalize + Pad + ToTensor + collate on the GPU: a list of HWC uint8 / float32 CUDA tensors (sizes may
+        differ) -> ((B,3,Hp,Wp) float32 batch, [(Hp, Wp)] * B); Hp, Wp = the largest image rounded up to
+        ``size_divisor`` (the reference pads every image of a KITTI batch to the same 384x1248/1280)."""
+        if not images:
+            raise _lib.MonoconHipError("preprocess: empty image list")
+        for t in images:
+            _need_cuda(t, "image")
+            if t.dim() != 3 or t.shape[2] != 3 or t.dtype not in (torch.uint8, torch.float32) or not t.is_contiguous():
+                raise _lib.MonoconHipError("preprocess: images must be contiguous (H,W,3) uint8 or float32 tensors")
+        d = int(size_divisor)
+        Hp = max((int(t.shape[0]) + d - 1) // d * d for t in images)
+        Wp = max((int(t.shape[1]) + d - 1) // d * d for t in images)
+        out = torch.empty((len(images), 3, Hp, Wp), dtype=torch.float32, device=images[0].device)
+        m = (C.c_double * 3)(*[float(v) for v in mean])
+        s = (C.c_double * 3)(*[float(v) for v in std])
+        with torch.cuda.device(out.device):
+            for b, t in enumerate(images):
+                rc = self.lib.mc_preprocess(self.h, _ptr(t), 2 if t.dtype == torch.uint8 else 0, int(t.shape[0]),
+                                            int(t.shape[1]), m, s, Hp, Wp, _ptr(out[b]), _stream())
+                _lib.check(self.h, rc, "mc_preprocess")
+        return out, [(Hp, Wp)] * len(images)
+
     def set_precision(self, mode):
         """0 = fp32 (parity path), 1 = bf16 MFMA operands with fp32 accumulation (config 3)."""
         _lib.check(self.h, self.lib.mc_set_precision(self.h, int(mode)), "mc_set_precision")

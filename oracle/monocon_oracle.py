@@ -13,6 +13,8 @@ parameters, and stores its outputs under ``tests/golden/``;
 ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
 import this module -- and only as the checker / the timed CPU baseline.  Nothing
 under ``monocon-pytorch_amd/`` imports it.
+One function is NOT pinned: ``preprocess`` (Normalize / Pad / ToTensor) -- the reference module it
+restates imports ``cv2`` at module level, which this image lacks, so no golden could be recorded for it.
 
 Each function cites the reference lines it follows (paths relative to the
 reference repository root).
@@ -480,3 +482,22 @@ def train_forward(sd, batch):
     T = make_targets(batch["label"], batch["img_metas"]["pad_shape"][0], tuple(feat.shape))
     L = losses(preds, T)
     return preds, T, L, newbuf
+
+
+# ------------------------------------------------------------------ input pipeline
+def preprocess(img_hwc, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), size_divisor=32):
+    """reference transforms/default_transforms.py:375-452 (Normalize -> Pad -> ToTensor, the tail of
+    dataset/monocon_dataset.py:32-33,39-40): ``img.astype(float32)``, ``(img - mean) / std`` with float64
+    mean / std arrays (numpy promotes to float64), zero canvas rounded up to ``size_divisor``,
+    ``torch.Tensor(...)`` (-> float32) and HWC -> CHW.  Returns (tensor (3,Hp,Wp), (Hp, Wp)).
+    parity unpinned for this function: the reference module imports cv2, which this image lacks, so it
+    cannot be imported to record a golden; the restatement follows the source line by line."""
+    img = np.asarray(img_hwc).astype(np.float32)
+    norm = (img - np.array(mean).reshape(1, 1, -1)) / np.array(std).reshape(1, 1, -1)
+    h, w = norm.shape[:2]
+    hp = int(np.ceil(h / size_divisor)) * size_divisor
+    wp = int(np.ceil(w / size_divisor)) * size_divisor
+    canvas = np.zeros((hp, wp, 3), dtype=norm.dtype)
+    canvas[:h, :w, :] = norm
+    return torch.Tensor(canvas).permute(2, 0, 1).contiguous(), (hp, wp)
+
