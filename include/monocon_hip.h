@@ -223,7 +223,9 @@ int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], dou
 /* Arithmetic of the convolutions (forward + data gradients).  0 (default): fp32 MFMA -- the parity
  * path.  1: both MFMA operands rounded to bf16 on their way into the matrix pipe, fp32 accumulation,
  * fp32 activations / master weights / BN statistics / losses (BASELINE config 3; not within the 1e-4
- * parity tolerance).  Re-pack (mc_pack_params) before the next forward. */
+ * parity tolerance).  2: fp32 EMULATED on the bf16 pipe -- both operands split into three bf16 pieces, six
+ * partial products per multiply accumulated in fp32; as close to the fp64 reference as the fp32 MFMA path (same
+ * parity tolerances), ~2.7x its matrix rate.  Re-pack (mc_pack_params) before the next forward. */
 int mc_set_precision(mc_handle *h, int mode);
 /* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
  * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel, 32 = the LDS-free

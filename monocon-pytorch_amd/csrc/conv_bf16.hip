@@ -13,7 +13,14 @@
 //   * one ds_read_b128 is the whole A operand of one MFMA (pixel li, channels 8g..8g+7 of a K=16 step).
 //   * weights are pre-packed as bf16 panels [tap][Cin/8][CoutP][8] (mc_pack_params), one 16-byte load
 //     per 32 output channels and MFMA.
-// Not the parity path: results differ from the fp32 reference by bf16 operand rounding (~1e-3
+// SPL = 3 (mc_set_precision(h, 2)): fp32 EMULATION.  Each fp32 operand is split into three bf16 pieces
+// (x = h + m + l exactly to 24 bits: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)) -- activations while they
+// are staged into three LDS planes, weights when the panels are packed -- and every product a*b is the sum of the six
+// partial products of weight >= 2^-24 (h*l, l*h, m*m, h*m, m*h, h*h; each exact in the fp32 accumulator, added small
+// to large).  Six bf16 MFMAs cost 192 cycles per K=16 against 512 for eight fp32 MFMAs, and the result is as close
+// to the fp64 reference as the fp32 FMA chain (measured: worst prediction map 5.0e-5 vs 5.3e-5, scratch/emu_split.py).
+//
+// SPL = 1 is not the parity path: results differ from the fp32 reference by bf16 operand rounding (~1e-3
 // norm-wise per layer); tests/test_hip_bf16.py states the tolerance.  Selected per handle with
 // mc_set_precision(h, 1); layers whose sources are not multiples of 32 channels stay on the fp32 kernels.
 #include "conv_mfma.h"
@@ -23,20 +30,22 @@ namespace mc {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int S, int WM, int WN, int WTM, int WTN>
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL>
 struct ConvCfgB16 {
     static constexpr int CK = 32;
     static constexpr int PB = WM * WTM, BNT = WN * WTN * 32, NT = 64 * WM * WN;
     static constexpr int KH = win_h(KS), KW = win_w(KS), PAD = win_pad(KS);
     static constexpr int IH = 3 * S + KH, IW = 7 * S + KW, NPIX = IH * IW;
     static constexpr int ROWB = (CK + 8) * 2;                      // bytes per staged pixel
-    static constexpr int TILE_BYTES = PB * NPIX * ROWB;
+    static constexpr int PLANE_BYTES = PB * NPIX * ROWB;          // one bf16 piece of the halo tile
+    static constexpr int TILE_BYTES = SPL * PLANE_BYTES;
     static constexpr size_t LDS_BYTES = TILE_BYTES + PB * 16 + 2 * WM * BNT * sizeof(float);
 };
 
-template <int KS, int S, int WM, int WN, int WTM, int WTN>
-__global__ __launch_bounds__(64 * WM * WN, 3) void conv_bf16_kernel(const ConvArgs a) {
-    using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN>;
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL>
+__global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kernel(const ConvArgs a) {
+    using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
+    constexpr int PLANE = Cfg::PLANE_BYTES;
     constexpr int CK = Cfg::CK, PB = Cfg::PB, BNT = Cfg::BNT, NT = Cfg::NT, PAD = Cfg::PAD;
     constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, ROWB = Cfg::ROWB;
     constexpr int C4 = CK / 4;
@@ -88,25 +97,31 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_bf16_kernel(const ConvAr
         a_off[tm] = ((wm * WTM + tm) * NPIX + ((li >> 3) * S) * IW + (li & 7) * S) * ROWB + g * 16;
 
     const int Cin8 = a.Cin >> 3;
-    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk16, (unsigned)(Cfg::KH * Cfg::KW * a.Cin * a.CoutP) * 2u);
+    const int w_plane = Cfg::KH * Cfg::KW * a.Cin * a.CoutP * 2;   // bytes of one bf16 piece of the panel
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk16, (unsigned)(SPL * w_plane));
     const int w_lane = (g * a.CoutP + n0 + wn * WTN * 32 + li) * 16;   // bytes
 
     constexpr int KSTEPS = CK / 16, NS = Cfg::KH * Cfg::KW * KSTEPS;
-    auto load_b = [&](bf16x8(&dst)[WTN], int kc, int s) {
+    auto load_b = [&](bf16x8(&dst)[SPL][WTN], int kc, int s) {
         const int tap = s / KSTEPS, m = s % KSTEPS;
         const int soff = (tap * Cin8 + ((kc + m * 16) >> 3)) * a.CoutP * 16;
 #pragma unroll
-        for (int tn = 0; tn < WTN; ++tn)
-            dst[tn] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, w_lane + tn * 32 * 16, soff, 0));
+        for (int q = 0; q < SPL; ++q)
+#pragma unroll
+            for (int tn = 0; tn < WTN; ++tn)
+                dst[q][tn] = __builtin_bit_cast(
+                    bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, w_lane + tn * 32 * 16, soff + q * w_plane, 0));
     };
-    auto load_a = [&](bf16x8(&dst)[WTM], int s) {
+    auto load_a = [&](bf16x8(&dst)[SPL][WTM], int s) {
         const int tap = s / KSTEPS, m = s % KSTEPS;
 #pragma unroll
-        for (int tm = 0; tm < WTM; ++tm)
-            dst[tm] = *reinterpret_cast<const bf16x8 *>(
-                lds_raw + a_off[tm] + ((tap / Cfg::KW) * IW + (tap % Cfg::KW)) * ROWB + m * 32);
+        for (int q = 0; q < SPL; ++q)
+#pragma unroll
+            for (int tm = 0; tm < WTM; ++tm)
+                dst[q][tm] = *reinterpret_cast<const bf16x8 *>(
+                    lds_raw + q * PLANE + a_off[tm] + ((tap / Cfg::KW) * IW + (tap % Cfg::KW)) * ROWB + m * 32);
     };
-    bf16x8 bcur[WTN];
+    bf16x8 bcur[SPL][WTN];
     load_b(bcur, 0, 0);
 
     int kbase = 0;
@@ -140,21 +155,30 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_bf16_kernel(const ConvAr
                 for (int u = 0; u < UB; ++u) {
                     const int i = i0 + u;
                     if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL)) {
-                        bf16x4 q;
+                        bf16x4 q[SPL];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) q[j] = (__bf16)v[u][j];
-                        *reinterpret_cast<bf16x4 *>(stage_dst + i * (NT / C4) * ROWB) = q;
+                        for (int j = 0; j < 4; ++j) {
+                            float r = v[u][j];
+#pragma unroll
+                            for (int pz = 0; pz < SPL; ++pz) {   // h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+                                q[pz][j] = (__bf16)r;
+                                r -= (float)q[pz][j];
+                            }
+                        }
+#pragma unroll
+                        for (int pz = 0; pz < SPL; ++pz)
+                            *reinterpret_cast<bf16x4 *>(stage_dst + pz * PLANE + i * (NT / C4) * ROWB) = q[pz];
                     }
                 }
             }
             __syncthreads();
             const int kc = kbase + c0;
             const int kc_next = (kc + CK < a.Cin) ? kc + CK : kc;
-            bf16x8 acur[WTM];
+            bf16x8 acur[SPL][WTM];
             load_a(acur, 0);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                bf16x8 anext[WTM], bnext[WTN];
+                bf16x8 anext[SPL][WTM], bnext[SPL][WTN];
                 if (s + 1 < NS) {
                     load_a(anext, s + 1);
                     load_b(bnext, kc, s + 1);
@@ -162,17 +186,27 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_bf16_kernel(const ConvAr
                     load_b(bnext, kc_next, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // partial products, smallest first: (piece of A, piece of B) with weight 2^-8*(i+j) >= 2^-16 relative
+                constexpr int NP = SPL == 1 ? 1 : 6;
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PBv[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-                for (int tm = 0; tm < WTM; ++tm)
+                for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
-                    for (int tn = 0; tn < WTN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[tm], bcur[tn], acc[tm][tn], 0, 0, 0);
+                    for (int tm = 0; tm < WTM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < WTN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                acur[SPL == 1 ? 0 : PA[pp]][tm], bcur[SPL == 1 ? 0 : PBv[pp]][tn], acc[tm][tn], 0, 0, 0);
                 if (s + 1 < NS) {
 #pragma unroll
-                    for (int tm = 0; tm < WTM; ++tm) acur[tm] = anext[tm];
+                    for (int q = 0; q < SPL; ++q)
+#pragma unroll
+                        for (int tm = 0; tm < WTM; ++tm) acur[q][tm] = anext[q][tm];
                 }
 #pragma unroll
-                for (int tn = 0; tn < WTN; ++tn) bcur[tn] = bnext[tn];
+                for (int q = 0; q < SPL; ++q)
+#pragma unroll
+                    for (int tn = 0; tn < WTN; ++tn) bcur[q][tn] = bnext[q][tn];
             }
         }
         kbase += Cs;
@@ -199,7 +233,8 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_bf16_kernel(const ConvAr
 // (transposed + flipped per source, or one output-parity class of a stride-2 data gradient; same tap
 // conventions as pack_conv_w_kernel / pack_conv_w_dgrad_kernel)
 __global__ void pack_conv_w_bf16_kernel(const float *__restrict__ w, int Cout, int Cin, int k, __bf16 *__restrict__ dst,
-                                        int CinPanel, int CoutP, int n_off, int c_off) {
+                                        int CinPanel, int CoutP, int n_off, int c_off, int nsplit) {
+    const size_t plane = (size_t)k * k * CinPanel * CoutP;
     const int kk = k * k;
     const size_t total = (size_t)Cout * Cin * kk;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -207,20 +242,26 @@ __global__ void pack_conv_w_bf16_kernel(const float *__restrict__ w, int Cout, i
         const int c = (e / kk) % Cin;
         const int n = e / ((size_t)kk * Cin);
         const int cc = c + c_off, nn = n + n_off;
-        dst[(((size_t)tap * (CinPanel >> 3) + (cc >> 3)) * CoutP + nn) * 8 + (cc & 7)] = (__bf16)w[e];
+        float r = w[e];
+        for (int q = 0; q < nsplit; ++q) {
+            const __bf16 piece = (__bf16)r;
+            dst[q * plane + (((size_t)tap * (CinPanel >> 3) + (cc >> 3)) * CoutP + nn) * 8 + (cc & 7)] = piece;
+            r -= (float)piece;
+        }
     }
 }
 hipError_t launch_pack_conv_w_bf16(const float *w, int Cout, int Cin, int k, void *dst, int CinPanel, int CoutP, int n_off,
-                                   int c_off, hipStream_t st) {
+                                   int c_off, int nsplit, hipStream_t st) {
     const size_t total = (size_t)Cout * Cin * k * k;
     size_t gsz = (total + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(pack_conv_w_bf16_kernel, dim3((unsigned)gsz), dim3(256), 0, st, w, Cout, Cin, k,
-                       static_cast<__bf16 *>(dst), CinPanel, CoutP, n_off, c_off);
+                       static_cast<__bf16 *>(dst), CinPanel, CoutP, n_off, c_off, nsplit);
     return hipGetLastError();
 }
 __global__ void pack_conv_w_dgrad_bf16_kernel(const float *__restrict__ w, int Cout, int CinTotal, int k, int c_off, int Cs,
-                                              int CsP, int CoutPad, int cls, __bf16 *__restrict__ dst) {
+                                              int CsP, int CoutPad, int cls, int nsplit, __bf16 *__restrict__ dst) {
+    const size_t plane = (size_t)(cls < 0 ? k * k : (1 + (cls >> 1)) * (1 + (cls & 1))) * CoutPad * CsP;
     const int kk = k * k;
     const size_t total = (size_t)Cout * Cs * kk;
     const int py = cls >> 1, px = cls & 1;
@@ -237,31 +278,36 @@ __global__ void pack_conv_w_dgrad_bf16_kernel(const float *__restrict__ w, int C
             const int dr = py ? (2 - r) / 2 : 0, ds = px ? (2 - s) / 2 : 0;
             tapd = dr * (1 + px) + ds;
         }
-        dst[(((size_t)tapd * (CoutPad >> 3) + (n >> 3)) * CsP + cl) * 8 + (n & 7)] =
-            (__bf16)w[(((size_t)n * CinTotal + c_off + cl) * k + r) * k + s];
+        float rem = w[(((size_t)n * CinTotal + c_off + cl) * k + r) * k + s];
+        for (int q = 0; q < nsplit; ++q) {
+            const __bf16 piece = (__bf16)rem;
+            dst[q * plane + (((size_t)tapd * (CoutPad >> 3) + (n >> 3)) * CsP + cl) * 8 + (n & 7)] = piece;
+            rem -= (float)piece;
+        }
     }
 }
 hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
-                                         int cls, void *dst, hipStream_t st) {
+                                         int cls, int nsplit, void *dst, hipStream_t st) {
     const size_t total = (size_t)Cout * Cs * k * k;
     size_t gsz = (total + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(pack_conv_w_dgrad_bf16_kernel, dim3((unsigned)gsz), dim3(256), 0, st, w, Cout, CinTotal, k, c_off, Cs,
-                       CsP, CoutPad, cls, static_cast<__bf16 *>(dst));
+                       CsP, CoutPad, cls, nsplit, static_cast<__bf16 *>(dst));
     return hipGetLastError();
 }
 
 // ---- dispatch
-template <int KS, int S, int WM, int WN, int WTM, int WTN>
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL>
 static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
-    using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN>;
+    using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
+    if (Cfg::LDS_BYTES > 160 * 1024) return hipErrorInvalidValue;
     a.ppr = (a.Wout + 7) / 8;
     a.ppi = a.ppr * ((a.Hout + 3) / 4);
     a.chunks = (a.ppi + Cfg::PB - 1) / Cfg::PB;
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
     static bool attr_set = false;
-    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN>;
+    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
@@ -272,15 +318,15 @@ static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved)
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * a.chunks * ntiles)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
     return hipGetLastError();
 }
-template <int KS, int S>
+template <int KS, int S, int SPL>
 static hipError_t launch_b16_shape(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
     switch (a.cfg & 15) {
-        case CFG_128x128: return launch_b16_one<KS, S, 2, 2, 2, 2>(a, st, resolved);
-        case CFG_128x64: return launch_b16_one<KS, S, 2, 2, 2, 1>(a, st, resolved);
-        case CFG_128x64m: return launch_b16_one<KS, S, 4, 1, 1, 2>(a, st, resolved);
-        case CFG_128x32: return launch_b16_one<KS, S, 4, 1, 1, 1>(a, st, resolved);
-        case CFG_64x128: return launch_b16_one<KS, S, 1, 4, 2, 1>(a, st, resolved);
-        case CFG_64x64: return launch_b16_one<KS, S, 2, 2, 1, 1>(a, st, resolved);
+        case CFG_128x128: return launch_b16_one<KS, S, 2, 2, 2, 2, SPL>(a, st, resolved);
+        case CFG_128x64: return launch_b16_one<KS, S, 2, 2, 2, 1, SPL>(a, st, resolved);
+        case CFG_128x64m: return launch_b16_one<KS, S, 4, 1, 1, 2, SPL>(a, st, resolved);
+        case CFG_128x32: return launch_b16_one<KS, S, 4, 1, 1, 1, SPL>(a, st, resolved);
+        case CFG_64x128: return launch_b16_one<KS, S, 1, 4, 2, 1, SPL>(a, st, resolved);
+        case CFG_64x64: return launch_b16_one<KS, S, 2, 2, 1, 1, SPL>(a, st, resolved);
         default: return hipErrorInvalidValue;
     }
 }
@@ -293,14 +339,19 @@ bool conv_bf16_ok(const ConvArgs &a, int ks, int stride) {
     return stride == 1 && (ks == 1 || ks == 12 || ks == 21 || ks == 22);
 }
 
+template <int SPL>
+static hipError_t launch_conv_b16_spl(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
+    if (ks == 3 && stride == 1) return launch_b16_shape<3, 1, SPL>(a, st, resolved);
+    if (ks == 3 && stride == 2) return launch_b16_shape<3, 2, SPL>(a, st, resolved);
+    if (ks == 1) return launch_b16_shape<1, 1, SPL>(a, st, resolved);
+    if (ks == 12) return launch_b16_shape<12, 1, SPL>(a, st, resolved);
+    if (ks == 21) return launch_b16_shape<21, 1, SPL>(a, st, resolved);
+    return launch_b16_shape<22, 1, SPL>(a, st, resolved);
+}
+
 hipError_t launch_conv_bf16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
     if (!conv_bf16_ok(a, ks, stride)) return hipErrorInvalidValue;
-    if (ks == 3 && stride == 1) return launch_b16_shape<3, 1>(a, st, resolved);
-    if (ks == 3 && stride == 2) return launch_b16_shape<3, 2>(a, st, resolved);
-    if (ks == 1) return launch_b16_shape<1, 1>(a, st, resolved);
-    if (ks == 12) return launch_b16_shape<12, 1>(a, st, resolved);
-    if (ks == 21) return launch_b16_shape<21, 1>(a, st, resolved);
-    return launch_b16_shape<22, 1>(a, st, resolved);
+    return a.prec == 2 ? launch_conv_b16_spl<3>(a, ks, stride, st, resolved) : launch_conv_b16_spl<1>(a, ks, stride, st, resolved);
 }
 
 }  // namespace mc

@@ -57,8 +57,9 @@ struct ConvArgs {
     // output / residual pixel mapping in floats (0 = dense NHWC: img = Hout*Wout*ld, row = Wout*ld, px = ld);
     // the stride-2 data-gradient classes scatter to every second pixel of a larger map
     int o_img, o_row, o_px, r_img, r_row, r_px;
-    // mixed precision (conv_bf16.hip): prec 1 = bf16 MFMA operands from the bf16 panel wpk16, fp32 everything else
-    const void *wpk16;       // [k*k][Cin/8][CoutP][8] bf16 or null
+    // conv_bf16.hip: prec 1 = bf16 MFMA operands from the bf16 panel wpk16 (fp32 everything else); prec 2 = fp32
+    // emulated by a 3-way bf16 split of both operands (six bf16 MFMAs per product, three panels in wpk16)
+    const void *wpk16;       // [pieces][k*k][Cin/8][CoutP][8] bf16 or null
     int prec;
 };
 
@@ -604,9 +605,9 @@ bool conv_small_ok(const ConvArgs &a, int ks, int stride);
 bool conv_bf16_ok(const ConvArgs &a, int ks, int stride);
 hipError_t launch_conv_bf16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved);
 hipError_t launch_pack_conv_w_bf16(const float *w, int Cout, int Cin, int k, void *dst, int CinPanel, int CoutP, int n_off,
-                                   int c_off, hipStream_t st);
+                                   int c_off, int nsplit, hipStream_t st);
 hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
-                                         int cls, void *dst, hipStream_t st);
+                                         int cls, int nsplit, void *dst, hipStream_t st);
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st);
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);

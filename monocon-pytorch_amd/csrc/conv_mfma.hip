@@ -113,7 +113,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
     }
     if (a.cfg == CFG_AUTO) a.cfg = conv_pick_cfg(a.Cout, a.CoutP, ks, stride, a.B, a.Hout, a.Wout);
     prof_last = conv_cost(a, ks);
-    if (a.prec == 1 && conv_bf16_ok(a, ks, stride)) return launch_conv_bf16(a, ks, stride, st, resolved);
+    if (a.prec >= 1 && conv_bf16_ok(a, ks, stride)) return launch_conv_bf16(a, ks, stride, st, resolved);
     if (ks == 3 && stride == 1) {
         return ck == 32 ? launch_shape<3, 1, 32>(a, st, resolved) : launch_shape<3, 1, 16>(a, st, resolved);
     } else if (ks == 3 && stride == 2) {

@@ -98,7 +98,7 @@ static int build_layers(mc_handle *h) {
         ConvLayer &L = kv.second;
         const size_t wn = (size_t)L.ks * L.ks * L.cin * L.coutp;
         if (dev_alloc(h, &L.wpk, wn, h->param_bufs, h->param_bytes)) return -1;
-        { float *q = nullptr; if (dev_alloc(h, &q, (wn + 1) / 2, h->param_bufs, h->param_bytes)) return -1; L.wpk16 = q; }
+        { float *q = nullptr; if (dev_alloc(h, &q, (3 * wn + 1) / 2, h->param_bufs, h->param_bytes)) return -1; L.wpk16 = q; }   // up to 3 bf16 pieces
         if (dev_alloc(h, &L.scale, L.cout, h->param_bufs, h->param_bytes)) return -1;
         if (dev_alloc(h, &L.shift, L.cout, h->param_bufs, h->param_bytes)) return -1;
     }
@@ -112,7 +112,7 @@ static int build_layers(mc_handle *h) {
     H3.cfg = CFG_128x64m;      // one head per 64-column tile
     H3.coutp = H3.cout;
     if (dev_alloc(h, &H3.wpk, (size_t)9 * 64 * H3.coutp, h->param_bufs, h->param_bytes)) return -1;
-    { float *q = nullptr; if (dev_alloc(h, &q, (size_t)9 * 64 * H3.coutp / 2, h->param_bufs, h->param_bytes)) return -1; H3.wpk16 = q; }
+    { float *q = nullptr; if (dev_alloc(h, &q, (size_t)3 * 9 * 64 * H3.coutp / 2, h->param_bufs, h->param_bytes)) return -1; H3.wpk16 = q; }
     if (dev_alloc(h, &h->head_bias, H3.cout, h->param_bufs, h->param_bytes)) return -1;
     if (dev_alloc(h, &h->head_rm, H3.cout, h->param_bufs, h->param_bytes)) return -1;
     if (dev_alloc(h, &h->att_scale, NUM_HEADS * NUM_AFFINE, h->param_bufs, h->param_bytes)) return -1;
@@ -272,9 +272,9 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     const bool small_ok = conv_small_ok(a_in, ks, stride);
     const int heuristic = small_ok ? (int)CFG_SMALL : conv_pick_cfg(a_in.Cout, a_in.CoutP, ks, stride, a_in.B, a_in.Hout, a_in.Wout);
     if (!h->autotune) return heuristic;
-    const bool b16 = a_in.prec == 1 && conv_bf16_ok(a_in, ks, stride);
+    const bool b16 = a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride);
     std::vector<int> key = {a_in.B, a_in.Hin, a_in.Win, ks, stride, a_in.Cout, a_in.CoutP, a_in.nsrc,
-                            (a_in.res ? 1 : 0) | (b16 ? 2 : 0)};
+                            (a_in.res ? 1 : 0) | (b16 ? 2 * a_in.prec : 0)};
     for (int i = 0; i < a_in.nsrc; ++i) key.push_back(a_in.src[i].C);
     auto it = h->tuned.find(key);
     if (it != h->tuned.end()) return it->second;
@@ -499,7 +499,7 @@ int mc_create(int device, mc_handle **out) {
     mc_handle *h = new mc_handle();
     h->device = device;
     if (const char *e = std::getenv("MONOCON_HIP_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MONOCON_HIP_PRECISION")) h->prec = (std::strcmp(e, "bf16") == 0 || std::strcmp(e, "1") == 0) ? 1 : 0;
+    if (const char *e = std::getenv("MONOCON_HIP_PRECISION")) h->prec = (std::strcmp(e, "bf16") == 0 || std::strcmp(e, "1") == 0) ? 1 : ((std::strcmp(e, "bf16x3") == 0 || std::strcmp(e, "2") == 0) ? 2 : 0);
     load_tune_cache(h);
     *out = h;
     return 0;
@@ -554,7 +554,8 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         if ((is_bb && !has_bb) || (!is_bb && !has_neck)) continue;
         NEEDP(w, L.conv + ".weight", (int64_t)L.cout * L.cin * L.ks * L.ks);
         HIPCHK(h, launch_pack_conv_w(w, L.cout, L.cin, L.ks, L.wpk, L.cin, L.coutp, 0, 0, st));
-        if (h->prec == 1 && L.cin % 8 == 0) HIPCHK(h, launch_pack_conv_w_bf16(w, L.cout, L.cin, L.ks, L.wpk16, L.cin, L.coutp, 0, 0, st));
+        if (h->prec >= 1 && L.cin % 8 == 0)
+            HIPCHK(h, launch_pack_conv_w_bf16(w, L.cout, L.cin, L.ks, L.wpk16, L.cin, L.coutp, 0, 0, h->prec == 2 ? 3 : 1, st));
         NEEDP(g, L.bn + ".weight", L.cout);
         NEEDP(b, L.bn + ".bias", L.cout);
         NEEDP(rm, L.bn + ".running_mean", L.cout);
@@ -584,7 +585,8 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         NEEDP(w3, pre + ".0.weight", 64 * 64 * 9);
         NEEDP(b3, pre + ".0.bias", 64);
         HIPCHK(h, launch_pack_conv_w(w3, 64, 64, 3, h->head3.wpk, 64, h->head3.coutp, hd * HEAD_CH, 0, st));
-        if (h->prec == 1) HIPCHK(h, launch_pack_conv_w_bf16(w3, 64, 64, 3, h->head3.wpk16, 64, h->head3.coutp, hd * HEAD_CH, 0, st));
+        if (h->prec >= 1)
+            HIPCHK(h, launch_pack_conv_w_bf16(w3, 64, 64, 3, h->head3.wpk16, 64, h->head3.coutp, hd * HEAD_CH, 0, h->prec == 2 ? 3 : 1, st));
         HIPCHK(h, launch_copy(b3, h->head_bias + hd * HEAD_CH, 64, st));
         const std::string an = pre + ".1";
         NEEDP(rm, an + ".running_mean", 64);
@@ -788,11 +790,12 @@ int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[],
     HIPCHK(h, launch_pack_conv_w(weight_oihw, Cout, cin, ksize, static_cast<float *>(wpk), cin, a.CoutP, 0, 0, st));
     a.wpk = static_cast<float *>(wpk);
     void *wpk16 = nullptr;
-    if (h->prec == 1 && cin % 8 == 0) {
-        HIPCHK(h, hipMalloc(&wpk16, wn * 2));
-        HIPCHK(h, hipMemsetAsync(wpk16, 0, wn * 2, st));
-        HIPCHK(h, launch_pack_conv_w_bf16(weight_oihw, Cout, cin, ksize, wpk16, cin, a.CoutP, 0, 0, st));
-        a.wpk16 = wpk16; a.prec = 1;
+    if (h->prec >= 1 && cin % 8 == 0) {
+        const int pieces = h->prec == 2 ? 3 : 1;
+        HIPCHK(h, hipMalloc(&wpk16, wn * 2 * pieces));
+        HIPCHK(h, hipMemsetAsync(wpk16, 0, wn * 2 * pieces, st));
+        HIPCHK(h, launch_pack_conv_w_bf16(weight_oihw, Cout, cin, ksize, wpk16, cin, a.CoutP, 0, 0, pieces, st));
+        a.wpk16 = wpk16; a.prec = h->prec;
     }
     a.scale = scale; a.bias = bias; a.res = residual; a.res_ld = Cout;
     a.out = out; a.out_ld = Cout; a.out_coff = 0; a.relu = relu;
@@ -973,7 +976,8 @@ int mc_set_conv_cfg(mc_handle *h, int cfg) {
 
 int mc_set_precision(mc_handle *h, int mode) {
     if (!h) return -1;
-    if (mode != 0 && mode != 1) return fail(h, "mc_set_precision: mode must be 0 (fp32) or 1 (bf16 MFMA operands)");
+    if (mode < 0 || mode > 2)
+        return fail(h, "mc_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 MFMA operands) or 2 (fp32 emulated by a 3-way bf16 split)");
     if (mode == h->prec) return 0;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());

@@ -253,7 +253,7 @@ struct TB {   // train plan builder
         j.CsP = conv_coutp(Cs); j.CoutPad = CoutPad; j.cls = cls;
         const int taps = cls < 0 ? k * k : (1 + (cls >> 1)) * (1 + (cls & 1));
         j.dst = alloc((size_t)taps * CoutPad * j.CsP);
-        j.dst16 = (h->prec == 1 && CoutPad % 8 == 0) ? alloc(((size_t)taps * CoutPad * j.CsP + 1) / 2) : nullptr;
+        j.dst16 = (h->prec >= 1 && CoutPad % 8 == 0) ? alloc((3 * (size_t)taps * CoutPad * j.CsP + 1) / 2) : nullptr;
         last_panel16 = j.dst16;
         ts->packs.push_back(j);
         *dst_out = j.dst;
@@ -717,7 +717,8 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
     for (const PackJob &j : ts->packs) {
         HIPCHK(h, launch_pack_conv_w_dgrad(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls, j.dst, st));
         if (j.dst16)
-            HIPCHK(h, launch_pack_conv_w_dgrad_bf16(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls, j.dst16, st));
+            HIPCHK(h, launch_pack_conv_w_dgrad_bf16(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls,
+                                                    h->prec == 2 ? 3 : 1, j.dst16, st));
     }
     for (auto &f : ts->fwd)
         if (f(h, st)) return -1;

@@ -110,7 +110,7 @@ class HipRuntime:
         self.precision = 0     # 0 fp32 (parity path), 1 bf16 MFMA operands (BASELINE config 3)
 
     def set_precision(self, mode):
-        self.precision = {"fp32": 0, "f32": 0, "bf16": 1}.get(mode, mode)
+        self.precision = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp32_split": 2}.get(mode, mode)
         if self.engine is not None:
             self.engine.set_precision(self.precision)
 

@@ -6,14 +6,14 @@ from hipmonocon.engine import Engine
 stats = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "bn_calib_seed7.npz"))
 sd = synth.make_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
 dsd = {k: v.cuda() for k, v in sd.items()}
-B = 32
-img = torch.randn((B, 3, 384, 1280), device="cuda")
-eng = Engine()
-for mode in [int(a) for a in sys.argv[1:]] or (0, 1, 2):
-    eng.set_precision(mode); eng.bind_state(dsd)
+eng = Engine(); eng.bind_state(dsd)
+for B in (1, 2, 4, 8):
+    img = torch.randn((B, 3, 384, 1280), device="cuda")
     for _ in range(3): eng.forward_infer(img)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): eng.forward_infer(img)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    n = 30
+    for _ in range(n): eng.forward_infer(img)
+    t_issue = (time.perf_counter() - t0) / n
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     pr = eng.profile_forward(iters=3)
-    print("mode", mode, "forward ms %.2f  img/s %.0f  conv_ms %.2f other_ms %.2f" % (dt * 1e3, B / dt, pr["conv_ms"], pr["other_ms"]))
+    print("B=%d  wall %.3f ms/forward (%.0f img/s)  cpu issue %.3f ms  gpu kernels %.3f ms (conv %.3f)" % (B, dt * 1e3, B / dt, t_issue * 1e3, pr["total_ms"], pr["conv_ms"]))

@@ -167,3 +167,53 @@ def test_wgrad_bf16_operands(eng16, case):
     assert rel_err(got, rounded) < 2e-5
     e = rel_err(got, exact)
     assert 1e-5 < e < 2e-2, e
+
+
+# ----------------------------------------------------------------------------------------------- mode 2: fp32 emulation
+@pytest.fixture()
+def eng_split():
+    from hipmonocon.engine import Engine
+    e = Engine()
+    e.set_precision(2)
+    yield e
+    e.set_precision(0)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0].replace("b16", "split") for c in CASES])
+def test_conv_split_emulation_is_fp32_accurate(eng_split, case):
+    """3-way bf16 split of both operands, six partial products, fp32 accumulation: held to the SAME tolerance as
+    the fp32 MFMA kernel (tests/test_hip_ops.py: 5e-6 norm-wise vs fp64), and agrees with that kernel to 2e-6."""
+    name, B, H, W, cins, cout, k, stride, use_res, relu = case
+    seed = 900 + CASES.index(case)
+    xs = [rnd(seed, "x%d" % i, (B, c, H, W)) for i, c in enumerate(cins)]
+    w = rnd(seed, "w", (cout, sum(cins), k, k), (2.0 / (k * k * sum(cins))) ** 0.5)
+    bias = 0.1 * rnd(seed, "bi", (cout,))
+    res = rnd(seed, "res", (B, cout, (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1)) if use_res else None
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), None, stride, k // 2) + bias.double()[None, :, None, None]
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    dev = eng_split.device
+    args = ([nhwc(x).to(dev) for x in xs], w.to(dev), stride, None, bias.to(dev), nhwc(res).to(dev) if use_res else None, relu)
+    got = eng_split.op_conv(*args).cpu()
+    eng_split.set_precision(0)
+    base = eng_split.op_conv(*args).cpu()
+    eng_split.set_precision(2)
+    assert rel_err(got.permute(0, 3, 1, 2), ref) < 5e-6
+    assert rel_err(got, base) < 2e-6
+
+
+def test_forward_split_emulation_meets_the_fp32_parity_gate(golden_sd):
+    """eval forward at 64x128 in mode 2 against the REFERENCE's fp64 golden: the same 1e-4 gate as the fp32 path."""
+    from conftest import load_golden
+    from hipmonocon.engine import Engine
+    eng = Engine()
+    eng.set_precision(2)
+    eng.bind_state({k: v.cuda() for k, v in golden_sd.items()})
+    img = synth.make_batch(GOLDEN_SEED + 1, 2, 64, 128, with_labels=False)["img"].cuda()
+    g = load_golden("fwd_small_eval.npz")
+    pred = eng.forward_infer(img)
+    worst = max(rel_err(v.cpu(), g["f64." + k]) for k, v in pred.items())
+    assert worst < 1e-4, worst
+    eng.set_precision(0)
