@@ -119,12 +119,14 @@ struct WgradArgs {
     float *partial;           // [ksplit][k*k][Cout][Cin]
     int ksplit, n_tiles, c_tiles, ppr, ppi, groups_per_img;
     int small;                // 1: 16-input-channel layer on the LDS-free 16x16x4 kernel (ksplit = workgroups)
-    int prec;                 // 1: bf16 MFMA operands where wgrad_bf16_ok() (wgrad_bf16.hip)
+    int prec;                 // 1: bf16 MFMA operands, 2: 3-way split fp32 emulation, where wgrad_bf16_ok() (wgrad_bf16.hip)
+    int pb;                   // 32-pixel patches per staged group (2, or 1 for the split kernel)
 };
 void wgrad_plan(WgradArgs &a, int ks, int stride);            // fills the tiling fields
 size_t wgrad_partial_floats(const WgradArgs &a, int ks);
 hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st);
 bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride);
 hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st);
+int wgrad_bf16_patches(int prec);
 
 }  // namespace mc

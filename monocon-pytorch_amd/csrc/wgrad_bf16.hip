@@ -13,6 +13,8 @@
 //   * staging: a thread loads the float4 (4 channels) of TWO horizontally adjacent pixels, rounds to bf16
 //     (RNE) and writes one packed dword per channel -- the transpose costs ds_write_b32, not ds_write_b16.
 //     Offsets, zero fill and the register prefetch across the MFMA phase are as in wgrad_mfma_kernel.
+//   * SPL = 3 (mode 2, fp32 emulation, see conv_bf16.hip): dY and X are each staged as three bf16 pieces and every tap
+//     accumulates the six partial products of weight >= 2^-16; one patch per staged group so two workgroups fit a CU.
 // Accumulation, split-K partials and the deterministic reduce stay fp32 (wgrad_reduce_kernel).
 // Stride-2 layers (five in DLA-34) and the 16-channel layers keep their fp32 kernels.
 #include <algorithm>
@@ -25,16 +27,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int WN, int WC>
+template <int KS, int WN, int WC, int SPL>
 struct WgB16Cfg {
-    static constexpr int PB = 2;
+    static constexpr int PB = SPL == 1 ? 2 : 1;                 // patches per staged group (WgradArgs::pb)
     static constexpr int NB = 32 * WN, CB = 32 * WC, NT = 64 * WN * WC;
     static constexpr int PAD = KS / 2;
     static constexpr int IH = 3 + KS, IW = 7 + KS;              // 6 x 10 (3x3) or 4 x 8 (1x1)
     static constexpr int XROW = KS == 3 ? 32 : 16;              // bytes per staged halo row (16 / 8 pixels)
     static constexpr int XCH = IH * XROW + 16;                  // bytes per channel (+16: spreads the b128 reads over banks)
     static constexpr int DCH = 4 * 16 + 16;                     // bytes per dY channel
-    static constexpr int X_BYTES = PB * CB * XCH, D_BYTES = PB * NB * DCH;
+    static constexpr int X_PLANE = PB * CB * XCH, D_PLANE = PB * NB * DCH;   // one bf16 piece of each tile
+    static constexpr int X_BYTES = SPL * X_PLANE, D_BYTES = SPL * D_PLANE;
     static constexpr size_t LDS_BYTES = X_BYTES + D_BYTES;
 };
 
@@ -45,9 +48,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int KS, int WN, int WC>
+template <int KS, int WN, int WC, int SPL>
 __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const WgradArgs a) {
-    using Cfg = WgB16Cfg<KS, WN, WC>;
+    using Cfg = WgB16Cfg<KS, WN, WC, SPL>;
+    constexpr int XPL = Cfg::X_PLANE, DPL = Cfg::D_PLANE;
     constexpr int PB = Cfg::PB, NB = Cfg::NB, CB = Cfg::CB, NT = Cfg::NT, PAD = Cfg::PAD;
     constexpr int IH = Cfg::IH, IW = Cfg::IW, XROW = Cfg::XROW, XCH = Cfg::XCH, DCH = Cfg::DCH;
     constexpr int T = KS * KS;
@@ -131,23 +135,29 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
             dv[p][i][1] = buf_load4(r_d, (xx >= 0 && xx + 1 < a.Wout) ? db + d_stat[i] + a.dy_ld * 4 : BUF_OOB, 0);
         }
     };
+    // piece q of (a, b): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (mode 2), packed pixel pair per channel
+    auto put = [&](unsigned char *dst, int plane, f32x4 v0, f32x4 v1, int chan_stride) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r0 = v0[j], r1 = v1[j];
+#pragma unroll
+            for (int q = 0; q < SPL; ++q) {
+                bf16x2 pr;
+                pr[0] = (__bf16)r0;
+                pr[1] = (__bf16)r1;
+                *reinterpret_cast<unsigned *>(dst + q * plane + j * chan_stride) = __builtin_bit_cast(unsigned, pr);
+                r0 -= (float)pr[0];
+                r1 -= (float)pr[1];
+            }
+        }
+    };
     auto store = [&](int p) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i)
-            if (NT * (i + 1) <= XP || tid + NT * i < XP) {
-                unsigned char *dst = xt + p * CB * XCH + x_dst[i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<unsigned *>(dst + j * XCH) = pack_bf16x2(xv[p][i][0][j], xv[p][i][1][j]);
-            }
+            if (NT * (i + 1) <= XP || tid + NT * i < XP) put(xt + p * CB * XCH + x_dst[i], XPL, xv[p][i][0], xv[p][i][1], XCH);
 #pragma unroll
         for (int i = 0; i < NID; ++i)
-            if (NT * (i + 1) <= DP || tid + NT * i < DP) {
-                unsigned char *dst = dyt + p * NB * DCH + d_dst[i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<unsigned *>(dst + j * DCH) = pack_bf16x2(dv[p][i][0][j], dv[p][i][1][j]);
-            }
+            if (NT * (i + 1) <= DP || tid + NT * i < DP) put(dyt + p * NB * DCH + d_dst[i], DPL, dv[p][i][0], dv[p][i][1], DCH);
     };
 
     const unsigned char *a_base = dyt + (wn * 32 + li) * DCH + g * 16;
@@ -166,28 +176,44 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
 #pragma unroll
             for (int p = 0; p < PB; ++p) fetch(gi + 1, p);
         }
+        // partial products (piece of dY, piece of X), smallest first; mode 1: the single (0, 0)
+        constexpr int NP = SPL == 1 ? 1 : 6;
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
         for (int p = 0; p < PB; ++p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {   // 16 pixels per MFMA: patch rows 2q (g = 0) and 2q + 1 (g = 1)
-                const bf16x8 av = *reinterpret_cast<const bf16x8 *>(a_base + p * NB * DCH + (2 * q) * 16);
+                bf16x8 av[SPL];
+#pragma unroll
+                for (int z = 0; z < SPL; ++z)
+                    av[z] = *reinterpret_cast<const bf16x8 *>(a_base + z * DPL + p * NB * DCH + (2 * q) * 16);
 #pragma unroll
                 for (int r = 0; r < KS; ++r) {
                     const unsigned char *row = b_base + p * CB * XCH + (2 * q + r) * XROW;
-                    const u32x4 lo = *reinterpret_cast<const u32x4 *>(row);
-                    if (KS == 1) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, lo), acc[0], 0, 0, 0);
-                    } else {
-                        const unsigned hi = *reinterpret_cast<const unsigned *>(row + 16);
-                        u32x4 s1, s2;
-                        s1[0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
-                        s1[1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
-                        s1[2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16);
-                        s1[3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
-                        s2[0] = lo[1]; s2[1] = lo[2]; s2[2] = lo[3]; s2[3] = hi;
-                        acc[r * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, lo), acc[r * 3 + 0], 0, 0, 0);
-                        acc[r * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s1), acc[r * 3 + 1], 0, 0, 0);
-                        acc[r * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, s2), acc[r * 3 + 2], 0, 0, 0);
+                    u32x4 b0[SPL], b1[SPL], b2[SPL];     // the three tap columns of every piece of X
+#pragma unroll
+                    for (int z = 0; z < SPL; ++z) {
+                        const u32x4 lo = *reinterpret_cast<const u32x4 *>(row + z * XPL);
+                        b0[z] = lo;
+                        if (KS == 3) {
+                            const unsigned hi = *reinterpret_cast<const unsigned *>(row + z * XPL + 16);
+                            b1[z][0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
+                            b1[z][1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
+                            b1[z][2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16);
+                            b1[z][3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
+                            b2[z][0] = lo[1]; b2[z][1] = lo[2]; b2[z][2] = lo[3]; b2[z][3] = hi;
+                        }
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) {
+                        const int za = SPL == 1 ? 0 : PA[pp], zx = SPL == 1 ? 0 : PX[pp];
+                        if (KS == 1) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[za], __builtin_bit_cast(bf16x8, b0[zx]), acc[0], 0, 0, 0);
+                        } else {
+                            acc[r * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[za], __builtin_bit_cast(bf16x8, b0[zx]), acc[r * 3 + 0], 0, 0, 0);
+                            acc[r * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[za], __builtin_bit_cast(bf16x8, b1[zx]), acc[r * 3 + 1], 0, 0, 0);
+                            acc[r * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[za], __builtin_bit_cast(bf16x8, b2[zx]), acc[r * 3 + 2], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -205,10 +231,11 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
     }
 }
 
-template <int KS, int WN, int WC>
+template <int KS, int WN, int WC, int SPL>
 static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
-    using Cfg = WgB16Cfg<KS, WN, WC>;
-    auto kern = wgrad_bf16_kernel<KS, WN, WC>;
+    using Cfg = WgB16Cfg<KS, WN, WC, SPL>;
+    if (a.pb != Cfg::PB) return hipErrorInvalidValue;
+    auto kern = wgrad_bf16_kernel<KS, WN, WC, SPL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -228,16 +255,23 @@ bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride) {
     return a.dy_ld % 4 == 0;
 }
 
-// the main kernel of launch_wgrad in mixed-precision mode (the split-K reduce is shared); WN / WC as planned
-hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st) {
-#define WG16(KS_)                                                   \
-    if (WN == 2 && WC == 2) return launch_wg16<KS_, 2, 2>(a, st);   \
-    if (WN == 4) return launch_wg16<KS_, 4, 1>(a, st);              \
-    if (WN == 2) return launch_wg16<KS_, 2, 1>(a, st);              \
-    return launch_wg16<KS_, 1, 1>(a, st);
+// patches per staged pixel group of the kernel launch_wgrad_bf16 will run (wgrad_plan sizes the groups with it)
+int wgrad_bf16_patches(int prec) { return prec == 2 ? 1 : 2; }
+
+// the main kernel of launch_wgrad in the bf16-pipe modes (the split-K reduce is shared); WN / WC as planned
+template <int SPL>
+static hipError_t launch_wgrad_b16_spl(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st) {
+#define WG16(KS_)                                                        \
+    if (WN == 2 && WC == 2) return launch_wg16<KS_, 2, 2, SPL>(a, st);   \
+    if (WN == 4) return launch_wg16<KS_, 4, 1, SPL>(a, st);              \
+    if (WN == 2) return launch_wg16<KS_, 2, 1, SPL>(a, st);              \
+    return launch_wg16<KS_, 1, 1, SPL>(a, st);
     if (ks == 3) { WG16(3) }
     WG16(1)
 #undef WG16
+}
+hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st) {
+    return a.prec == 2 ? launch_wgrad_b16_spl<3>(a, ks, WN, WC, st) : launch_wgrad_b16_spl<1>(a, ks, WN, WC, st);
 }
 
 }  // namespace mc

@@ -341,7 +341,8 @@ void wgrad_plan(WgradArgs &a, int ks, int stride) {
     a.c_tiles = (a.Cin + 32 * WC - 1) / (32 * WC);
     a.ppr = (a.Wout + 7) / 8;
     a.ppi = a.ppr * ((a.Hout + 3) / 4);
-    a.groups_per_img = (a.ppi + 1) / 2;
+    a.pb = (a.prec >= 1 && wgrad_bf16_ok(a, ks, stride)) ? wgrad_bf16_patches(a.prec) : 2;
+    a.groups_per_img = (a.ppi + a.pb - 1) / a.pb;
     const long long G = (long long)a.B * a.groups_per_img;
     int ks_ = 512 * 4 / (WN * WC) / (a.n_tiles * a.c_tiles);   // two resident 4-wave workgroups per CU
     if (ks_ < 1) ks_ = 1;
@@ -364,7 +365,7 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
         int WN, WC;
         wgrad_shape(a, &WN, &WC);
         if (!wgrad_sources_ok(a)) return hipErrorInvalidValue;
-        if (a.prec == 1 && wgrad_bf16_ok(a, ks, stride)) {
+        if (a.prec >= 1 && wgrad_bf16_ok(a, ks, stride)) {
             e = launch_wgrad_bf16(a, ks, WN, WC, st);
         } else {
 #define WG_DISPATCH(KS_, S_)                                                     \

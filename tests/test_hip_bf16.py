@@ -217,3 +217,17 @@ def test_forward_split_emulation_meets_the_fp32_parity_gate(golden_sd):
     worst = max(rel_err(v.cpu(), g["f64." + k]) for k, v in pred.items())
     assert worst < 1e-4, worst
     eng.set_precision(0)
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0].replace("b16wg", "splitwg") for c in WG_CASES])
+def test_wgrad_split_emulation_is_fp32_accurate(eng_split, case):
+    """weight gradient in mode 2: same tolerance as the fp32 MFMA wgrad (tests/test_hip_ops.py: 5e-6 vs fp64)."""
+    name, B, H, W, cins, cout, k = case
+    seed = 950 + WG_CASES.index(case)
+    xs = [rnd(seed, "x%d" % i, (B, c, H, W)) for i, c in enumerate(cins)]
+    dy = rnd(seed, "dy", (B, cout, H, W))
+    w = torch.zeros(cout, sum(cins), k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(torch.cat(xs, 1).double(), w, None, 1, k // 2).backward(dy.double())
+    dev = eng_split.device
+    got = eng_split.op_conv_wgrad([nhwc(x).to(dev) for x in xs], nhwc(dy).to(dev), k, 1).cpu()
+    assert rel_err(got, w.grad) < 5e-6
