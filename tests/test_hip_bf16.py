@@ -79,6 +79,7 @@ def test_forward_bf16_close_to_fp32(golden_sd):
     DESIGN.md section 4), so the bounds are stated per depth: level2 < 2e-2, predictions < 0.3 relative L2."""
     from hipmonocon.engine import Engine
     eng = Engine()
+    eng.set_precision(0)          # (the suite may run under MONOCON_HIP_PRECISION=...)
     dsd = {k: v.cuda() for k, v in golden_sd.items()}
     img = synth.make_batch(GOLDEN_SEED + 1, 2, 64, 128, with_labels=False)["img"].cuda()
     eng.bind_state(dsd)
