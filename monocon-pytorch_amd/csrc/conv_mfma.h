@@ -21,7 +21,14 @@
 //   * virtual concat: up to 4 source tensors are walked chunk by chunk; torch.cat is never
 //     materialised.
 //   * epilogue: folded-BN scale/shift or conv bias, residual add, ReLU, optional per-(image,
-//     channel) sum / sum-of-squares partials (for AttnBN instance statistics / train-mode BN).
+//     channel) sum / sum-of-squares partials (for AttnBN instance statistics / train-mode BN);
+//     output (and residual) may be a strided scatter (o_px / o_row), used by the stride-2 data gradient.
+//   * every global access is a buffer instruction: descriptor in SGPRs, lane offset resolved once,
+//     wave-uniform SGPR offset per K-chunk / tap -- no vector address arithmetic in the K loop.
+// Family: conv_mfma_kernel (this tiling), conv_mfma_ws_kernel (producer wave + double-buffered LDS),
+// conv_small_kernel (conv_small.hip: 16/32-channel layers on 16x16x4, no LDS), conv_bf16_kernel
+// (conv_bf16.hip: bf16 operands, or fp32 emulated by a 3-way bf16 split).  launch_conv() dispatches on
+// ConvArgs::cfg / ::prec; results of the fp32 variants are bit-identical across workgroup shapes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
