@@ -409,13 +409,98 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float *__r
     __syncthreads();
     if (threadIdx.x == 0) dw[o * 147 + t] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
+// ---- the same gradient on v_mfma_f32_16x16x4_f32 (see wgrad_small_kernel in wgrad_mfma.hip for the mapping):
+// A[n][k] = dY[pixel k][n] (one coalesced dword per lane), B[k][j] = img[c(t)][y + r(t) - 3][x + k + s(t) - 3] for the
+// 16 taps t = 16*jt + j of tap tile jt (ten tiles cover the 147 taps; a lane's (c, r, s) are fixed, so its image offset is
+// resolved once per row and an interior group of 4 pixels is 1 + 10 loads + 10 MFMAs with SGPR offsets only).
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float *__restrict__ img, const float *__restrict__ dy,
+                                                              int B, int H, int W, float *__restrict__ partial) {
+    constexpr int NJT = 10;
+    __shared__ float red[NJT * 4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = lane >> 4, j = lane & 15;
+    int toff[NJT], tr[NJT], tsx[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int t = jt * 16 + j;
+        const int c = t / 49, r = (t % 49) / 7, s = t % 7;
+        tr[jt] = t < 147 ? r - 3 : -(1 << 20);                 // dead taps: a row that is never inside the image
+        tsx[jt] = s - 3 + k;
+        toff[jt] = ((c * H + r - 3) * W + s - 3 + k) * 4;
+    }
+    f32x4w acc[NJT];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt) acc[jt] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    const int va = (k * 16 + j) * 4;
+    const int R = B * H;
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const int b = row / H, y = row - b * H;
+        const __amdgpu_buffer_rsrc_t r_img = make_rsrc(img + (size_t)b * 3 * H * W, (unsigned)(3 * H * W) * 4u);
+        const __amdgpu_buffer_rsrc_t r_dy = make_rsrc(dy + (size_t)row * W * 16, (unsigned)(W * 16) * 4u);
+        int rowoff[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int yy = y + tr[jt];
+            rowoff[jt] = (yy >= 0 && yy < H) ? toff[jt] + y * W * 4 : BUF_OOB;
+        }
+        auto group = [&](int x0, bool edge) {
+            const float av = buf_load1(r_dy, va, x0 * 64);
+            float bv[NJT];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                if (!edge) {
+                    bv[jt] = buf_load1(r_img, rowoff[jt], x0 * 4);
+                } else {
+                    const int xx = x0 + tsx[jt];
+                    bv[jt] = buf_load1(r_img, (xx >= 0 && xx < W && rowoff[jt] != BUF_OOB) ? rowoff[jt] + x0 * 4 : BUF_OOB, 0);
+                }
+            }
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[jt], acc[jt], 0, 0, 0);
+        };
+        group(0, true);
+#pragma unroll 2
+        for (int x0 = 4; x0 <= W - 12; x0 += 4) group(x0, false);     // x0 + k + s - 3 in [1, W - 3]
+        group(W - 8, true);
+        group(W - 4, true);
+    }
+    // workgroup reduction, wave after wave (fixed order); D: row (out channel n) = 4*(lane>>4) + q, column = tap j
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float *dst = &red[jt * 4 + q][lane];
+                    *dst = w == 0 ? acc[jt][q] : *dst + acc[jt][q];
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < NJT * 4 * 64; e += 256) {
+        const int l = e & 63, idx = e >> 6;
+        const int q = idx & 3, jt = idx >> 2;
+        const int t = jt * 16 + (l & 15), n = 4 * (l >> 4) + q;
+        if (t < 147) partial[((size_t)blockIdx.x * 147 + t) * 16 + n] = red[idx][l];
+    }
+}
+static bool stem_wgrad_use_mfma(int W) { return W % 4 == 0 && W >= 16; }
 int stem_wgrad_blocks(int B, int H, int W) {
+    if (stem_wgrad_use_mfma(W)) {
+        const int nb = (B * H + 3) / 4;
+        return nb > 1024 ? 1024 : nb;
+    }
     return (B * ((W + 31) / 32) * ((H + 7) / 8) + STEM_WG_TILES - 1) / STEM_WG_TILES;
 }
 hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
                              hipStream_t st) {
     const int nb = stem_wgrad_blocks(B, H, W);
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(192), 0, st, img, dy, B, H, W, partial);
+    if (stem_wgrad_use_mfma(W))
+        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nb), dim3(256), 0, st, img, dy, B, H, W, partial);
+    else
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(192), 0, st, img, dy, B, H, W, partial);
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(147 * 16), dim3(256), 0, st, partial, nb, dw);
     return hipGetLastError();
 }
