@@ -196,6 +196,12 @@ int mc_op_maxpool2(mc_handle *h, const float *in, int B, int H, int W, int C, fl
  * (model/backbone/dla_neck.py:58-65). */
 int mc_op_deconv4x4(mc_handle *h, const float *in, int B, int H, int W, int C,
                     const float *weight, float *out, void *stream);
+/* Data gradient of the same convolution wrt ONE source of its virtual concat (autograd's conv2d input
+ * backward): dx (B,Hin,Win,Cs) NHWC = conv_transpose(dy (B,Hout,Wout,Cout), W[:, c_off:c_off+Cs]); accumulate != 0
+ * adds to dx.  Runs exactly what the train plan launches: the fused conv kernel on a transposed / flipped weight
+ * panel for stride 1, four output-parity window convs for stride 2. */
+int mc_op_conv_dgrad(mc_handle *h, const float *dy, const float *weight_oihw, int B, int Hin, int Win, int CinTotal,
+                     int c_off, int Cs, int Cout, int ksize, int stride, int accumulate, float *dx, void *stream);
 /* layout helpers */
 int mc_op_nchw_to_nhwc(mc_handle *h, const float *in, int B, int C, int H, int W, float *out,
                        void *stream);

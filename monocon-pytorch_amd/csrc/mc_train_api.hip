@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 static int check_targets(mc_handle *h, const mc_targets *t, const char *who) {
     if (!t) return fail(h, "%s: targets is NULL", who);
@@ -167,6 +168,63 @@ int mc_op_conv_wgrad(mc_handle *h, const float *const src[], const int src_chann
     hipError_t e = mc::launch_wgrad(a, ksize, stride, dw_oihw, st);
     hipError_t e2 = hipStreamSynchronize(st);
     (void)hipFree(part);
+    HIPCHK(h, e);
+    HIPCHK(h, e2);
+    return 0;
+}
+
+int mc_op_conv_dgrad(mc_handle *h, const float *dy, const float *weight_oihw, int B, int Hin, int Win, int CinTotal,
+                     int c_off, int Cs, int Cout, int ksize, int stride, int accumulate, float *dx, void *stream) {
+    if (!h) return -1;
+    if (!dy || !weight_oihw || !dx) return fail(h, "mc_op_conv_dgrad: null argument");
+    if (!((ksize == 3 && (stride == 1 || stride == 2)) || (ksize == 1 && stride == 1)))
+        return fail(h, "mc_op_conv_dgrad: unsupported k=%d stride=%d", ksize, stride);
+    if (Cout % 16 || Cs % 4 || c_off < 0 || c_off + Cs > CinTotal) return fail(h, "mc_op_conv_dgrad: bad channel arguments");
+    if (stride == 2 && ((Hin | Win) & 1)) return fail(h, "mc_op_conv_dgrad: stride 2 needs even Hin, Win");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int Ho = (Hin + 2 * (ksize / 2) - ksize) / stride + 1, Wo = (Win + 2 * (ksize / 2) - ksize) / stride + 1;
+    const int CsP = mc::conv_coutp(Cs), pieces = h->prec == 2 ? 3 : 1;
+    const int nclass = stride == 2 ? 4 : 1;
+    std::vector<void *> tmp;
+    hipError_t e = hipSuccess;
+    for (int cls = 0; cls < nclass && e == hipSuccess; ++cls) {
+        const int cid = stride == 2 ? cls : -1;
+        const int py = cls >> 1, px = cls & 1;
+        const int taps = stride == 2 ? (1 + py) * (1 + px) : ksize * ksize;
+        const size_t pn = (size_t)taps * Cout * CsP;
+        void *panel = nullptr, *panel16 = nullptr;
+        if (hipMalloc(&panel, pn * 4) != hipSuccess) { e = hipErrorOutOfMemory; break; }
+        tmp.push_back(panel);
+        (void)hipMemsetAsync(panel, 0, pn * 4, st);
+        e = mc::launch_pack_conv_w_dgrad(weight_oihw, Cout, CinTotal, ksize, c_off, Cs, CsP, Cout, cid, static_cast<float *>(panel), st);
+        if (e != hipSuccess) break;
+        if (h->prec >= 1 && Cout % 32 == 0) {
+            if (hipMalloc(&panel16, pn * 2 * pieces) != hipSuccess) { e = hipErrorOutOfMemory; break; }
+            tmp.push_back(panel16);
+            (void)hipMemsetAsync(panel16, 0, pn * 2 * pieces, st);
+            e = mc::launch_pack_conv_w_dgrad_bf16(weight_oihw, Cout, CinTotal, ksize, c_off, Cs, CsP, Cout, cid, pieces, panel16, st);
+            if (e != hipSuccess) break;
+        }
+        mc::ConvArgs d{};
+        d.nsrc = 1; d.src[0].p = dy; d.src[0].C = Cout;
+        d.B = B; d.Hin = Ho; d.Win = Wo; d.Hout = Ho; d.Wout = Wo;
+        d.Cin = Cout; d.Cout = Cs; d.CoutP = CsP; d.wpk = static_cast<float *>(panel);
+        d.wpk16 = panel16; d.prec = panel16 ? h->prec : 0;
+        d.out = dx; d.out_ld = Cs;
+        int kk = ksize;
+        if (stride == 2) {
+            d.out = dx + ((size_t)py * Win + px) * Cs;
+            d.o_px = 2 * Cs; d.o_row = 2 * Win * Cs; d.o_img = Hin * Win * Cs;
+            kk = (1 + py) * 10 + (1 + px);
+            if (kk == 11) kk = 1;
+        }
+        if (accumulate) { d.res = d.out; d.res_ld = Cs; d.r_px = d.o_px; d.r_row = d.o_row; d.r_img = d.o_img; }
+        d.cfg = h->force_cfg;
+        e = mc::launch_conv(d, kk, 1, st);
+    }
+    hipError_t e2 = hipStreamSynchronize(st);   // test entry point: the panels are temporaries
+    for (void *q : tmp) (void)hipFree(q);
     HIPCHK(h, e);
     HIPCHK(h, e2);
     return 0;

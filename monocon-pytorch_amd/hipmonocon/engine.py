@@ -330,6 +330,21 @@ class Engine:
         _lib.check(self.h, rc, "mc_op_conv")
         return out
 
+    def op_conv_dgrad(self, dy, weight, in_hw, c_off=0, cs=None, stride=1, accumulate_into=None):
+        """data gradient wrt input channels [c_off, c_off + cs) of conv2d(x, weight, stride, pad k//2):
+        dy NHWC (B,Ho,Wo,Cout) -> NHWC (B,Hin,Win,cs)."""
+        _need_cuda(dy, "dy"); _need_cuda(weight, "weight")
+        B, Ho, Wo, Cout = dy.shape
+        _, cin_total, k, _ = weight.shape
+        cs = cin_total - c_off if cs is None else cs
+        Hin, Win = in_hw
+        out = accumulate_into if accumulate_into is not None else torch.empty((B, Hin, Win, cs), dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            rc = self.lib.mc_op_conv_dgrad(self.h, _ptr(dy), _ptr(weight), B, Hin, Win, cin_total, c_off, cs, Cout, k, stride,
+                                           int(accumulate_into is not None), _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_op_conv_dgrad")
+        return out
+
     def op_conv_wgrad(self, srcs, dy, ksize, stride=1):
         """weight gradient of the fused conv: srcs NHWC list, dy NHWC -> (Cout, sum C, k, k)."""
         B, H, W, _ = srcs[0].shape

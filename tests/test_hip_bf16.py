@@ -232,3 +232,31 @@ def test_wgrad_split_emulation_is_fp32_accurate(eng_split, case):
     dev = eng_split.device
     got = eng_split.op_conv_wgrad([nhwc(x).to(dev) for x in xs], nhwc(dy).to(dev), k, 1).cpu()
     assert rel_err(got, w.grad) < 5e-6
+
+
+@pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 5e-6)], ids=["bf16", "split"])
+@pytest.mark.parametrize("case", [(2, 16, 24, 64, 0, 64, 64, 3, 1), (1, 8, 16, 192, 64, 64, 64, 3, 1),
+                                  (2, 16, 32, 32, 0, 32, 64, 3, 2), (1, 24, 48, 64, 0, 64, 128, 3, 2),
+                                  (1, 12, 16, 448, 256, 64, 128, 1, 1)],
+                         ids=["s1", "s1_slice", "s2_32_64", "s2_64_128", "k1_slice"])
+def test_dgrad_on_the_bf16_pipe(mode, tol, case):
+    """data gradients (stride-1 panel and the stride-2 parity classes) in modes 1 and 2 vs autograd in fp64."""
+    from hipmonocon.engine import Engine
+    B, H, W, cin_total, c_off, cs, cout, k, stride = case
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    w = rnd(1234, "w", (cout, cin_total, k, k), (2.0 / (k * k * cin_total)) ** 0.5)
+    dy = rnd(1234, "dy", (B, cout, Ho, Wo))
+    x = torch.zeros(B, cin_total, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w.double(), None, stride, k // 2).backward(dy.double())
+    ref = x.grad[:, c_off:c_off + cs]
+    eng = Engine()
+    eng.set_precision(mode)
+    try:
+        got = eng.op_conv_dgrad(nhwc(dy).cuda(), w.cuda(), (H, W), c_off, cs, stride)
+    finally:
+        eng.set_precision(0)
+    e = rel_err(got.cpu().permute(0, 3, 1, 2), ref)
+    assert e < tol, e
+    if mode == 1:
+        assert e > 1e-5       # the bf16 kernel really ran
+

@@ -211,3 +211,41 @@ def test_conv_wgrad(eng, case):
     got = eng.op_conv_wgrad([nhwc(x).to(dev) for x in xs], nhwc(dy).to(dev), k, stride).cpu()
     assert got.shape == w.grad.shape
     assert rel_err(got, w.grad) < 5e-6
+
+
+DGRAD_CASES = [
+    # (name, B, Hin, Win, CinTotal, c_off, Cs, Cout, k, stride)
+    ("dg_s1_64_64", 2, 16, 24, 64, 0, 64, 64, 3, 1),
+    ("dg_s1_128_128", 1, 12, 40, 128, 0, 128, 128, 3, 1),
+    ("dg_s1_source_slice", 2, 8, 16, 192, 64, 64, 64, 3, 1),      # second source of a 64+64+64 concat
+    ("dg_s1_odd_edges", 1, 6, 10, 32, 0, 32, 64, 3, 1),
+    ("dg_k1_root_slice", 1, 12, 16, 448, 256, 64, 128, 1, 1),
+    ("dg_s2_32_64", 2, 16, 32, 32, 0, 32, 64, 3, 2),              # four output-parity window convs
+    ("dg_s2_64_128", 1, 24, 48, 64, 0, 64, 128, 3, 2),
+    ("dg_s2_16_32", 1, 24, 32, 16, 0, 16, 32, 3, 2),
+    ("dg_s2_256_512_tiny", 1, 8, 8, 256, 0, 256, 512, 3, 2),
+    ("dg_head_576_64", 1, 8, 16, 64, 0, 64, 576, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+def test_conv_dgrad(eng, case):
+    """data gradient through exactly the launches the train plan emits (transposed / flipped panel for stride 1,
+    output-parity classes scattering into dx for stride 2) vs autograd in fp64; then the accumulate form."""
+    name, B, H, W, cin_total, c_off, cs, cout, k, stride = case
+    seed = 600 + DGRAD_CASES.index(case)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    w = rnd(seed, "w", (cout, cin_total, k, k), (2.0 / (k * k * cin_total)) ** 0.5)
+    dy = rnd(seed, "dy", (B, cout, Ho, Wo))
+    x = torch.zeros(B, cin_total, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w.double(), None, stride, k // 2).backward(dy.double())
+    ref = x.grad[:, c_off:c_off + cs]
+    dev = eng.device
+    tol = TOL if cout * k * k <= 4608 else 5e-6        # one fp32 FMA chain over K = Cout*k*k terms
+    got = eng.op_conv_dgrad(nhwc(dy).to(dev), w.to(dev), (H, W), c_off, cs, stride)
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < tol
+    base = rnd(seed, "acc", (B, cs, H, W))
+    acc = nhwc(base).to(dev).clone()
+    eng.op_conv_dgrad(nhwc(dy).to(dev), w.to(dev), (H, W), c_off, cs, stride, accumulate_into=acc)
+    assert rel_err(acc.cpu().permute(0, 3, 1, 2), ref + base.double()) < tol
+
