@@ -82,3 +82,21 @@ def test_decode_k_limits(eng):
     assert R["scores"].shape == (1, 1)
     with pytest.raises(MonoconHipError):
         run(eng, d, 2000)
+
+
+def test_decode_full_size_properties(eng):
+    """B=64, K=100 (BASELINE config 5) size-independent properties: scores sorted descending per image, flat
+    indices unique, every kept candidate is a local maximum, classes derived from the flat index."""
+    d = synth.make_decode_inputs(9001, 64, 96, 320, topk=100)
+    R = run(eng, d, 100)
+    sc, fi = R["scores"].cpu(), R["flat_index"].cpu()
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all())
+    HW = 96 * 320
+    for b in range(64):
+        assert len(set(fi[b].tolist())) == 100
+    assert torch.equal(R["cls"].cpu(), (fi // HW).to(R["cls"].dtype))
+    heat = torch.from_numpy(d["center_heatmap_pred"]).reshape(64, -1)
+    assert torch.equal(torch.gather(heat, 1, fi), sc)                       # scores are the heat-map values at the indices
+    keep = R["keep"].cpu().bool().reshape(64, -1)
+    assert bool(torch.gather(keep, 1, fi).all())                            # ... and every one of them is a 3x3 local maximum
+

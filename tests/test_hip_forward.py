@@ -75,6 +75,21 @@ def test_forward_shape_sweep_vs_oracle(eng, shape):
         assert rel_err(v.cpu(), ref[k]) < TOL_F32, (k, shape)
 
 
+def test_full_size_batch_invariance_is_bit_exact(eng):
+    """size-independent property at the full 384x1280 resolution: in eval mode an image's predictions do not depend
+    on what else is in the batch -- and since the B=8 and B=1 plans are autotuned separately (different workgroup
+    shapes per layer), bit-equality also checks that the conv result is independent of the tiling."""
+    imgs = torch.randn((8, 3, 384, 1280), generator=torch.Generator().manual_seed(5)).to(eng.device)
+    full = {k: v.clone() for k, v in eng.forward_infer(imgs).items()}
+    for i in (0, 5):
+        one = eng.forward_infer(imgs[i:i + 1].contiguous())
+        for k in full:
+            assert torch.equal(one[k][0], full[k][i]), (k, i)
+    pair = eng.forward_infer(imgs[[5, 2]].contiguous())
+    for k in full:
+        assert torch.equal(pair[k][1], full[k][2]) and torch.equal(pair[k][0], full[k][5]), k
+
+
 def test_repack_follows_parameter_update(eng):
     """in-place update of a master weight must be picked up (``_version`` tracking)."""
     img = synth.make_batch(5, 1, 64, 64, with_labels=False)["img"].to(eng.device)
