@@ -39,7 +39,7 @@ struct ConvCfgB16 {
     static constexpr int ROWB = (CK + 8) * 2;                      // bytes per staged pixel
     static constexpr int PLANE_BYTES = PB * NPIX * ROWB;          // one bf16 piece of the halo tile
     static constexpr int TILE_BYTES = SPL * PLANE_BYTES;
-    static constexpr size_t LDS_BYTES = TILE_BYTES + PB * 16 + 2 * WM * BNT * sizeof(float);
+    static constexpr size_t LDS_BYTES = TILE_BYTES + PB * 16;
 };
 
 template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL>
@@ -53,7 +53,6 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int *pinfo = reinterpret_cast<int *>(lds_raw + Cfg::TILE_BYTES);   // [PB][4] = b, oy0, ox0, valid
-    float *sred = reinterpret_cast<float *>(lds_raw + Cfg::TILE_BYTES + PB * 16);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -212,21 +211,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
         kbase += Cs;
     }
 
-    conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, sred, img, n0, wm, wn, g, li);
-    if (a.stats) {
-        __syncthreads();
-        for (int nl = tid; nl < BNT; nl += NT) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                s1 += sred[(w * BNT + nl) * 2 + 0];
-                s2 += sred[(w * BNT + nl) * 2 + 1];
-            }
-            float *dst = a.stats + (((size_t)img * a.chunks + chunk) * a.CoutP + n0 + nl) * 2;
-            dst[0] = s1;
-            dst[1] = s2;
-        }
-    }
+    conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
 }
 
 // ---- weight packing: OIHW fp32 -> [tap][Cin/8][CoutP][8] bf16 (forward) and the dgrad variants

@@ -57,7 +57,7 @@ struct ConvArgs {
     float *out;              // NHWC, channel stride out_ld, channel offset out_coff
     int out_ld, out_coff;
     int relu;
-    float *stats;            // optional [B][chunks][CoutP][2] partial (sum, sumsq) of (v - shift)
+    float *stats;            // optional [B][patches per image][CoutP][2] partial (sum, sumsq) of (v - shift), per 4x8 patch
     const float *stat_shift; // [Cout] or null
     int ppr, ppi, chunks;    // patches per row / per image, workgroup chunks per image
     int cfg;                 // ConvCfgId workgroup shape (CFG_AUTO = conv_pick_cfg)
@@ -88,7 +88,7 @@ struct ConvCfg {
     static constexpr int IW = 7 * S + KW;
     static constexpr int NPIX = IH * IW;
     static constexpr int CKP = CK + 4;
-    static constexpr int LDS_FLOATS = PB * NPIX * CKP + PB * 4 + 2 * WM * BNT;
+    static constexpr int LDS_FLOATS = PB * NPIX * CKP + PB * 4;
     static constexpr size_t LDS_BYTES = sizeof(float) * LDS_FLOATS;
 };
 
@@ -118,16 +118,16 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, in
 // = (oy0 + (r>>2), ox0 + (r&3) + 4*(lane>>5)).
 template <int WM, int WN, int WTM, int WTN, int BNT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[WTM][WTN], const int *pinfo,
-                                              float *sred, int img, int n0, int wm, int wn, int g, int li) {
+                                              int patch0, int img, int n0, int wm, int wn, int g, int li) {
     const bool do_stats = a.stats != nullptr;
     const bool has_res = a.res != nullptr;
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (size_t)img * a.o_img, (unsigned)a.o_img * 4u);
     const __amdgpu_buffer_rsrc_t r_res =
         make_rsrc(has_res ? a.res + (size_t)img * a.r_img : a.out, has_res ? (unsigned)a.r_img * 4u : 0u);
-    float ssum[WTN], ssq[WTN];
-#pragma unroll
-    for (int tn = 0; tn < WTN; ++tn) ssum[tn] = ssq[tn] = 0.f;
+    // statistics partials are per 4x8 PATCH and channel: stats[b][patch][CoutP][2].  A patch's 32 values are
+    // summed in an order fixed by the MFMA layout, so the partials -- and with them train-mode BN -- do not depend
+    // on the workgroup shape the autotuner picked.
 #pragma unroll
     for (int tn = 0; tn < WTN; ++tn) {
         const int n = n0 + (wn * WTN + tn) * 32 + li;
@@ -144,6 +144,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
             const int ox0 = __builtin_amdgcn_readfirstlane(pinfo[p * 4 + 2]);
             const int pv = __builtin_amdgcn_readfirstlane(pinfo[p * 4 + 3]);
             if (!pv) continue;
+            float ssum = 0.f, ssq = 0.f;
             if (oy0 + 4 <= a.Hout && ox0 + 8 <= a.Wout) {
                 // whole patch inside the image: wave-uniform offsets only
                 const int s_out = (oy0 * a.o_row + ox0 * a.o_px) * 4;
@@ -160,8 +161,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                     if (has_res) v += rv[r];
                     if (do_stats) {
                         const float d = v - sh;
-                        ssum[tn] += d;
-                        ssq[tn] += d * d;
+                        ssum += d;
+                        ssq += d * d;
                     }
                     v = fmaxf(v, floor_v);
                     buf_store1(v, r_out, v_out, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
@@ -174,24 +175,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         float v = acc[tm][tn][r] * sc + bi;
                         if (has_res) v += buf_load1(r_res, (y * a.r_row + x * a.r_px + n) * 4, 0);
                         const float d = v - sh;
-                        ssum[tn] += d;
-                        ssq[tn] += d * d;
+                        ssum += d;
+                        ssq += d * d;
                         v = fmaxf(v, floor_v);
                         buf_store1(v, r_out, (y * a.o_row + x * a.o_px + a.out_coff + n) * 4, 0);
                     }
                 }
             }
-        }
-    }
-    if (do_stats) {
-#pragma unroll
-        for (int tn = 0; tn < WTN; ++tn) {
-            ssum[tn] += __shfl_xor(ssum[tn], 32);
-            ssq[tn] += __shfl_xor(ssq[tn], 32);
-            if (g == 0) {
-                const int nl = (wn * WTN + tn) * 32 + li;
-                sred[(wm * BNT + nl) * 2 + 0] = ssum[tn];
-                sred[(wm * BNT + nl) * 2 + 1] = ssq[tn];
+            if (do_stats) {
+                ssum += __shfl_xor(ssum, 32);
+                ssq += __shfl_xor(ssq, 32);
+                if (g == 0 && nok) {
+                    float *dst = a.stats + (((size_t)img * a.ppi + patch0 + p) * a.CoutP + n) * 2;
+                    dst[0] = ssum;
+                    dst[1] = ssq;
+                }
             }
         }
     }
@@ -207,7 +205,6 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvAr
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int *pinfo = reinterpret_cast<int *>(lds + PB * NPIX * CKP);   // [PB][4] = b, oy0, ox0, valid
-    float *sred = lds + PB * NPIX * CKP + PB * 4;                    // [WM][BNT][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -349,21 +346,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvAr
         kbase += Cs;
     }
 
-    conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, sred, img, n0, wm, wn, g, li);
-    if (a.stats) {
-        __syncthreads();
-        for (int nl = tid; nl < BNT; nl += NT) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                s1 += sred[(w * BNT + nl) * 2 + 0];
-                s2 += sred[(w * BNT + nl) * 2 + 1];
-            }
-            float *dst = a.stats + (((size_t)img * a.chunks + chunk) * a.CoutP + n0 + nl) * 2;
-            dst[0] = s1;
-            dst[1] = s2;
-        }
-    }
+    conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
 }
 
 // ---- wave-specialised variant -------------------------------------------------------------
@@ -376,20 +359,19 @@ struct ConvCfgWS : ConvCfg<KS, S, CK, WM, WN, WTM, WTN> {
     using Base = ConvCfg<KS, S, CK, WM, WN, WTM, WTN>;
     static constexpr int NT = 64 * (WM * WN + 1);
     static constexpr int TILE = Base::PB * Base::NPIX * Base::CKP;
-    static constexpr int LDS_FLOATS = 2 * TILE + Base::PB * 4 + 2 * WM * Base::BNT;
+    static constexpr int LDS_FLOATS = 2 * TILE + Base::PB * 4;
     static constexpr size_t LDS_BYTES = sizeof(float) * LDS_FLOATS;
 };
 
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
 __global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(const ConvArgs a) {
     using Cfg = ConvCfgWS<KS, S, CK, WM, WN, WTM, WTN>;
-    constexpr int PB = Cfg::PB, BNT = Cfg::BNT, NT = Cfg::NT, PAD = Cfg::PAD;
+    constexpr int PB = Cfg::PB, BNT = Cfg::BNT, PAD = Cfg::PAD;
     constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, CKP = Cfg::CKP, TILE = Cfg::TILE;
     constexpr int C4 = CK / 4;
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int *pinfo = reinterpret_cast<int *>(lds + 2 * TILE);   // [PB][4] = b, oy0, ox0, valid
-    float *sred = lds + 2 * TILE + PB * 4;                    // [WM][BNT][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -528,21 +510,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(con
             }
             if (ci + 1 < nch) __syncthreads();   // chunk ci+1 staged, chunk ci released
         }
-        conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, sred, img, n0, wm, wn, g, li);
-    }
-    if (a.stats) {
-        __syncthreads();
-        for (int nl = tid; nl < BNT; nl += NT) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                s1 += sred[(w * BNT + nl) * 2 + 0];
-                s2 += sred[(w * BNT + nl) * 2 + 1];
-            }
-            float *dst = a.stats + (((size_t)img * a.chunks + chunk) * a.CoutP + n0 + nl) * 2;
-            dst[0] = s1;
-            dst[1] = s2;
-        }
+        conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
     }
 }
 
@@ -604,9 +572,8 @@ int conv_pick_cfg(int Cout, int CoutP, int ks, int stride, int B, int Hout, int 
 inline int conv_patches_per_block(int cfg) { return conv_shape(cfg).PB(); }
 // statistics partials per image a launch with this shape writes (ConvArgs::chunks)
 inline int conv_chunks_per_image(int cfg, int Hout, int Wout) {
-    if (cfg == CFG_SMALL) return Hout;
-    const int ppi = ((Wout + 7) / 8) * ((Hout + 3) / 4), pb = conv_patches_per_block(cfg);
-    return (ppi + pb - 1) / pb;
+    if (cfg == CFG_SMALL) return Hout;                    // the row kernel: one partial per output row
+    return ((Wout + 7) / 8) * ((Hout + 3) / 4);           // every tiling: one partial per 4x8 patch
 }
 bool conv_small_ok(const ConvArgs &a, int ks, int stride);
 bool conv_bf16_ok(const ConvArgs &a, int ks, int stride);

@@ -448,8 +448,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
         c3.B = B; c3.Hin = fh; c3.Win = fw; c3.Hout = fh; c3.Wout = fw; c3.Cin = 64; c3.Cout = CP; c3.CoutP = h->head3.coutp;
         c3.wpk = h->head3.wpk; c3.bias = h->head_bias; c3.out = xh.p; c3.out_ld = CP; c3.cfg = h->head3.cfg;
         c3.wpk16 = h->head3.wpk16; c3.prec = h->prec;
-        const int ppr = (fw + 7) / 8, ppi = ppr * ((fh + 3) / 4), pb = conv_patches_per_block(c3.cfg);
-        at.chunks = (ppi + pb - 1) / pb;
+        at.chunks = conv_chunks_per_image(c3.cfg, fh, fw);
         at.stat_ld = h->head3.coutp;
         float *stats = b.alloc((size_t)B * at.chunks * at.stat_ld * 2);
         c3.stats = stats; c3.stat_shift = h->head_rm;

@@ -42,8 +42,11 @@ def test_full_res_eval_forward_vs_reference_golden(eng):
         s = v.cpu().reshape(-1)[::97]
         assert rel_err(s, g[k + ".f64sample"]) < TOL, k
         assert rel_err(s, g[k + ".sample"]) < TOL_F32, k
+        # checksum over ALL elements vs the reference's fp32 output: a systematic per-element bias above 1e-6 of the
+        # mean magnitude (a wrong tile / tap anywhere) shows up here even where the strided samples miss it
         ref_sum = float(g[k + ".sum"])
-        assert abs(float(v.double().sum()) - ref_sum) <= 2e-5 * abs(ref_sum) + 1e-2, k
+        tol = max(2e-5 * abs(ref_sum), 1e-6 * float(v.double().abs().sum())) + 1e-2
+        assert abs(float(v.double().sum()) - ref_sum) <= tol, k
 
 
 def test_forward_vs_oracle_other_shape(eng):
