@@ -268,11 +268,11 @@ struct Builder {
 }  // namespace
 
 int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
-    if (h->force_cfg) return h->force_cfg;
     const bool small_ok = conv_small_ok(a_in, ks, stride);
     // the 16x16x4 row kernel sums K in a different order than the 32x32x2 tilings: choosing it by eligibility, not by
     // timing, keeps results independent of the batch size / of autotuning noise (it is also the faster one)
     if (small_ok && !(a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride))) return CFG_SMALL;
+    if (h->force_cfg) return h->force_cfg;   // mc_set_conv_cfg: every other layer
     const int heuristic = small_ok ? (int)CFG_SMALL : conv_pick_cfg(a_in.Cout, a_in.CoutP, ks, stride, a_in.B, a_in.Hout, a_in.Wout);
     if (!h->autotune) return heuristic;
     const bool b16 = a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride);

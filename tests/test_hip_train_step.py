@@ -151,3 +151,30 @@ def test_train_forward_shape_sweep_vs_oracle(golden_sd, shape):
     g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
     assert bool(torch.isfinite(g).all())
     assert abs(float(g.double().norm()) - ref_norm) <= 0.05 * ref_norm, (float(g.double().norm()), ref_norm)
+
+
+def test_train_step_is_independent_of_the_conv_tiling(golden_sd):
+    """losses, gradients and updated BN buffers are bit-identical whether the conv workgroup shapes are autotuned
+    or forced to one tiling: the accumulation order of an output element and the per-patch statistics partials do
+    not depend on the shape (so plan-build timing noise can never change a training run)."""
+    from model import MonoConDetector
+    batch = to_cuda(synth.make_batch(GOLDEN_SEED + 9, 2, 96, 160))
+    res = []
+    for cfg in (0, 6, 22):          # autotuned; 128 px x 32 ch everywhere; its wave-specialised variant
+        m = MonoConDetector(34, pretrained_backbone=False)
+        m.load_state_dict(golden_sd, strict=True)
+        m = m.cuda().train()
+        eng = m._engine()
+        eng.set_conv_cfg(cfg)
+        _, loss = m(batch)
+        sum(loss.values()).backward()
+        res.append(([v.detach().clone() for v in loss.values()],
+                    torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).clone(),
+                    torch.cat([b.flatten().float() for b in m.buffers()]).clone()))
+        eng.set_conv_cfg(0)
+    for other in res[1:]:
+        for a, b in zip(res[0][0], other[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(res[0][1], other[1])
+        assert torch.equal(res[0][2], other[2])
+
