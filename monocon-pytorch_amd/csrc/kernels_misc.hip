@@ -273,33 +273,44 @@ const int *head_row_begin() { init_rows(); return g_row_begin; }
 
 // AttnBN attention path (reference model/norm/attentive_norm.py:79-91,154-164), eval mode.
 // One 64-lane workgroup per (image, head); lane = channel.
-__global__ __launch_bounds__(64) void head_attn_kernel(const float *__restrict__ stats, int chunks, int HW,
-                                                        HeadAttnParams p, float *__restrict__ scale,
-                                                        float *__restrict__ shift) {
-    const int b = blockIdx.x, h = blockIdx.y, c = threadIdx.x;
+__global__ __launch_bounds__(256) void head_attn_kernel(const float *__restrict__ stats, int chunks, int HW,
+                                                         HeadAttnParams p, float *__restrict__ scale,
+                                                         float *__restrict__ shift) {
+    const int b = blockIdx.x, h = blockIdx.y, c = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int CP = NUM_HEADS * HEAD_CH;
+    // per-patch partials (conv epilogue) summed in fp64: four waves take interleaved quarters, fixed order
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
+    for (int k = part; k < chunks; k += 4) {
         const float *q = stats + (((size_t)b * chunks + k) * CP + h * HEAD_CH + c) * 2;
         s1 += (double)q[0];
         s2 += (double)q[1];
     }
+    __shared__ double red[2][4][64];
+    red[0][part][c] = s1;
+    red[1][part][c] = s2;
+    __syncthreads();
+    const bool lead = part == 0;     // wave 0 finishes; the others only keep the barrier below company
+    s1 = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    s2 = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
     const double n = (double)HW;
     const float rm = p.rm[h][c], rv = p.rv[h][c];
     const double mean = (double)rm + s1 / n;
     const double var = (s2 - s1 * s1 / n) / (n - 1.0);          // unbiased (torch.var_mean)
     const float sstat = (float)(mean / sqrt(var + 1e-3));
     __shared__ float y[NUM_AFFINE];
-    for (int k = 0; k < NUM_AFFINE; ++k) {
-        float v = sstat * p.att_w[h][k * HEAD_CH + c];
+    if (lead) {
+        for (int k = 0; k < NUM_AFFINE; ++k) {
+            float v = sstat * p.att_w[h][k * HEAD_CH + c];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (c == 0) {
-            const float t = v * p.att_scale[h][k] + p.att_shift[h][k];
-            y[k] = fminf(fmaxf(t + 3.f, 0.f), 6.f) / 6.f;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (c == 0) {
+                const float t = v * p.att_scale[h][k] + p.att_shift[h][k];
+                y[k] = fminf(fmaxf(t + 3.f, 0.f), 6.f) / 6.f;
+            }
         }
     }
     __syncthreads();
+    if (!lead) return;
     float gam = 0.f, bet = 0.f;
 #pragma unroll
     for (int k = 0; k < NUM_AFFINE; ++k) {
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(64) void head_attn_kernel(const float *__restrict__
 }
 hipError_t launch_head_attn(const float *stats, int B, int chunks, int HW, const HeadAttnParams &p, float *scale,
                             float *shift, hipStream_t st) {
-    hipLaunchKernelGGL(head_attn_kernel, dim3(B, NUM_HEADS), dim3(64), 0, st, stats, chunks, HW, p, scale, shift);
+    hipLaunchKernelGGL(head_attn_kernel, dim3(B, NUM_HEADS), dim3(256), 0, st, stats, chunks, HW, p, scale, shift);
     return hipGetLastError();
 }
 
