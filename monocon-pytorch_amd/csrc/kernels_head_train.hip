@@ -170,6 +170,28 @@ __device__ __forceinline__ void group_reduce2(double &s1, double &s2, double (*s
     for (int g = 0; g < 16; ++g) { s1 += sh[g][c][0]; s2 += sh[g][c][1]; }
 }
 
+// per-(image, channel) sums of the conv epilogue's per-patch partials, fp64, four interleaved quarters combined in a
+// fixed order (same scheme as head_attn_kernel)
+__global__ __launch_bounds__(256) void inst_stats_kernel(const float *__restrict__ stats, int chunks, int stat_ld,
+                                                         double *__restrict__ out) {
+    const int b = blockIdx.x, ch = blockIdx.y * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = part; k < chunks; k += 4) {
+        const float *q = stats + (((size_t)b * chunks + k) * stat_ld + ch) * 2;
+        s1 += (double)q[0];
+        s2 += (double)q[1];
+    }
+    __shared__ double red[2][4][64];
+    const int c = threadIdx.x & 63;
+    red[0][part][c] = s1;
+    red[1][part][c] = s2;
+    __syncthreads();
+    if (part == 0) {
+        out[((size_t)b * stat_ld + ch) * 2] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        out[((size_t)b * stat_ld + ch) * 2 + 1] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+
 __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArgs a) {
     __shared__ double shred[16][64][2];
     const int h = blockIdx.x, c = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -180,11 +202,16 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArg
     double S1 = 0, S2 = 0;
     for (int b = 0; b < a.B; ++b) {
         double s1 = 0, s2 = 0;
-        for (int k = grp; k < a.chunks; k += 16) {
-            const float *q = a.stats + (((size_t)b * a.chunks + k) * a.stat_ld + ch) * 2;
-            s1 += q[0]; s2 += q[1];
+        if (a.stats64) {                        // pre-reduced by inst_stats_kernel (B x 9 workgroups instead of 9)
+            s1 = a.stats64[((size_t)b * a.stat_ld + ch) * 2];
+            s2 = a.stats64[((size_t)b * a.stat_ld + ch) * 2 + 1];
+        } else {
+            for (int k = grp; k < a.chunks; k += 16) {
+                const float *q = a.stats + (((size_t)b * a.chunks + k) * a.stat_ld + ch) * 2;
+                s1 += q[0]; s2 += q[1];
+            }
+            group_reduce2(s1, s2, shred, grp, c);   // every row-group now holds the full per-image sums
         }
-        group_reduce2(s1, s2, shred, grp, c);   // every row-group now holds the full per-image sums
         S1 += s1; S2 += s2;
         if (grp != 0) continue;                 // wave 0 (lane = channel) does the per-image attention input
         const double m0 = s1 / HW;
@@ -249,6 +276,10 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArg
 }
 hipError_t launch_attn_train_fwd(const AttnTrainArgs &a, hipStream_t st) {
     if (a.B > 64 || a.B < 2) return hipErrorInvalidValue;
+    if (a.stats64) {
+        if (a.stat_ld % 64) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(inst_stats_kernel, dim3(a.B, a.stat_ld / 64), dim3(256), 0, st, a.stats, a.chunks, a.stat_ld, a.stats64);
+    }
     hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(NUM_HEADS), dim3(1024), 0, st, a);
     return hipGetLastError();
 }

@@ -453,6 +453,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
         float *stats = b.alloc((size_t)B * at.chunks * at.stat_ld * 2);
         c3.stats = stats; c3.stat_shift = h->head_rm;
         at.stats = stats; at.B = B; at.HW = HW;
+        at.stats64 = reinterpret_cast<double *>(b.alloc((size_t)B * at.stat_ld * 4));   // [B][stat_ld][2] doubles
         at.sv_inst = b.alloc((size_t)B * CP * 3); at.mu_r = b.alloc((size_t)CP * 2); at.bn10 = b.alloc(NUM_HEADS * NUM_AFFINE * 2);
         at.that = b.alloc((size_t)B * NUM_HEADS * NUM_AFFINE); at.yatt = b.alloc((size_t)B * NUM_HEADS * NUM_AFFINE);
         at.gamma_p = b.alloc((size_t)B * CP); at.scale = b.alloc((size_t)B * CP); at.shift = b.alloc((size_t)B * CP);

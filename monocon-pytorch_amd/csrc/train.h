@@ -87,6 +87,7 @@ hipError_t launch_dpred_pack(const float *const dpred[10], int ld, int B, int HW
 struct AttnTrainArgs {
     const float *stats;            // [B][chunks][stat_ld][2] partial (sum, sumsq) of (x - running_mean)
     int chunks, stat_ld, B, HW;
+    double *stats64;               // [B][stat_ld][2] scratch: the partials of every image summed in fp64 (fixed order)
     float *rm[9], *rv[9];          // AttnBN running statistics (updated in place, momentum 0.03)
     long long *nbt[9];
     const float *att_w[9], *att_g[9], *att_b[9];
