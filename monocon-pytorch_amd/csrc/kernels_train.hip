@@ -18,10 +18,15 @@ static inline int grid_for(size_t total, int bs, int cap = 16384) {
 
 // ------------------------------------------------------------------ per-(image,row-block,channel) sums
 // mode 0: (sum(y - shift), sum((y - shift)^2));  mode 1: d = relu ? dz*[z>0] : dz -> (sum d, sum d*y)
-constexpr int RED_ROWS = 256;
+// rows per workgroup: 256, halved (down to 32) while the launch would not fill the chip
+static int red_rows(int B, int rows_per_img) {
+    int r = 256;
+    while (r > 32 && (long long)B * ((rows_per_img + r - 1) / r) < 1024) r >>= 1;
+    return r;
+}
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restrict__ y, const float *__restrict__ dz,
                                                           const float *__restrict__ z, const float *__restrict__ shift,
-                                                          int rows_per_img, int C, int mode, int relu,
+                                                          int rows_per_img, int RED_ROWS, int C, int mode, int relu,
                                                           float *__restrict__ partial, int Cstride,
                                                           const float *__restrict__ fa, const float *__restrict__ fb) {
     const int C4 = C >> 2;
@@ -93,37 +98,40 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
         for (int j = 0; j < 4; ++j) { dst[j * 2] = a1[j]; dst[j * 2 + 1] = a2[j]; }
     }
 }
-int chan_reduce_blocks(int B, int rows_per_img) { return B * ((rows_per_img + RED_ROWS - 1) / RED_ROWS); }
+int chan_reduce_blocks(int B, int rows_per_img) {
+    const int r = red_rows(B, rows_per_img);
+    return B * ((rows_per_img + r - 1) / r);
+}
 hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, const float *shift, int B, int rows_per_img,
                               int C, int mode, int relu, float *partial, int Cstride, hipStream_t st, const float *fa,
                               const float *fb) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
     if (relu == 2 && (!fa || !fb)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(chan_reduce_kernel, dim3(chan_reduce_blocks(B, rows_per_img)), dim3(256), 0, st, y, dz, z, shift,
-                       rows_per_img, C, mode, relu, partial, Cstride, fa, fb);
+                       rows_per_img, red_rows(B, rows_per_img), C, mode, relu, partial, Cstride, fa, fb);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ BatchNorm (train) finalise
 // partial: [nb][Cstride][2] sums of (y - shift), (y - shift)^2 over n = nb * rows values per channel.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int nb, int Cstride, double n,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ partial, int nb, int Cstride, double n,
                                                           const float *shift, const float *gamma, const float *beta,
                                                           float eps, float momentum, float *running_mean,
                                                           float *running_var, long long *nbt, float *a_out, float *b_out,
                                                           float *mean_out, float *rstd_out) {
     const int c = blockIdx.x;
     double s1 = 0, s2 = 0;
-    for (int i = threadIdx.x; i < nb; i += 256) {
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
         const float *p = partial + ((size_t)i * Cstride + c) * 2;
         s1 += p[0]; s2 += p[1];
     }
-    __shared__ double sh[8];
+    __shared__ double sh[32];
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((threadIdx.x & 63) == 0) { sh[(threadIdx.x >> 6) * 2] = s1; sh[(threadIdx.x >> 6) * 2 + 1] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        s1 = sh[0] + sh[2] + sh[4] + sh[6];
-        s2 = sh[1] + sh[3] + sh[5] + sh[7];
+        s1 = s2 = 0;
+        for (int w = 0; w < (int)blockDim.x / 64; ++w) { s1 += sh[w * 2]; s2 += sh[w * 2 + 1]; }
         const double m0 = s1 / n;
         const double mean = (shift ? (double)shift[c] : 0.0) + m0;
         double var = s2 / n - m0 * m0;
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
 hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
                               const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
                               long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nb, Cstride, n, shift, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nb >= 2048 ? 1024 : 256), 0, st, partial, nb, Cstride, n, shift, gamma, beta, eps,
                        momentum, rm, rv, nbt, a, b, mean, rstd);
     return hipGetLastError();
 }
@@ -229,23 +237,23 @@ hipError_t launch_affine_act(const float *y, const float *a, const float *b, con
 // ------------------------------------------------------------------ BatchNorm backward finalise
 // partial: [nb][Cstride][2] = (sum d, sum d*y).  dy = P*d + Q*y + R with
 //   P = a, Q = -a*r*S2/n, R = -a*S1/n + a*r*mean*S2/n,  S2 = r*(sum d*y - mean*sum d);  dgamma = S2, dbeta = S1.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb, int Cstride,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb, int Cstride,
                                                               double n, const float *gamma, const float *mean,
                                                               const float *rstd, float *dgamma, float *dbeta,
                                                               float *coef /*[C][4]*/) {
     const int c = blockIdx.x;
     double s1 = 0, s2 = 0;
-    for (int i = threadIdx.x; i < nb; i += 256) {
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
         const float *p = partial + ((size_t)i * Cstride + c) * 2;
         s1 += p[0]; s2 += p[1];
     }
-    __shared__ double sh[8];
+    __shared__ double sh[32];
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((threadIdx.x & 63) == 0) { sh[(threadIdx.x >> 6) * 2] = s1; sh[(threadIdx.x >> 6) * 2 + 1] = s2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        s1 = sh[0] + sh[2] + sh[4] + sh[6];
-        s2 = sh[1] + sh[3] + sh[5] + sh[7];
+        s1 = s2 = 0;
+        for (int w = 0; w < (int)blockDim.x / 64; ++w) { s1 += sh[w * 2]; s2 += sh[w * 2 + 1]; }
         const double r = rstd[c], mu = mean[c], g = gamma ? gamma[c] : 1.0;
         const double S2 = r * (s2 - mu * s1);
         if (dgamma) dgamma[c] = (float)S2;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
 hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
                                   const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
                                   hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nb, Cstride, n, gamma, mean, rstd, dgamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(nb >= 2048 ? 1024 : 256), 0, st, partial, nb, Cstride, n, gamma, mean, rstd, dgamma,
                        dbeta, coef);
     return hipGetLastError();
 }

@@ -183,15 +183,41 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_mfma_kernel(const Wgrad
 }
 
 // dW (O,I,kh,kw) = sum_ks partial[ks][tap][n][c]
+// The layers with few weights have the deepest split (64x64x9 weights: 512 slices), so the slices
+// are spread over KL lanes of the workgroup (fixed order: lane kl sums slices kl, kl+KL, ...; lane 0
+// then adds the KL lane sums in order) instead of one long dependent chain per element.
+template <int KL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, int ksplit, int T, int Cout,
                                                            int Cin, float *__restrict__ dw) {
-    const size_t total = (size_t)T * Cout * Cin;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += partial[(size_t)k * total + e];
-        const int c = e % Cin, n = (e / Cin) % Cout, t = e / ((size_t)Cin * Cout);
-        dw[((size_t)n * Cin + c) * T + t] = s;
+    constexpr int EL = 256 / KL;                      // float4 columns per workgroup
+    __shared__ f32x4 red[KL > 1 ? KL : 1][EL];
+    const size_t total = (size_t)T * Cout * Cin;      // multiple of 4 (Cin is)
+    const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
+    const size_t e = ((size_t)blockIdx.x * EL + el) * 4;
+    const bool live = e < total;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float *p = partial + e + (size_t)kl * total;
+#pragma unroll 4
+        for (int k = kl; k < ksplit; k += KL, p += (size_t)KL * total) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
     }
+    if (KL > 1) {
+        red[kl][el] = s;
+        __syncthreads();
+        if (kl != 0) return;
+        for (int j = 1; j < KL; ++j) {
+            const f32x4 v = red[j][el];
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+    }
+    if (!live) return;
+    const int c = e % Cin, n = (e / Cin) % Cout, t = e / ((size_t)Cin * Cout);
+    float *d = dw + ((size_t)n * Cin + c) * T + t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[(size_t)q * T] = s[q];
 }
 
 
@@ -381,10 +407,14 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
     }
     if (e != hipSuccess) return e;
     const size_t total = (size_t)ks * ks * a.Cout * a.Cin;
-    size_t gsz = (total + 255) / 256;
-    if (gsz > 4096) gsz = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, st, a.partial, a.ksplit, ks * ks, a.Cout, a.Cin,
-                       dw_oihw);
+    const int T = ks * ks;
+#define WR_LAUNCH(KL_)                                                                                              \
+    hipLaunchKernelGGL((wgrad_reduce_kernel<KL_>), dim3((unsigned)((total / 4 + 256 / KL_ - 1) / (256 / KL_))), \
+                       dim3(256), 0, st, a.partial, a.ksplit, T, a.Cout, a.Cin, dw_oihw)
+    if (a.ksplit >= 32) WR_LAUNCH(16);
+    else if (a.ksplit >= 4) WR_LAUNCH(4);
+    else WR_LAUNCH(1);
+#undef WR_LAUNCH
     return hipGetLastError();
 }
 

@@ -61,7 +61,7 @@ def test_forward_vs_oracle_other_shape(eng):
         assert rel_err(v.cpu(), ref[k]) < TOL, k
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 128), (2, 128, 512), (5, 64, 64), (2, 32, 2048), (1, 160, 1280)],
+@pytest.mark.parametrize("shape", [(1, 64, 128), (2, 128, 512), (5, 64, 64), (2, 32, 2048), (1, 160, 1280), (1, 384, 1248)],
                          ids=lambda s: "B%d_%dx%d" % s)
 def test_forward_shape_sweep_vs_oracle(eng, shape):
     """batch 1 / odd batches / widths that do and do not qualify for the 16-channel row kernels (Wout % 16),

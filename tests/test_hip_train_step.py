@@ -126,7 +126,7 @@ def test_train_step_with_fused_optimizer_reduces_loss(golden_sd):
     assert all(torch.isfinite(v).all() for v in out.values())
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 128), (2, 128, 512), (5, 96, 160)], ids=lambda s: "B%d_%dx%d" % s)
+@pytest.mark.parametrize("shape", [(3, 64, 128), (2, 128, 512), (5, 96, 160), (2, 96, 1248)], ids=lambda s: "B%d_%dx%d" % s)
 def test_train_forward_shape_sweep_vs_oracle(golden_sd, shape):
     """odd batches / other resolutions through the train plan (autotuned conv shapes, 16-channel row kernels
     where the width allows, parity-class stride-2 data gradients): losses vs the CPU oracle's train forward,
