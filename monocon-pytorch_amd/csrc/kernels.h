@@ -64,6 +64,7 @@ struct HeadApplyArgs {
     float *pred[10];         // NCHW outputs
     int pred_c[10];
     int B, HW;
+    float *z_out;            // optional [B][HW][576]: the normalised + ReLU'd hidden maps (saved for the train-mode backward)
 };
 hipError_t launch_head_apply(const HeadApplyArgs &a, hipStream_t st);
 const HeadRow *head_rows();          // host table, NUM_OUT_ROWS entries, grouped by head

@@ -83,6 +83,96 @@ hipError_t launch_head_w1_extract(const float *dense_grad, const int *row_head, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ backward of the nine 1x1 convs, fused
+// One pass over the hidden maps does everything between the raw-output gradient and the AttnBN backward:
+//   dW1[r][c]  = sum_px draw[px][r] * z[px][head(r)*64 + c]                (partials per workgroup)
+//   d[px][hc]  = [z > 0] * sum_{r in head} draw[px][r] * W1[r][c]          (ReLU-masked data gradient, written)
+//   (sum d, sum d*x) per (image, row block, channel)                        (the chan_reduce mode-1 partials)
+// A wave owns one head (lane = channel, so every z / x / d access is one 256-byte row), the rows of
+// draw are wave-uniform and come down the scalar path.  Replaces a dense 576->65 wgrad, a dense 65->576
+// dgrad (8/9 of both multiplying structural zeros) and a three-tensor reduction pass.
+// (reference model/dense_heads/monocon_heads.py:119-120 under autograd)
+struct HeadBwdArgs {
+    const float *draw; int ld;
+    const float *z, *x, *w1;
+    float *d, *dw_partial, *red_partial;
+    int HW, rows_per_block, blocks_per_img;
+};
+template <int RB, int NR>
+__device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, int h, int lane, size_t p0, int np, int blk) {
+    constexpr int CP = NUM_HEADS * HEAD_CH;
+    typedef const float __attribute__((address_space(4))) cfloat;
+    float w[NR], acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { w[r] = a.w1[(RB + r) * HEAD_CH + lane]; acc[r] = 0.f; }
+    float s1 = 0.f, s2 = 0.f;
+    const float *zp = a.z + p0 * CP + h * HEAD_CH + lane, *xp = a.x + p0 * CP + h * HEAD_CH + lane;
+    float *dp = a.d + p0 * CP + h * HEAD_CH + lane;
+    auto one = [&](int i, float zv, float xv) {
+        cfloat *g = (cfloat *)(uintptr_t)(a.draw + (p0 + i) * a.ld + RB);
+        float dh = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float gv = g[r];
+            acc[r] = fmaf(gv, zv, acc[r]);
+            dh = fmaf(gv, w[r], dh);
+        }
+        const float dv = zv > 0.f ? dh : 0.f;
+        s1 += dv;
+        s2 = fmaf(dv, xv, s2);
+        dp[(size_t)i * CP] = dv;
+    };
+    constexpr int U = 8;
+    int i = 0;
+    for (; i + U <= np; i += U) {
+        float zv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { zv[u] = zp[(size_t)(i + u) * CP]; xv[u] = xp[(size_t)(i + u) * CP]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(i + u, zv[u], xv[u]);
+    }
+    for (; i < np; ++i) one(i, zp[(size_t)i * CP], xp[(size_t)i * CP]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) a.dw_partial[((size_t)blk * NUM_OUT_ROWS + RB + r) * HEAD_CH + lane] = acc[r];
+    float *rp = a.red_partial + ((size_t)blk * CP + h * HEAD_CH + lane) * 2;
+    rp[0] = s1;
+    rp[1] = s2;
+}
+__global__ __launch_bounds__(NUM_HEADS * 64) void head_bwd_kernel(const HeadBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x;
+    const int b = blk / a.blocks_per_img, rb = blk % a.blocks_per_img;
+    const int r0 = rb * a.rows_per_block;
+    const int np = min(a.HW, r0 + a.rows_per_block) - r0;
+    const size_t p0 = (size_t)b * a.HW + r0;
+    switch (h) {   // (first row, row count) of each head in HeadRow order
+        case 0: head_bwd_rows<0, 3>(a, h, lane, p0, np, blk); break;
+        case 1: head_bwd_rows<3, 2>(a, h, lane, p0, np, blk); break;
+        case 2: head_bwd_rows<5, 2>(a, h, lane, p0, np, blk); break;
+        case 3: head_bwd_rows<7, 18>(a, h, lane, p0, np, blk); break;
+        case 4: head_bwd_rows<25, 9>(a, h, lane, p0, np, blk); break;
+        case 5: head_bwd_rows<34, 2>(a, h, lane, p0, np, blk); break;
+        case 6: head_bwd_rows<36, 3>(a, h, lane, p0, np, blk); break;
+        case 7: head_bwd_rows<39, 2>(a, h, lane, p0, np, blk); break;
+        default: head_bwd_rows<41, 24>(a, h, lane, p0, np, blk); break;
+    }
+}
+// blocks = chan_reduce_blocks(B, HW); rows_per_block = that partition's row count (kernels_train.hip)
+hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const float *x, const float *w1, int B, int HW,
+                           int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st) {
+    const int *rbeg = head_row_begin();
+    static const int RB[NUM_HEADS + 1] = {0, 3, 5, 7, 25, 34, 36, 39, 41, 65};
+    for (int i = 0; i <= NUM_HEADS; ++i)
+        if (rbeg[i] != RB[i]) return hipErrorInvalidValue;      // the switch above hard-codes the HeadRow table
+    if (blocks % B) return hipErrorInvalidValue;
+    HeadBwdArgs a;
+    a.draw = draw; a.ld = ld; a.z = z; a.x = x; a.w1 = w1; a.d = d; a.dw_partial = dw_partial; a.red_partial = red_partial;
+    a.HW = HW; a.blocks_per_img = blocks / B; a.rows_per_block = (HW + a.blocks_per_img - 1) / a.blocks_per_img;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(NUM_HEADS * 64), 0, st, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ raw (B,HW,ld) -> NCHW predictions (+ epilogues)
 struct HeadActArgs {
     const float *raw;

@@ -420,8 +420,11 @@ __global__ __launch_bounds__(192) void head_apply_kernel(const HeadApplyArgs a) 
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int px = it * 4 + (lane >> 4);
+        f32x4 zv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hl[px * 65 + c4 * 4 + j] = fmaxf(fmaf(v[it][j], sc[j], sh[j]), 0.f);
+        for (int j = 0; j < 4; ++j) hl[px * 65 + c4 * 4 + j] = zv[j] = fmaxf(fmaf(v[it][j], sc[j], sh[j]), 0.f);
+        if (a.z_out && hw0 + px < a.HW)
+            *reinterpret_cast<f32x4 *>(a.z_out + ((size_t)b * a.HW + hw0 + px) * (NUM_HEADS * HEAD_CH) + h * HEAD_CH + c4 * 4) = zv;
     }
     __syncthreads();
     const int hw = hw0 + lane;

@@ -458,40 +458,24 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
         at.that = b.alloc((size_t)B * NUM_HEADS * NUM_AFFINE); at.yatt = b.alloc((size_t)B * NUM_HEADS * NUM_AFFINE);
         at.gamma_p = b.alloc((size_t)B * CP); at.scale = b.alloc((size_t)B * CP); at.shift = b.alloc((size_t)B * CP);
     }
-    // block-diagonal 1x1: dense (65, 576) master copy, forward panel, dgrad panel
-    float *w1dense = b.alloc((size_t)NUM_OUT_ROWS * CP);
-    const int c1p = conv_coutp(NUM_OUT_ROWS);
-    float *w1panel = b.alloc((size_t)CP * c1p);
-    int *row_head = reinterpret_cast<int *>(b.alloc(NUM_OUT_ROWS));
-    {
-        std::vector<int> rh(NUM_OUT_ROWS);
-        const HeadRow *rows = head_rows();
-        for (int r = 0; r < NUM_OUT_ROWS; ++r) rh[r] = rows[r].head;
-        if (hipMemcpy(row_head, rh.data(), NUM_OUT_ROWS * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) ts->ok = false;
-    }
     float *w3dense = b.alloc((size_t)CP * 64 * 9);
-    ConvArgs c1{};
-    c1.nsrc = 1; c1.src[0].p = hn.p; c1.src[0].C = CP;
-    c1.B = B; c1.Hin = fh; c1.Win = fw; c1.Hout = fh; c1.Wout = fw; c1.Cin = CP; c1.Cout = NUM_OUT_ROWS; c1.CoutP = c1p;
-    c1.wpk = w1panel; c1.bias = h->head_b1; c1.out = raw.p; c1.out_ld = LD;
-    c1.cfg = ts->ok ? mc_choose_conv_cfg(h, c1, 1, 1) : CFG_128x32;
+    // AttnBN apply + ReLU + the nine 1x1 convs + prediction epilogues in ONE pass over the hidden maps
+    // (head_apply_kernel, the inference kernel), which also stores the normalised maps for the backward
+    HeadApplyArgs ha{};
     {
-        const float *w1 = h->head_w1, *scale = at.scale, *shift = at.shift;
-        ts->pack_fns.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_head_w1_dense(w1, row_head, w1dense, st));
-            HIPCHK(hh, launch_pack_conv_w(w1dense, NUM_OUT_ROWS, CP, 1, w1panel, CP, c1p, 0, 0, st));
-            return 0;
-        });
-        float *xp = xh.p, *hp = hn.p, *rawp = raw.p;
+        ha.hidden = xh.p; ha.scale = at.scale; ha.shift = at.shift; ha.w = h->head_w1t; ha.b = h->head_b1;
+        ha.B = B; ha.HW = HW; ha.z_out = hn.p;
+        static const int PCH[10] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
+        for (int i = 0; i < 10; ++i) ha.pred_c[i] = PCH[i];     // the prediction pointers are per call (ts->preds)
         // one closure per kernel family so that mc_profile_train attributes the durations correctly
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(c3, 3, 1, st)); return 0; });
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
             HIPCHK(hh, launch_attn_train_fwd(at, st));
-            HIPCHK(hh, launch_affine_act(xp, scale, shift, nullptr, B, (size_t)HW, CP, 1, 1, hp, st));
+            HeadApplyArgs a2 = ha;
+            for (int i = 0; i < 10; ++i) a2.pred[i] = ts->preds[i];
+            HIPCHK(hh, launch_head_apply(a2, st));
             return 0;
         });
-        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(c1, 1, 1, st)); return 0; });
-        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_head_act(rawp, LD, B, HW, ts->preds, st)); return 0; });
     }
     // targets + losses
     {
@@ -534,19 +518,19 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
     {
         float *draw = b.alloc(raw.numel());
         float *cs1 = b.alloc(colsum_partial_floats((size_t)B * HW, LD));
-        float *db1 = b.alloc(NUM_OUT_ROWS), *dw1dense = b.alloc((size_t)NUM_OUT_ROWS * CP), *dw1 = b.alloc((size_t)NUM_OUT_ROWS * HEAD_CH);
-        Tensor drawT = raw; drawT.p = draw;
+        float *db1 = b.alloc(NUM_OUT_ROWS), *dw1 = b.alloc((size_t)NUM_OUT_ROWS * HEAD_CH);
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
             if (mc_losses_backward(hh, ts->preds, &ts->targets, B, ts->max_objs, fh, fw, ts->grad_losses, ts->dpred, st)) return -1;
             HIPCHK(hh, launch_dpred_pack(ts->dpred, LD, B, HW, draw, st));
             HIPCHK(hh, launch_colsum(draw, (size_t)B * HW, NUM_OUT_ROWS, LD, cs1, db1, st));
             return 0;
         });
-        // dense wgrad of the block-diagonal 1x1, then keep the diagonal blocks
-        TNode hnode; hnode.t = hn; hnode.needs_grad = false;
-        ts->nodes.push_back(hnode);
-        const int hn_idx = (int)ts->nodes.size() - 1;
-        b.emit_wgrad({hn_idx}, drawT, LD, NUM_OUT_ROWS, 1, 1, dw1dense);
+        // the nine 1x1 convs backwards in one pass (head_bwd_kernel): weight-gradient partials, the ReLU-masked
+        // data gradient d, and the (sum d, sum d*x) partials of the AttnBN backward
+        const int nbr = chan_reduce_blocks(B, HW), rb_per_img = nbr / B;
+        float *dh = b.alloc(xh.numel());
+        float *dw1p = b.alloc((size_t)nbr * NUM_OUT_ROWS * HEAD_CH);
+        float *partial = b.alloc((size_t)nbr * CP * 2), *coef = b.alloc((size_t)B * CP * 4), *dx = b.alloc(xh.numel());
         // scatter dw1 / db1 rows to the parameter gradient tensors (rows are in concatenation order)
         const int *rb = head_row_begin();
         struct Seg { float *dst_w, *dst_b; int r0, nr; };
@@ -556,37 +540,27 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
                                rb[hd], rb[hd + 1] - rb[hd]});
         segs.push_back(Seg{b.G("head.dir_cls.0.weight"), b.G("head.dir_cls.0.bias"), rb[8], 12});
         segs.push_back(Seg{b.G("head.dir_reg.0.weight"), b.G("head.dir_reg.0.bias"), rb[8] + 12, 12});
-        ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_head_w1_extract(dw1dense, row_head, dw1, st));
-            for (const Seg &s : segs) {
-                HIPCHK(hh, hipMemcpyAsync(s.dst_w, dw1 + (size_t)s.r0 * HEAD_CH, (size_t)s.nr * HEAD_CH * 4, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hh, hipMemcpyAsync(s.dst_b, db1 + s.r0, (size_t)s.nr * 4, hipMemcpyDeviceToDevice, st));
-            }
-            return 0;
-        });
-        // dh = draw x W1^T  (dgrad of the 1x1), AttnBN backward, dx
-        float *dh = b.alloc(xh.numel());
         {
-            float *panel; int csp;
-            b.pack_job(w1dense, NUM_OUT_ROWS, CP, 1, 0, CP, LD, &panel, &csp);
-            ConvArgs d{};
-            d.nsrc = 1; d.src[0].p = draw; d.src[0].C = LD;
-            d.B = B; d.Hin = fh; d.Win = fw; d.Hout = fh; d.Wout = fw; d.Cin = LD; d.Cout = CP; d.CoutP = csp; d.wpk = panel;
-            d.out = dh; d.out_ld = CP;
-            d.cfg = ts->ok ? mc_choose_conv_cfg(h, d, 1, 1) : CFG_128x32;
-            ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(d, 1, 1, st)); return 0; });
+            const float *xp = xh.p, *hp = hn.p, *w1 = h->head_w1;
+            ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
+                HIPCHK(hh, launch_head_bwd(draw, LD, hp, xp, w1, B, HW, nbr, dh, dw1p, partial, st));
+                HIPCHK(hh, launch_splitk_reduce(dw1p, nbr, 1, NUM_OUT_ROWS, HEAD_CH, dw1, st));
+                for (const Seg &s : segs) {
+                    HIPCHK(hh, hipMemcpyAsync(s.dst_w, dw1 + (size_t)s.r0 * HEAD_CH, (size_t)s.nr * HEAD_CH * 4, hipMemcpyDeviceToDevice, st));
+                    HIPCHK(hh, hipMemcpyAsync(s.dst_b, db1 + s.r0, (size_t)s.nr * 4, hipMemcpyDeviceToDevice, st));
+                }
+                return 0;
+            });
         }
-        const int nbr = chan_reduce_blocks(B, HW), rb_per_img = nbr / B;
-        float *partial = b.alloc((size_t)nbr * CP * 2), *coef = b.alloc((size_t)B * CP * 4), *dx = b.alloc(xh.numel());
         float *db3 = b.alloc(CP), *dw3 = b.alloc((size_t)CP * 64 * 9);
         float *cs3 = b.alloc(colsum_partial_floats((size_t)B * HW, CP));
         Tensor dxT = xh; dxT.p = dx;
         {
             const float *xp = xh.p, *hp = hn.p;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_chan_reduce(xp, dh, hp, nullptr, B, HW, CP, 1, 1, partial, CP, st));
+                // d is already masked: the AttnBN backward is the plain per-(image, channel) affine map
                 HIPCHK(hh, launch_attn_train_bwd(at, partial, rb_per_img, gp, coef, st));
-                HIPCHK(hh, launch_affine_bwd(dh, hp, xp, coef, B, (size_t)HW, CP, 1, 1, dx, nullptr, 0, st));
+                HIPCHK(hh, launch_affine_bwd(dh, hp, xp, coef, B, (size_t)HW, CP, 1, 0, dx, nullptr, 0, st));
                 HIPCHK(hh, launch_colsum(dx, (size_t)B * HW, CP, CP, cs3, db3, st));
                 return 0;
             });

@@ -106,6 +106,9 @@ struct AttnGradPtrs { float *d_weight_[9], *d_bias_[9], *d_att_w[9], *d_att_g[9]
 hipError_t launch_attn_train_fwd(const AttnTrainArgs &a, hipStream_t st);
 hipError_t launch_attn_train_bwd(const AttnTrainArgs &a, const float *partial, int rb_per_img, const AttnGradPtrs &gp,
                                  float *coef, hipStream_t st);
+hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const float *x, const float *w1, int B, int HW,
+                           int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st);
+hipError_t launch_splitk_reduce(const float *partial, int ksplit, int T, int Cout, int Cin, float *dw, hipStream_t st);
 int stem_wgrad_blocks(int B, int H, int W);
 hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
                              hipStream_t st);

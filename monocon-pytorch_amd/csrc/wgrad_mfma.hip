@@ -406,13 +406,19 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
         }
     }
     if (e != hipSuccess) return e;
-    const size_t total = (size_t)ks * ks * a.Cout * a.Cin;
-    const int T = ks * ks;
+    return launch_splitk_reduce(a.partial, a.ksplit, ks * ks, a.Cout, a.Cin, dw_oihw, st);
+}
+
+// dw (Cout, Cin, T) = sum over `ksplit` slices of partial[slice][T][Cout][Cin]   (Cin % 4 == 0)
+hipError_t launch_splitk_reduce(const float *partial, int ksplit, int T, int Cout, int Cin, float *dw, hipStream_t st) {
+    if (Cin % 4) return hipErrorInvalidValue;
+    const size_t total = (size_t)T * Cout * Cin;
 #define WR_LAUNCH(KL_)                                                                                              \
     hipLaunchKernelGGL((wgrad_reduce_kernel<KL_>), dim3((unsigned)((total / 4 + 256 / KL_ - 1) / (256 / KL_))), \
-                       dim3(256), 0, st, a.partial, a.ksplit, T, a.Cout, a.Cin, dw_oihw)
-    if (a.ksplit >= 32) WR_LAUNCH(16);
-    else if (a.ksplit >= 4) WR_LAUNCH(4);
+                       dim3(256), 0, st, partial, ksplit, T, Cout, Cin, dw)
+    if (ksplit >= 2048 && total <= 65536) WR_LAUNCH(64);
+    else if (ksplit >= 32) WR_LAUNCH(16);
+    else if (ksplit >= 4) WR_LAUNCH(4);
     else WR_LAUNCH(1);
 #undef WR_LAUNCH
     return hipGetLastError();
