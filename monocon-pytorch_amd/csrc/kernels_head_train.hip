@@ -5,12 +5,11 @@
 // model/norm/attentive_norm.py:79-91,154-164 under autograd):
 //   x   = conv3x3(feat) + bias                      fused MFMA conv, 9 heads side by side (576 ch)
 //   AttnBN statistics / attention / per-sample affine            attn_train_fwd_kernel (one WG per head)
-//   h   = relu(scale_bc * x + shift_bc)             affine_act (per-sample coefficients)
-//   raw = conv1x1(h; block-diagonal 576 -> 65) + b  fused MFMA conv (zeros outside the blocks)
-//   pred = sigmoid/clamp | depth transform | identity, NCHW      head_act_kernel
-// and the mirror image backwards; the AttnBN backward reduces to one per-(image, channel)
-// affine map dx = P*dout + Q*x + R (attn_train_bwd_kernel computes P, Q, R and all the small
-// parameter gradients).
+//   h   = relu(scale_bc * x + shift_bc), nine 1x1 convs + b, sigmoid/clamp | depth transform | identity,
+//         NCHW predictions                          head_apply_kernel (kernels_misc.hip; also stores h)
+// backwards: head_bwd_kernel (1x1 weight gradients, ReLU-masked data gradient, AttnBN reductions in one
+// pass); the AttnBN backward then reduces to one per-(image, channel) affine map dx = P*d + Q*x + R
+// (attn_train_bwd_kernel computes P, Q, R and all the small parameter gradients).
 #include "kernels.h"
 #include "train.h"
 
@@ -52,34 +51,6 @@ hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int 
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(pack_conv_w_dgrad_kernel, dim3((unsigned)g), dim3(256), 0, st, w, Cout, CinTotal, k, c_off, Cs, CsP,
                        CoutPad, cls, dst);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------ block-diagonal 1x1 head weights
-// dense (65, 576): row r (head h(r)) holds its 64 weights at columns [64 h, 64 h + 64)
-__global__ void head_w1_dense_kernel(const float *__restrict__ w1 /*[65][64]*/, const int *__restrict__ row_head,
-                                     float *__restrict__ dense /*[65][576]*/) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= NUM_OUT_ROWS * NUM_HEADS * HEAD_CH) return;
-    const int r = e / (NUM_HEADS * HEAD_CH), col = e % (NUM_HEADS * HEAD_CH);
-    const int h = col / HEAD_CH, c = col % HEAD_CH;
-    dense[e] = (row_head[r] == h) ? w1[r * HEAD_CH + c] : 0.f;
-}
-__global__ void head_w1_extract_kernel(const float *__restrict__ dense_grad /*[65][576]*/, const int *__restrict__ row_head,
-                                       float *__restrict__ dw1 /*[65][64]*/) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= NUM_OUT_ROWS * HEAD_CH) return;
-    const int r = e / HEAD_CH, c = e % HEAD_CH;
-    dw1[e] = dense_grad[(size_t)r * NUM_HEADS * HEAD_CH + row_head[r] * HEAD_CH + c];
-}
-hipError_t launch_head_w1_dense(const float *w1, const int *row_head, float *dense, hipStream_t st) {
-    hipLaunchKernelGGL(head_w1_dense_kernel, dim3((NUM_OUT_ROWS * NUM_HEADS * HEAD_CH + 255) / 256), dim3(256), 0, st, w1,
-                       row_head, dense);
-    return hipGetLastError();
-}
-hipError_t launch_head_w1_extract(const float *dense_grad, const int *row_head, float *dw1, hipStream_t st) {
-    hipLaunchKernelGGL(head_w1_extract_kernel, dim3((NUM_OUT_ROWS * HEAD_CH + 255) / 256), dim3(256), 0, st, dense_grad,
-                       row_head, dw1);
     return hipGetLastError();
 }
 
@@ -173,42 +144,6 @@ hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const floa
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ raw (B,HW,ld) -> NCHW predictions (+ epilogues)
-struct HeadActArgs {
-    const float *raw;
-    int ld, B, HW;
-    float *pred[10];
-    int row_pred[NUM_OUT_ROWS], row_ch[NUM_OUT_ROWS], row_epi[NUM_OUT_ROWS], pred_c[10];
-};
-__global__ __launch_bounds__(256) void head_act_kernel(const HeadActArgs a) {
-    __shared__ float t[64][NUM_OUT_ROWS + 2];
-    const int tiles = (a.HW + 63) / 64;
-    const int b = blockIdx.x / tiles, hw0 = (blockIdx.x % tiles) * 64;
-    for (int e = threadIdx.x; e < 64 * NUM_OUT_ROWS; e += 256) {
-        const int px = e / NUM_OUT_ROWS, r = e % NUM_OUT_ROWS;
-        t[px][r] = (hw0 + px < a.HW) ? a.raw[((size_t)b * a.HW + hw0 + px) * a.ld + r] : 0.f;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * NUM_OUT_ROWS; e += 256) {
-        const int r = e / 64, px = e % 64;
-        if (hw0 + px >= a.HW) continue;
-        float v = t[px][r];
-        if (a.row_epi[r] == 1) v = fminf(fmaxf(1.0f / (1.0f + expf(-v)), 1e-4f), 1.0f - 1e-4f);
-        else if (a.row_epi[r] == 2) v = 1.0f / (1.0f / (1.0f + expf(-v)) + 1e-12f) - 1.0f;
-        const int p = a.row_pred[r];
-        a.pred[p][((size_t)b * a.pred_c[p] + a.row_ch[r]) * a.HW + hw0 + px] = v;
-    }
-}
-hipError_t launch_head_act(const float *raw, int ld, int B, int HW, float *const pred[10], hipStream_t st) {
-    HeadActArgs a;
-    a.raw = raw; a.ld = ld; a.B = B; a.HW = HW;
-    const HeadRow *rows = head_rows();
-    static const int PC[10] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
-    for (int i = 0; i < 10; ++i) { a.pred[i] = pred[i]; a.pred_c[i] = PC[i]; }
-    for (int r = 0; r < NUM_OUT_ROWS; ++r) { a.row_pred[r] = rows[r].pred; a.row_ch[r] = rows[r].ch; a.row_epi[r] = rows[r].epi; }
-    hipLaunchKernelGGL(head_act_kernel, dim3(B * ((HW + 63) / 64)), dim3(256), 0, st, a);
-    return hipGetLastError();
-}
 
 // ten NCHW gradient maps -> (B,HW,ld) rows in HeadRow order, zero-padded to ld columns
 struct DpredPackArgs {

@@ -80,9 +80,6 @@ hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H
 // ---- head / stem train kernels (kernels_head_train.hip)
 hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
                                     int cls, float *dst, hipStream_t st);
-hipError_t launch_head_w1_dense(const float *w1, const int *row_head, float *dense, hipStream_t st);
-hipError_t launch_head_w1_extract(const float *dense_grad, const int *row_head, float *dw1, hipStream_t st);
-hipError_t launch_head_act(const float *raw, int ld, int B, int HW, float *const pred[10], hipStream_t st);
 hipError_t launch_dpred_pack(const float *const dpred[10], int ld, int B, int HW, float *out, hipStream_t st);
 struct AttnTrainArgs {
     const float *stats;            // [B][chunks][stat_ld][2] partial (sum, sumsq) of (x - running_mean)
