@@ -81,8 +81,12 @@ struct DecodeArgs {
     float *box2d, *box3d;
     uint8_t *keep_localmax, *keep_thr;
     float *filt;             // workspace [B][C*H*W]
+    unsigned *cand_key;      // workspace [B][C*H*W]: order-preserving keys of the positive local maxima, in chunks
+    int *cand_idx;           // workspace [B][C*H*W]: their flat indices
+    unsigned *cand_count;    // workspace [B][chunks]: live entries at the head of each chunk (written by every call)
 };
 hipError_t launch_decode(const DecodeArgs &a, hipStream_t st);
+int decode_chunks(int n_per_image);    // candidate-list chunks per image (sizes DecodeArgs::cand_count)
 
 hipError_t launch_preprocess(const void *img_hwc, int is_u8, int H, int W, const double mean[3], const double std[3], int Hp,
                              int Wp, float *out_chw, hipStream_t st);

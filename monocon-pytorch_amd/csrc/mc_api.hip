@@ -740,14 +740,18 @@ int mc_decode(mc_handle *h, const float *const preds[MC_NUM_PREDS], const float 
         return fail(h, "mc_decode: bad shape B=%d C=%d H=%d W=%d K=%d (1 <= K <= min(1024, C*H*W))", B, C, H, W, K);
     HIPCHK(h, hipSetDevice(h->device));
     const size_t n = (size_t)B * C * H * W;
-    if (n > h->decode_filt_n) {
+    const size_t ncnt = (size_t)B * decode_chunks(C * H * W);
+    if (n > h->decode_filt_n || ncnt > h->decode_count_n) {
+        // one block: filtered map, candidate keys, candidate indices (n words each), per-(image, chunk) candidate counts
         if (h->decode_filt) HIPCHK(h, hipFree(h->decode_filt));
         h->decode_filt = nullptr;
         h->decode_filt_n = 0;
+        h->decode_count_n = 0;
         void *q = nullptr;
-        HIPCHK(h, hipMalloc(&q, n * sizeof(float)));
+        HIPCHK(h, hipMalloc(&q, (3 * n + ncnt) * sizeof(float)));
         h->decode_filt = static_cast<float *>(q);
         h->decode_filt_n = n;
+        h->decode_count_n = ncnt;
     }
     DecodeArgs a{};
     for (int i = 0; i < MC_NUM_PREDS; ++i) a.pred[i] = preds[i];
@@ -758,6 +762,9 @@ int mc_decode(mc_handle *h, const float *const preds[MC_NUM_PREDS], const float 
     a.box2d = box2d; a.box3d = box3d;
     a.keep_localmax = keep_localmax; a.keep_thr = keep_thr;
     a.filt = h->decode_filt;
+    a.cand_key = reinterpret_cast<unsigned *>(h->decode_filt + h->decode_filt_n);
+    a.cand_idx = reinterpret_cast<int *>(h->decode_filt + 2 * h->decode_filt_n);
+    a.cand_count = reinterpret_cast<unsigned *>(h->decode_filt + 3 * h->decode_filt_n);
     HIPCHK(h, launch_decode(a, static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -997,7 +1004,7 @@ int mc_set_precision(mc_handle *h, int mode) {
 // ---------------------------------------------------------------------------- introspection
 size_t mc_workspace_bytes(mc_handle *h) {
     if (!h) return 0;
-    size_t n = h->param_bytes + h->decode_filt_n * sizeof(float) + h->train_bytes;
+    size_t n = h->param_bytes + (3 * h->decode_filt_n + h->decode_count_n) * sizeof(float) + h->train_bytes;
     for (auto &kv : h->plans) n += kv.second->bytes;
     return n;
 }

@@ -96,6 +96,7 @@ struct mc_handle {
     Plan *last_plan = nullptr;
     float *decode_filt = nullptr;
     size_t decode_filt_n = 0;
+    size_t decode_count_n = 0;
     int force_cfg = 0;   // tuning aid (mc_bench_conv)
     int prec = 0;        // 0 fp32 (parity path), 1 bf16 MFMA operands (mc_set_precision)
     int autotune = 1;    // time the workgroup shapes of every distinct conv once (MONOCON_HIP_AUTOTUNE=0: heuristic)

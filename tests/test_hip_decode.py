@@ -75,6 +75,26 @@ def test_decode_ties_canonical_order(eng):
     assert torch.equal(R["scores"].cpu(), ref["scores"])
 
 
+def test_decode_fewer_positive_maxima_than_k(eng):
+    """fewer than K positive local maxima: exact zeros reach the top-K (ascending flat index) -- the selection then
+    runs over the whole filtered map instead of the compacted candidate list; a second call checks that the
+    candidate counters were left clean."""
+    from oracle import monocon_oracle as O
+    d = synth.make_decode_inputs(78, 2, 16, 32, topk=12)
+    h = d["center_heatmap_pred"]
+    h[:] = 0.0
+    h[0, 0, 5, 5] = 0.9; h[0, 2, 9, 30] = 0.7; h[0, 1, 0, 0] = 0.2
+    h[1, 1, 15, 31] = 0.6
+    for _ in range(2):
+        R = run(eng, d, 12, pad_hw=(64, 128))
+        ref = O.decode({k: torch.from_numpy(v) for k, v in d.items()}, np.stack([synth.KITTI_P2] * 2), (64, 128),
+                       topk=12, thres=0.4)
+        assert torch.equal(R["keep"].cpu().bool(), ref["keep"])
+        assert torch.equal(R["flat_index"].cpu(), ref["flat_index"])
+        assert torch.equal(R["scores"].cpu(), ref["scores"])
+        assert torch.equal(R["cls"].cpu(), ref["cls"].to(R["cls"].dtype))
+
+
 def test_decode_k_limits(eng):
     from hipmonocon.lib import MonoconHipError
     d = synth.make_decode_inputs(5, 1, 8, 8, topk=4)
