@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--forward-steps", type=int, default=10,
                     help="also time this many eval forwards (BASELINE configs[1]); 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--no-extra-modes", action="store_true",
+                    help="skip the fp32_emulated / mixed_precision legs (profiles/collect.sh: keeps the kernel trace on the headline path)")
     return ap.parse_args()
 
 
@@ -254,7 +256,7 @@ def main():
                 "forward_ms_per_step": round(fdt2 / args.forward_steps * 1e3, 3)}
 
     mixed, emulated = None, None
-    if args.forward_steps > 0:
+    if args.forward_steps > 0 and not args.no_extra_modes:
         emulated = timed_mode("bf16x3")
         emulated.update({
             "workload": "the same train step / eval forward with fp32 EMULATED on the bf16 matrix pipe: both operands of every "
@@ -291,7 +293,10 @@ def main():
         dms = (time.perf_counter() - t0) / 20 * 1e3
         dec = {"workload": "BASELINE configs[4]: decode of the ten maps, batch=%d, top-k=%d (local max + exact top-K + box "
                            "assembly; indices / keep masks bit-exact vs the oracle in tests/test_hip_decode.py)" % (DB, K),
-               "images_per_sec": round(DB / (dms * 1e-3), 1), "ms_per_batch": round(dms, 3)}
+               "images_per_sec": round(DB / (dms * 1e-3), 1), "ms_per_batch": round(dms, 3),
+               "heatmap_gb_per_s": round(DB * 3 * (H // 4) * (W // 4) * 4 / (dms * 1e-3) / 1e9, 1),
+               "note": "two launches (filter + candidate compaction, per-image select + box assembly); the only "
+                       "algorithmic traffic is one read of the 23.6 MB heat map, so this is launch- and latency-bound"}
 
     if rank == 0:
         conv, wg, oth = prof["conv"], prof["wgrad"], prof["other"]

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export MONOCON_HIP_TUNE_CACHE=/tmp/monocon_tune_cache.txt
-BENCH="timeout 600 python $ROOT/bench.py --steps 2 --warmup 1 --forward-steps 2 --no-cpu-baseline $*"
+BENCH="timeout 600 python $ROOT/bench.py --steps 2 --warmup 1 --forward-steps 2 --no-cpu-baseline --no-extra-modes $*"
 $BENCH > "$OUT/bench_plain.log" 2>&1   # warms the tune cache so the traces hold no autotuning launches
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- $BENCH > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE \
