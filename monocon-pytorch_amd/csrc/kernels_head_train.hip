@@ -467,62 +467,62 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float *__r
 }
 // ---- the same gradient on v_mfma_f32_16x16x4_f32 (see wgrad_small_kernel in wgrad_mfma.hip for the mapping):
 // A[n][k] = dY[pixel k][n] (one coalesced dword per lane), B[k][j] = img[c(t)][y + r(t) - 3][x + k + s(t) - 3] for the
-// 16 taps t = 16*jt + j of tap tile jt (ten tiles cover the 147 taps; a lane's (c, r, s) are fixed, so its image offset is
-// resolved once per row and an interior group of 4 pixels is 1 + 10 loads + 10 MFMAs with SGPR offsets only).
+// 16 taps t = 16*jt + j of tap tile jt (ten tiles cover the 147 taps).  Fetching B straight from global memory (ten
+// dword loads per group of four pixels, the 64 lanes spread over the (channel, tap-row) rows of the window) is bound by
+// the texture-address path (measured: MFMA busy 0.23, 2.2 ms); so a workgroup stages the 3 x (4+6) x (128+6) image
+// window of a 4-row x 128-pixel output tile once (coalesced), and the B operands are ds_read_b32 at immediate offsets
+// (row pitch 136: consecutive tap rows land 8 banks apart, the two K lanes of a tap share an address): 0.88 ms.
 typedef float f32x4w __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float *__restrict__ img, const float *__restrict__ dy,
-                                                              int B, int H, int W, float *__restrict__ partial) {
+constexpr int SWL_XT = 128, SWL_P = 136, SWL_ROWS = 10;
+__global__ __launch_bounds__(256) void stem_wgrad_lds_kernel(const float *__restrict__ img, const float *__restrict__ dy,
+                                                             int B, int H, int W, float *__restrict__ partial) {
     constexpr int NJT = 10;
+    __shared__ float tile[3 * SWL_ROWS * SWL_P];
     __shared__ float red[NJT * 4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = lane >> 4, j = lane & 15;
-    int toff[NJT], tr[NJT], tsx[NJT];
+    int boff[NJT];
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) {
         const int t = jt * 16 + j;
         const int c = t / 49, r = (t % 49) / 7, s = t % 7;
-        tr[jt] = t < 147 ? r - 3 : -(1 << 20);                 // dead taps: a row that is never inside the image
-        tsx[jt] = s - 3 + k;
-        toff[jt] = ((c * H + r - 3) * W + s - 3 + k) * 4;
+        boff[jt] = t < 147 ? (c * SWL_ROWS + wave + r) * SWL_P + s + k : 0;     // dead taps: any finite address
     }
     f32x4w acc[NJT];
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt) acc[jt] = f32x4w{0.f, 0.f, 0.f, 0.f};
     const int va = (k * 16 + j) * 4;
-    const int R = B * H;
-    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
-        const int b = row / H, y = row - b * H;
-        const __amdgpu_buffer_rsrc_t r_img = make_rsrc(img + (size_t)b * 3 * H * W, (unsigned)(3 * H * W) * 4u);
-        const __amdgpu_buffer_rsrc_t r_dy = make_rsrc(dy + (size_t)row * W * 16, (unsigned)(W * 16) * 4u);
-        int rowoff[NJT];
-#pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            const int yy = y + tr[jt];
-            rowoff[jt] = (yy >= 0 && yy < H) ? toff[jt] + y * W * 4 : BUF_OOB;
+    const int tiles_x = (W + SWL_XT - 1) / SWL_XT, tiles_y = (H + 3) / 4;
+    const int ntiles = B * tiles_y * tiles_x;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int b = tl / (tiles_y * tiles_x), rem = tl - b * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * 4, x0 = (rem % tiles_x) * SWL_XT;
+        __syncthreads();                         // the previous tile's reads are done
+        for (int e = tid; e < 3 * SWL_ROWS * (SWL_XT + 6); e += 256) {
+            const int row = e / (SWL_XT + 6), col = e - row * (SWL_XT + 6);
+            const int c = row / SWL_ROWS, rr = row - c * SWL_ROWS;
+            const int gy = y0 - 3 + rr, gx = x0 - 3 + col;
+            float v = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[(((size_t)b * 3 + c) * H + gy) * W + gx];
+            tile[row * SWL_P + col] = v;
         }
-        auto group = [&](int x0, bool edge) {
-            const float av = buf_load1(r_dy, va, x0 * 64);
+        __syncthreads();
+        const int y = y0 + wave;
+        const __amdgpu_buffer_rsrc_t r_dy =
+            make_rsrc(dy + ((size_t)b * H + (y < H ? y : 0)) * W * 16, y < H ? (unsigned)(W * 16) * 4u : 0u);
+#pragma unroll 4
+        for (int g = 0; g < SWL_XT / 4; ++g) {
+            const float av = buf_load1(r_dy, va, (x0 + g * 4) * 64);      // beyond the row: zero
             float bv[NJT];
 #pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                if (!edge) {
-                    bv[jt] = buf_load1(r_img, rowoff[jt], x0 * 4);
-                } else {
-                    const int xx = x0 + tsx[jt];
-                    bv[jt] = buf_load1(r_img, (xx >= 0 && xx < W && rowoff[jt] != BUF_OOB) ? rowoff[jt] + x0 * 4 : BUF_OOB, 0);
-                }
-            }
+            for (int jt = 0; jt < NJT; ++jt) bv[jt] = tile[boff[jt] + g * 4];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[jt], acc[jt], 0, 0, 0);
-        };
-        group(0, true);
-#pragma unroll 2
-        for (int x0 = 4; x0 <= W - 12; x0 += 4) group(x0, false);     // x0 + k + s - 3 in [1, W - 3]
-        group(W - 8, true);
-        group(W - 4, true);
+        }
     }
     // workgroup reduction, wave after wave (fixed order); D: row (out channel n) = 4*(lane>>4) + q, column = tap j
+    __syncthreads();
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float *__res
 static bool stem_wgrad_use_mfma(int W) { return W % 4 == 0 && W >= 16; }
 int stem_wgrad_blocks(int B, int H, int W) {
     if (stem_wgrad_use_mfma(W)) {
-        const int nb = (B * H + 3) / 4;
+        const int nb = B * ((H + 3) / 4) * ((W + SWL_XT - 1) / SWL_XT);
         return nb > 1024 ? 1024 : nb;
     }
     return (B * ((W + 31) / 32) * ((H + 7) / 8) + STEM_WG_TILES - 1) / STEM_WG_TILES;
@@ -554,7 +554,7 @@ hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, in
                              hipStream_t st) {
     const int nb = stem_wgrad_blocks(B, H, W);
     if (stem_wgrad_use_mfma(W))
-        hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nb), dim3(256), 0, st, img, dy, B, H, W, partial);
+        hipLaunchKernelGGL(stem_wgrad_lds_kernel, dim3(nb), dim3(256), 0, st, img, dy, B, H, W, partial);
     else
         hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nb), dim3(192), 0, st, img, dy, B, H, W, partial);
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(147 * 16), dim3(256), 0, st, partial, nb, dw);
