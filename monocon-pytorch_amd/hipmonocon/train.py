@@ -10,6 +10,8 @@ engine/monocon_engine.py:84-102) runs unchanged on top of it.
 """
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import dist as _dist
@@ -100,14 +102,24 @@ class _HipTrainStep(torch.autograd.Function):
         return (None, None, None, None, None, None, *out)
 
 
+def _require_objects(detector, mask):
+    """The reference asserts on empty targets (losses/l1_loss.py:15, README.MD:208-210); so does this path, before
+    anything is launched.  Reading the count back is a host sync, so a mask tensor that was already validated
+    (the SAME tensor object, unmodified: a resident batch stepped repeatedly) is not read back again."""
+    seen = getattr(detector, "_mask_validated", None)
+    if seen is not None and seen[0]() is mask and seen[1] == mask._version:
+        return
+    if float(mask.sum()) == 0:
+        raise AssertionError("no valid objects in the batch: l1_loss requires target.numel() > 0")
+    object.__setattr__(detector, "_mask_validated", (weakref.ref(mask), mask._version))
+
+
 def forward_train(detector, data_dict):
     img = data_dict["img"]
     if not img.is_cuda:
         raise _lib.MonoconHipError("img must live on a HIP device; libmonocon_hip has no CPU path")
     label = data_dict["label"]
-    if float(label["mask"].sum()) == 0:
-        # the reference asserts on empty targets (losses/l1_loss.py:15, README.MD:208-210)
-        raise AssertionError("no valid objects in the batch: l1_loss requires target.numel() > 0")
+    _require_objects(detector, label["mask"])
     tb = _binding(detector)
     for n, p in tb.live:
         # a .grad that still aliases the flat buffer (zero_grad(set_to_none=False)) would be overwritten

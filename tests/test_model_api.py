@@ -121,3 +121,25 @@ def test_batch_eval_kitti_format(golden_sd):
         n = len(a["score"])
         assert a["bbox"].shape == (n, 4) and a["location"].shape == (n, 3) and a["dimensions"].shape == (n, 3)
         assert len(a["name"]) == len(a["alpha"]) == len(a["rotation_y"]) == len(a["sample_idx"]) == n
+
+
+@pytest.mark.gpu
+def test_empty_targets_raise_like_the_reference(golden_sd):
+    """reference losses/l1_loss.py:15 (README.MD:208-210): a batch without a single valid object asserts -- before
+    anything is launched.  A validated mask tensor is not read back again (no per-step host sync on a resident
+    batch), but an in-place edit or a new tensor is."""
+    m = build(golden_sd).cuda().train()
+    batch = synth.make_batch(11, 2, 64, 128)
+    dd = {"img": batch["img"].cuda(), "label": {k: v.cuda() for k, v in batch["label"].items()},
+          "img_metas": {"pad_shape": [(64, 128)] * 2}}
+    _, losses = m(dd)
+    assert all(torch.isfinite(v) for v in losses.values())
+    _, losses2 = m(dd)                                   # same tensor object: validated once
+    # (not bit-equal: the batch statistics are accumulated around the running mean, which the first pass moved)
+    assert torch.allclose(torch.stack(list(losses.values())), torch.stack(list(losses2.values())), rtol=1e-3)
+    dd["label"]["mask"].zero_()                          # in-place edit bumps the version: checked again
+    with pytest.raises(AssertionError):
+        m(dd)
+    dd["label"]["mask"] = torch.zeros_like(dd["label"]["mask"])
+    with pytest.raises(AssertionError):
+        m(dd)
