@@ -29,3 +29,17 @@ print("---- families (ms/step)")
 for f, ms in sorted(fam.items(), key=lambda kv: -kv[1])[:30]:
     print("%-48s %8.3f" % (f, ms))
 print("total kernel ms/step %.2f" % tot)
+# ---- GPU busy fraction over the last ~60 % of the trace (steady state): union of kernel intervals / wall
+iv = sorted((s, e) for _, s, e, _, _ in rows)
+t0 = iv[0][0] + (iv[-1][1] - iv[0][0]) * 2 // 5
+iv = [(max(s, t0), e) for s, e in iv if e > t0]
+busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+for s, e in iv[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s; cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+wall = iv[-1][1] - t0
+gaps = sorted(((iv[i + 1][0] - max(x[1] for x in iv[:i + 1][-8:])) for i in range(len(iv) - 1)), reverse=True)
+print("steady-state wall %.1f ms, GPU busy (union) %.1f ms = %.1f %%" % (wall / 1e6, busy / 1e6, 100.0 * busy / wall))
