@@ -76,20 +76,35 @@ def cpu_baseline(sd, height, width, budget_s):
         with torch.no_grad():
             O.clip_and_adamw([p.detach() for p in ps], gs, ms, vs, 1, 2.25e-4, 0.95)
 
-    # pick the fastest intra-op thread count the box actually sustains (a container may expose far
-    # more logical CPUs than it is allowed to run; oversubscribing MKLDNN is orders of magnitude
-    # slower), then time at that setting
+    # pick the intra-op thread count the box actually sustains (a container may expose far more logical CPUs than
+    # its quota lets it run, and oversubscribed MKLDNN is orders of magnitude slower) on a CHEAP probe -- one
+    # 64->64 3x3 convolution of the level-2 shape -- so that a bad candidate costs seconds, not minutes
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    cands = sorted({n for n in (4, 8, 16, 32, 64, 128, avail) if n <= avail})
+    if quota:
+        cands = [n for n in cands if n <= int(quota + 0.5)] or [max(1, int(quota))]
+    px, pw = torch.randn(2, 64, 96, 320), torch.randn(64, 64, 3, 3)
     best = None
-    for nt in sorted({n for n in (8, 16, 32, 64, avail) if n <= avail}):
+    for nt in cands:
         torch.set_num_threads(nt)
-        t0 = time.perf_counter()
-        one_step(sd)                         # doubles as warm-up
-        dt = time.perf_counter() - t0
+        torch.nn.functional.conv2d(px, pw, padding=1)
+        dt = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            torch.nn.functional.conv2d(px, pw, padding=1)
+            dt = min(dt, time.perf_counter() - t0)
         if best is None or dt < best[1]:
             best = (nt, dt)
-        if dt > budget_s:                    # already hopeless at this count; larger is worse
+        elif dt > 2.0 * best[1]:             # past the knee: larger counts only get worse
             break
     torch.set_num_threads(best[0])
+    one_step(sd)                             # warm-up at the chosen count
     times = []
     t_end = time.perf_counter() + budget_s
     while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
@@ -100,6 +115,15 @@ def cpu_baseline(sd, height, width, budget_s):
     return {"value": round(2 / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle full train step (fwd + targets + losses + autograd bwd + clip + AdamW), B=2 x 3x%dx%d fp32, "
                       "median of %d runs (%.3f s/run)" % (height, width, len(times), med)}
+
+
+_T0 = time.perf_counter()
+
+
+def _phase(msg):
+    """progress to stderr (stdout carries only the JSON line)"""
+    if os.environ.get("RANK", "0") == "0":
+        print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -171,9 +195,11 @@ def main():
         sch.step()
         return total
 
+    _phase("model + batch resident; first step builds and autotunes the train plan")
     for _ in range(max(args.warmup, 1)):      # the first step builds (and autotunes) the plan
         total = step()
     sync_all()
+    _phase("warm-up done; timing %d steps" % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         total = step()
@@ -182,12 +208,14 @@ def main():
     assert bool(torch.isfinite(total)), "non-finite loss in the timed region"
     ms_step = elapsed / args.steps * 1e3
 
+    _phase("timed region done: %.2f ms/step" % ms_step)
     eng = m._rt.engine
     prof = eng.profile_train(iters=2) if rank == 0 else None      # HIP events on the launch stream
     train_ws = eng.workspace_bytes()
 
     # ---------------------------------------------------------------- forward only (configs[1])
     fwd = None
+    _phase("per-launch event profile done; eval forward")
     if args.forward_steps > 0:
         m.eval()
         gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
@@ -230,6 +258,7 @@ def main():
         pass
     # ---------------------------------------------------------------- the bf16-pipe modes
     def timed_mode(mode):
+        _phase("precision mode %s" % mode)
         m.train().set_precision(mode)
         for _ in range(2):
             total = step()
@@ -277,6 +306,7 @@ def main():
 
     # ---------------------------------------------------------------- decode only (configs[4])
     dec = None
+    _phase("decode")
     if args.forward_steps > 0 and rank == 0:
         K, DB = 100, 64
         from hipmonocon.engine import p2_inverse
@@ -342,7 +372,9 @@ def main():
         if dec is not None:
             out["decode_only"] = dec
         if not args.no_cpu_baseline:
+            _phase("CPU baseline (oracle train step, B=2)")
             out["cpu_baseline"] = cpu_baseline(sd, H, W, args.cpu_seconds)
+        _phase("done")
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()
