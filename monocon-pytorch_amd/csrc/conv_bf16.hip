@@ -61,8 +61,9 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     const int g = lane >> 5, li = lane & 31;
 
     const int ntiles = a.CoutP / BNT;
-    const int nt = blockIdx.x % ntiles;
-    const int mchunk = blockIdx.x / ntiles;
+    const int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int nt = bid % ntiles;
+    const int mchunk = bid / ntiles;
     const int img = mchunk / a.chunks, chunk = mchunk % a.chunks;
     const int n0 = nt * BNT;
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
 
     const int vx = (li * S * CIN + kq * 4) * 4;                     // input lane offset inside a group
-    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+    for (int row = xcd_order(blockIdx.x, gridDim.x) * 4 + wave; row < R; row += gridDim.x * 4) {
         const int img = row / a.Hout, oy = row - img * a.Hout;
         __amdgpu_buffer_rsrc_t r_x[3];
 #pragma unroll

@@ -63,9 +63,10 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave / WC, wc = wave % WC;
     const int g = lane >> 5, li = lane & 31;
-    const int ct = blockIdx.x % a.c_tiles;
-    const int nt = (blockIdx.x / a.c_tiles) % a.n_tiles;
-    const int ks = blockIdx.x / (a.c_tiles * a.n_tiles);
+    const int bid = xcd_order(blockIdx.x, gridDim.x);      // the tiles of one split-K slice read the same pixels
+    const int ct = bid % a.c_tiles;
+    const int nt = (bid / a.c_tiles) % a.n_tiles;
+    const int ks = bid / (a.c_tiles * a.n_tiles);
     const int n0 = nt * NB, c0 = ct * CB;
     const long long G = (long long)a.B * a.groups_per_img;
     const int g_begin = (int)(G * ks / a.ksplit), g_end = (int)(G * (ks + 1) / a.ksplit);
