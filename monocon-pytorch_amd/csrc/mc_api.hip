@@ -794,26 +794,23 @@ int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[],
     a.Wout = (Win + 2 * (ksize / 2) - ksize) / stride + 1;
     a.Cin = cin; a.Cout = Cout; a.CoutP = conv_coutp(Cout);
     const size_t wn = (size_t)ksize * ksize * cin * a.CoutP;
-    void *wpk = nullptr;
-    HIPCHK(h, hipMalloc(&wpk, wn * sizeof(float)));
-    HIPCHK(h, hipMemsetAsync(wpk, 0, wn * sizeof(float), st));
-    HIPCHK(h, launch_pack_conv_w(weight_oihw, Cout, cin, ksize, static_cast<float *>(wpk), cin, a.CoutP, 0, 0, st));
-    a.wpk = static_cast<float *>(wpk);
-    void *wpk16 = nullptr;
+    ScratchBuf wpk, wpk16;
+    HIPCHK(h, wpk.alloc(wn * sizeof(float)));
+    HIPCHK(h, hipMemsetAsync(wpk.p, 0, wn * sizeof(float), st));
+    HIPCHK(h, launch_pack_conv_w(weight_oihw, Cout, cin, ksize, wpk.as<float>(), cin, a.CoutP, 0, 0, st));
+    a.wpk = wpk.as<float>();
     if (h->prec >= 1 && cin % 8 == 0) {
         const int pieces = h->prec == 2 ? 3 : 1;
-        HIPCHK(h, hipMalloc(&wpk16, wn * 2 * pieces));
-        HIPCHK(h, hipMemsetAsync(wpk16, 0, wn * 2 * pieces, st));
-        HIPCHK(h, launch_pack_conv_w_bf16(weight_oihw, Cout, cin, ksize, wpk16, cin, a.CoutP, 0, 0, pieces, st));
-        a.wpk16 = wpk16; a.prec = h->prec;
+        HIPCHK(h, wpk16.alloc(wn * 2 * pieces));
+        HIPCHK(h, hipMemsetAsync(wpk16.p, 0, wn * 2 * pieces, st));
+        HIPCHK(h, launch_pack_conv_w_bf16(weight_oihw, Cout, cin, ksize, wpk16.p, cin, a.CoutP, 0, 0, pieces, st));
+        a.wpk16 = wpk16.p; a.prec = h->prec;
     }
     a.scale = scale; a.bias = bias; a.res = residual; a.res_ld = Cout;
     a.out = out; a.out_ld = Cout; a.out_coff = 0; a.relu = relu;
     a.cfg = h->force_cfg;
     hipError_t e = launch_conv(a, ksize, stride, st);
-    hipError_t e2 = hipStreamSynchronize(st);   // test entry point: weights are a temporary
-    (void)hipFree(wpk);
-    if (wpk16) (void)hipFree(wpk16);
+    hipError_t e2 = hipStreamSynchronize(st);   // test entry point: the packed weights are a temporary
     HIPCHK(h, e);
     HIPCHK(h, e2);
     return 0;
@@ -825,12 +822,11 @@ int mc_op_stem(mc_handle *h, const float *img, int B, int H, int W, const float 
     if (!img || !weight_oihw || !scale || !bias || !out) return fail(h, "mc_op_stem: null argument");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    void *wpk = nullptr;
-    HIPCHK(h, hipMalloc(&wpk, 147 * 16 * sizeof(float)));
-    HIPCHK(h, launch_pack_stem_w(weight_oihw, static_cast<float *>(wpk), st));
-    hipError_t e = launch_stem(img, B, H, W, static_cast<float *>(wpk), scale, bias, out, st);
+    ScratchBuf wpk;
+    HIPCHK(h, wpk.alloc(147 * 16 * sizeof(float)));
+    HIPCHK(h, launch_pack_stem_w(weight_oihw, wpk.as<float>(), st));
+    hipError_t e = launch_stem(img, B, H, W, wpk.as<float>(), scale, bias, out, st);
     hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(wpk);
     HIPCHK(h, e);
     HIPCHK(h, e2);
     return 0;
@@ -850,12 +846,11 @@ int mc_op_deconv4x4(mc_handle *h, const float *in, int B, int H, int W, int C, c
     if (!in || !out || !weight || (C % 4)) return fail(h, "mc_op_deconv4x4: bad argument");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    void *wpk = nullptr;
-    HIPCHK(h, hipMalloc(&wpk, (size_t)16 * C * sizeof(float)));
-    HIPCHK(h, launch_pack_deconv_w(weight, C, static_cast<float *>(wpk), st));
-    hipError_t e = launch_deconv4(in, B, H, W, C, static_cast<float *>(wpk), out, st);
+    ScratchBuf wpk;
+    HIPCHK(h, wpk.alloc((size_t)16 * C * sizeof(float)));
+    HIPCHK(h, launch_pack_deconv_w(weight, C, wpk.as<float>(), st));
+    hipError_t e = launch_deconv4(in, B, H, W, C, wpk.as<float>(), out, st);
     hipError_t e2 = hipStreamSynchronize(st);
-    (void)hipFree(wpk);
     HIPCHK(h, e);
     HIPCHK(h, e2);
     return 0;

@@ -131,6 +131,17 @@ static inline int fail(mc_handle *h, const char *fmt, ...) {
     return -1;
 }
 
+// device scratch of the op-level (test) entry points: released on every return path
+struct ScratchBuf {
+    void *p = nullptr;
+    ScratchBuf() = default;
+    ScratchBuf(const ScratchBuf &) = delete;
+    ScratchBuf &operator=(const ScratchBuf &) = delete;
+    ~ScratchBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 #define HIPCHK(h, expr)                                                                       \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
