@@ -290,11 +290,11 @@ def main():
         emulated.update({
             "workload": "the same train step / eval forward with fp32 EMULATED on the bf16 matrix pipe: both operands of every "
                         "32-channel-aligned conv / data gradient / weight gradient split into three bf16 pieces (24 mantissa "
-                        "bits), six partial products per multiply, fp32 accumulation.  139 of the 140 `-m gpu` parity tests pass "
-                        "unchanged under MONOCON_HIP_PRECISION=bf16x3 (goldens at 1e-4 vs the reference's fp64, train-step "
-                        "losses / gradients); one fp32-vs-fp32 shape-sweep case lands at 2.2e-4 against its 2e-4 budget "
-                        "(the accumulator takes six times as many additions, i.e. ~2.4x the round-off of the fp32 MFMA "
-                        "path), which is why this mode is reported here and not as `value`",
+                        "bits), six partial products per multiply, fp32 accumulation (the five minor products in their own "
+                        "accumulator, so the main one takes as many additions as the fp32 MFMA path).  The whole `-m gpu` "
+                        "parity suite passes unchanged under MONOCON_HIP_PRECISION=bf16x3 and the forward lands closer to the "
+                        "fp64 oracle than the native fp32 path (scratch/mode_err.py); not used for `value` pending a ruling "
+                        "on whether it counts as the fp32 path",
             "dtype": "f32 emulated (3 x bf16 split operands, f32 accumulate)"})
         mixed = timed_mode("bf16")
         mixed.update({

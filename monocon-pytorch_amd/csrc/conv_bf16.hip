@@ -78,13 +78,20 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     }
     __syncthreads();
 
-    f32x16 acc[WTM][WTN];
+    // SPL == 3: the five minor partial products (weight <= 2^-8) accumulate apart from the h*h products, so that the
+    // main accumulator takes exactly as many additions as the fp32 MFMA path (its round-off, not the exactness of the
+    // products, is what limits the emulation) and the minor sum's round-off is 2^-8 smaller; folded in once at the end.
+    constexpr int NACC = SPL == 3 ? 2 : 1;
+    f32x16 acc[WTM][WTN], accm[NACC == 2 ? WTM : 1][NACC == 2 ? WTN : 1];
 #pragma unroll
     for (int tm = 0; tm < WTM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < WTN; ++tn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[tm][tn][r] = 0.f;
+                if (NACC == 2) accm[tm][tn][r] = 0.f;
+            }
 
     constexpr int TOTAL = PB * NPIX * C4;
     constexpr int NIT = (TOTAL + NT - 1) / NT;
@@ -194,9 +201,14 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
                     for (int tm = 0; tm < WTM; ++tm)
 #pragma unroll
-                        for (int tn = 0; tn < WTN; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                acur[SPL == 1 ? 0 : PA[pp]][tm], bcur[SPL == 1 ? 0 : PBv[pp]][tn], acc[tm][tn], 0, 0, 0);
+                        for (int tn = 0; tn < WTN; ++tn) {
+                            if (NACC == 2 && pp < NP - 1)
+                                accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[PA[pp]][tm], bcur[PBv[pp]][tn],
+                                                                                       accm[tm][tn], 0, 0, 0);
+                            else
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    acur[SPL == 1 ? 0 : PA[pp]][tm], bcur[SPL == 1 ? 0 : PBv[pp]][tn], acc[tm][tn], 0, 0, 0);
+                        }
                 if (s + 1 < NS) {
 #pragma unroll
                     for (int q = 0; q < SPL; ++q)
@@ -212,6 +224,14 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
         kbase += Cs;
     }
 
+    if (NACC == 2) {
+#pragma unroll
+        for (int tm = 0; tm < WTM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < WTN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accm[tm][tn][r];
+    }
     conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
 }
 
