@@ -68,6 +68,14 @@ struct ConvArgs {
     // emulated by a 3-way bf16 split of both operands (six bf16 MFMAs per product, three panels in wpk16)
     const void *wpk16;       // [pieces][k*k][Cin/8][CoutP][8] bf16 or null
     int prec;
+    // backward-statistics mode, for a data gradient whose output completes the gradient of a BatchNorm'd map (dense
+    // NHWC, Cout channels): the epilogue applies that map's ReLU mask to the total (accumulated) gradient d, stores
+    // the masked d, and writes the (sum d, sum d*y) partials of the BatchNorm backward to `stats` (per 4x8 patch) --
+    // the separate three-tensor reduction pass over the activation disappears
+    const float *bm_y;       // pre-BN conv output y of the forward, or null (mode off)
+    const float *bm_z;       // post-BN map z (mask z > 0), bm_relu == 1
+    const float *bm_a, *bm_b;// forward BN coefficients (mask fma(y, a, b) > 0, bit-identical to z > 0), bm_relu == 2
+    int bm_relu;             // 0: no ReLU (no mask), 1, 2
 };
 
 // Filter window code KS: 3 = 3x3 (pad 1), 1 = 1x1; 12 / 21 / 22 = 1x2, 2x1, 2x2 windows without padding --
@@ -138,10 +146,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                                               int patch0, int img, int n0, int wm, int wn, int g, int li) {
     const bool do_stats = a.stats != nullptr;
     const bool has_res = a.res != nullptr;
+    const bool bm = a.bm_y != nullptr;           // backward-statistics mode (see ConvArgs)
+    const int bm_relu = a.bm_relu;
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (size_t)img * a.o_img, (unsigned)a.o_img * 4u);
     const __amdgpu_buffer_rsrc_t r_res =
         make_rsrc(has_res ? a.res + (size_t)img * a.r_img : a.out, has_res ? (unsigned)a.r_img * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t r_y = make_rsrc(bm ? a.bm_y + (size_t)img * a.o_img : a.out, bm ? (unsigned)a.o_img * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t r_z =
+        make_rsrc(bm && bm_relu == 1 ? a.bm_z + (size_t)img * a.o_img : a.out, bm && bm_relu == 1 ? (unsigned)a.o_img * 4u : 0u);
     // statistics partials are per 4x8 PATCH and channel: stats[b][patch][CoutP][2].  A patch's 32 values are
     // summed in an order fixed by the MFMA layout, so the partials -- and with them train-mode BN -- do not depend
     // on the workgroup shape the autotuner picked.
@@ -152,8 +165,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
         const float sc = (a.scale && nok) ? a.scale[n] : 1.f;
         const float bi = (a.bias && nok) ? a.bias[n] : 0.f;
         const float sh = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
+        const float ma = (bm && bm_relu == 2 && nok) ? a.bm_a[n] : 0.f;
+        const float mb = (bm && bm_relu == 2 && nok) ? a.bm_b[n] : 0.f;
         const int v_out = nok ? (4 * g * a.o_px + a.out_coff + n) * 4 : BUF_OOB;
         const int v_res = nok ? (4 * g * a.r_px + n) * 4 : BUF_OOB;
+        const int v_bm = nok ? (4 * g * a.o_px + n) * 4 : BUF_OOB;      // y / z share the dense layout of the output
 #pragma unroll
         for (int tm = 0; tm < WTM; ++tm) {
             const int p = wm * WTM + tm;
@@ -166,17 +182,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                 // whole patch inside the image: wave-uniform offsets only
                 const int s_out = (oy0 * a.o_row + ox0 * a.o_px) * 4;
                 const int s_res = (oy0 * a.r_row + ox0 * a.r_px) * 4;
-                float rv[16];
+                float rv[16], yv[16], zv[16];
                 if (has_res) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         rv[r] = buf_load1(r_res, v_res, s_res + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
                 }
+                if (bm) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        yv[r] = buf_load1(r_y, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+                    if (bm_relu == 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            zv[r] = buf_load1(r_z, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[tm][tn][r] * sc + bi;
                     if (has_res) v += rv[r];
-                    if (do_stats) {
+                    if (bm) {
+                        const bool on = bm_relu == 0 || (bm_relu == 1 ? zv[r] > 0.f : fmaf(yv[r], ma, mb) > 0.f);
+                        v = on ? v : 0.f;
+                        ssum += v;
+                        ssq = fmaf(v, yv[r], ssq);
+                    } else if (do_stats) {
                         const float d = v - sh;
                         ssum += d;
                         ssq += d * d;
@@ -191,9 +222,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                     if (nok && y < a.Hout && x < a.Wout) {
                         float v = acc[tm][tn][r] * sc + bi;
                         if (has_res) v += buf_load1(r_res, (y * a.r_row + x * a.r_px + n) * 4, 0);
-                        const float d = v - sh;
-                        ssum += d;
-                        ssq += d * d;
+                        if (bm) {
+                            const float yy = buf_load1(r_y, (y * a.o_row + x * a.o_px + n) * 4, 0);
+                            bool on = true;
+                            if (bm_relu == 1) on = buf_load1(r_z, (y * a.o_row + x * a.o_px + n) * 4, 0) > 0.f;
+                            else if (bm_relu == 2) on = fmaf(yy, ma, mb) > 0.f;
+                            v = on ? v : 0.f;
+                            ssum += v;
+                            ssq = fmaf(v, yy, ssq);
+                        } else {
+                            const float d = v - sh;
+                            ssum += d;
+                            ssq += d * d;
+                        }
                         v = fmaxf(v, floor_v);
                         buf_store1(v, r_out, (y * a.o_row + x * a.o_px + a.out_coff + n) * 4, 0);
                     }

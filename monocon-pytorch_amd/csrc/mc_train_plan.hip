@@ -7,6 +7,7 @@
 // of tensors with several consumers (tree children, residuals, neck skips) accumulate in place
 // through the fused conv's residual input, and every conv uses the MFMA dgrad (= the forward
 // kernel on transposed/flipped panels) and the MFMA split-K wgrad.
+#include <deque>
 #include <functional>
 
 #include "mc_internal.h"
@@ -21,6 +22,9 @@ struct TNode {
     Tensor t;
     float *g = nullptr;
     bool ginit = false, needs_grad = true;
+    // the launch that wrote g last, when that is a generic stride-1 data-gradient conv (else null): its epilogue
+    // sees the COMPLETE gradient of this map and can take over the reductions of the BatchNorm backward
+    ConvArgs *last_conv = nullptr;
 };
 
 struct PackJob {           // dgrad panel refreshed from the master weights before every forward
@@ -55,6 +59,7 @@ struct TrainState {
     std::vector<TNode> nodes;
     std::vector<Rec> recs;
     std::vector<Fn> fwd, bwd;
+    std::deque<ConvArgs> dgrads;     // data-gradient launches (stable addresses: bn_backward may still patch them)
     // backward closures that only produce weight gradients (nothing downstream in the step reads them) run
     // on a second stream: MFMA-bound wgrad overlaps the HBM-bound BN passes and the tails of the dgrad chain
     std::vector<char> bwd_side;
@@ -290,6 +295,7 @@ struct TB {   // train plan builder
                 ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(d, kk, 1, st)); return 0; });
             }
             sn.ginit = true;
+            sn.last_conv = nullptr;
             return;
         }
         float *panel;
@@ -307,8 +313,11 @@ struct TB {   // train plan builder
         if (sn.ginit) { d.res = sn.g; d.res_ld = sn.t.C; }
         if (Hd != sn.t.H || Wd != sn.t.W) { ts->ok = false; h->err = "train plan: dgrad shape mismatch"; }
         d.cfg = ts->ok ? mc_choose_conv_cfg(h, d, ks, 1) : CFG_128x32;
-        ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(d, ks, 1, st)); return 0; });
+        ts->dgrads.push_back(d);
+        ConvArgs *dp = &ts->dgrads.back();
+        ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(*dp, ks, 1, st)); return 0; });
         sn.ginit = true;
+        sn.last_conv = d.cfg == CFG_SMALL ? nullptr : dp;
     }
 
     void emit_wgrad(const std::vector<int> &srcs, const Tensor &dy, int dy_ld, int Cout, int ks, int stride, float *dw) {
@@ -331,14 +340,13 @@ struct TB {   // train plan builder
 
     // BN(+ReLU)(+residual) backward: returns dy (gradient wrt the raw conv output)
     Tensor bn_backward(const Rec &r, const std::string &bn) {
-        const TNode &zn = ts->nodes[r.z];
+        TNode &zn = ts->nodes[r.z];
         Tensor dy = r.y;
         dy.p = alloc(r.y.numel());
         const int B = r.y.B, C = r.y.C, rows = r.y.H * r.y.W;
-        const int nb = chan_reduce_blocks(B, rows);
-        float *partial = alloc((size_t)nb * C * 2), *coef = alloc((size_t)C * 4);
         const float *yp = r.y.p, *gz = zn.g, *zp = zn.t.p, *gamma = P(bn + ".weight"), *mean = r.mean, *rstd = r.rstd;
         float *dg = G(bn + ".weight"), *db = G(bn + ".bias"), *dyp = dy.p;
+        float *coef = alloc((size_t)C * 4);
         // ReLU without residual: the mask is recomputed from y (bit-identical to z > 0), z is not read
         const int relu = r.relu ? ((r.res < 0 && r.ca && r.cb) ? 2 : 1) : 0;
         const float *fa = r.ca, *fb = r.cb;
@@ -348,8 +356,26 @@ struct TB {   // train plan builder
             gres = ts->nodes[r.res].g;
             gmode = ts->nodes[r.res].ginit ? 2 : 1;
             ts->nodes[r.res].ginit = true;
+            ts->nodes[r.res].last_conv = nullptr;
         }
         const double n = (double)B * rows;
+        ConvArgs *lc = zn.last_conv;
+        if (lc && lc->out == zn.g && lc->Cout == C && lc->out_ld == C && lc->Hout == r.y.H && lc->Wout == r.y.W && !lc->stats) {
+            // the gradient of this map was completed by a data-gradient conv: its epilogue masks it and emits the
+            // (sum d, sum d*y) partials per 4x8 patch -- no reduction pass, and the affine pass needs no mask
+            const int ppi = ((r.y.W + 7) / 8) * ((r.y.H + 3) / 4), nbp = B * ppi, cstride = lc->CoutP;
+            float *partial = alloc((size_t)nbp * cstride * 2);
+            lc->stats = partial;
+            lc->bm_y = yp; lc->bm_z = zp; lc->bm_a = fa; lc->bm_b = fb; lc->bm_relu = relu;
+            ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
+                HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, cstride, n, C, gamma, mean, rstd, dg, db, coef, st));
+                HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, 0, dyp, gres, gmode, st));
+                return 0;
+            });
+            return dy;
+        }
+        const int nb = chan_reduce_blocks(B, rows);
+        float *partial = alloc((size_t)nb * C * 2);
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
             HIPCHK(hh, launch_chan_reduce(yp, gz, zp, nullptr, B, rows, C, 1, relu, partial, C, st, fa, fb));
             HIPCHK(hh, launch_bn_bwd_finalize(partial, nb, C, n, C, gamma, mean, rstd, dg, db, coef, st));
@@ -600,6 +626,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
             const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C, acc = in.ginit;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_maxpool2_bwd(xp, go, Bq, Hq, Wq, Cq, gi, acc, st)); return 0; });
             in.ginit = true;
+            in.last_conv = nullptr;
         } else if (r.kind == REC_DECONV) {
             TNode &in = ts->nodes[r.in];
             const TNode &o = ts->nodes[r.z];
@@ -615,6 +642,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
                 return 0;
             });
             in.ginit = true;
+            in.last_conv = nullptr;
         } else if (r.kind == REC_CONV) {
             if (r.dead || !ts->nodes[r.z].ginit) continue;
             Tensor dy = b.bn_backward(r, r.bn);
