@@ -112,9 +112,47 @@ hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, c
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ partial-sum fold
+// The conv epilogues leave one (s1, s2) pair per 4x8 patch and channel: tens of thousands of rows for the
+// 96x320 maps.  Walking them channel by channel (one workgroup per channel, 8 bytes out of every Cstride*8) uses a
+// sliver of each cache line; this pre-pass reads whole rows (thread = channel, consecutive 8-byte pairs) and folds
+// FOLD_ROWS of them into one row of doubles, which the finalise kernels then finish.  Fixed order throughout.
+constexpr int FOLD_ROWS = 128, FOLD_MIN_NB = 2048;
+__global__ __launch_bounds__(256) void partial_fold_kernel(const float *__restrict__ partial, int nb, int Cstride, int C,
+                                                           double *__restrict__ out /*[blocks][C][2]*/) {
+    __shared__ double red[256][2];
+    const int r0 = blockIdx.x * FOLD_ROWS, r1 = min(nb, r0 + FOLD_ROWS);
+    const int CG = C < 256 ? C : 256, RG = 256 / CG;          // thread = (row group, channel)
+    const int cl = threadIdx.x % CG, rg = threadIdx.x / CG;
+    for (int c0 = 0; c0 < C; c0 += CG) {
+        const int c = c0 + cl;
+        double s1 = 0, s2 = 0;
+        if (rg < RG && c < C) {
+            const float2 *p = reinterpret_cast<const float2 *>(partial) + (size_t)(r0 + rg) * Cstride + c;
+            const size_t step = (size_t)RG * Cstride;
+            int r = r0 + rg;
+            for (; r + 3 * RG < r1; r += 4 * RG, p += 4 * step) {
+                const float2 v0 = p[0], v1 = p[step], v2 = p[2 * step], v3 = p[3 * step];
+                s1 += v0.x; s2 += v0.y; s1 += v1.x; s2 += v1.y; s1 += v2.x; s2 += v2.y; s1 += v3.x; s2 += v3.y;
+            }
+            for (; r < r1; r += RG, p += step) { const float2 v = *p; s1 += v.x; s2 += v.y; }
+        }
+        red[threadIdx.x][0] = s1; red[threadIdx.x][1] = s2;
+        __syncthreads();
+        if (rg == 0 && c < C) {
+            for (int g = 1; g < RG; ++g) { s1 += red[g * CG + cl][0]; s2 += red[g * CG + cl][1]; }
+            out[((size_t)blockIdx.x * C + c) * 2] = s1;
+            out[((size_t)blockIdx.x * C + c) * 2 + 1] = s2;
+        }
+        __syncthreads();
+    }
+}
+size_t partial_fold_doubles(int nb, int C) { return nb >= FOLD_MIN_NB ? (size_t)((nb + FOLD_ROWS - 1) / FOLD_ROWS) * C * 2 : 0; }
+
 // ------------------------------------------------------------------ BatchNorm (train) finalise
 // partial: [nb][Cstride][2] sums of (y - shift), (y - shift)^2 over n = nb * rows values per channel.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ partial, int nb, int Cstride, double n,
+template <typename T>
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const T *__restrict__ partial, int nb, int Cstride, double n,
                                                           const float *shift, const float *gamma, const float *beta,
                                                           float eps, float momentum, float *running_mean,
                                                           float *running_var, long long *nbt, float *a_out, float *b_out,
@@ -122,7 +160,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     const int c = blockIdx.x;
     double s1 = 0, s2 = 0;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-        const float *p = partial + ((size_t)i * Cstride + c) * 2;
+        const T *p = partial + ((size_t)i * Cstride + c) * 2;
         s1 += p[0]; s2 += p[1];
     }
     __shared__ double sh[32];
@@ -151,8 +189,15 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
 }
 hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
                               const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
-                              long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nb >= 2048 ? 1024 : 256), 0, st, partial, nb, Cstride, n, shift, gamma, beta, eps,
+                              long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st, double *fold) {
+    if (fold && nb >= FOLD_MIN_NB) {
+        const int nb2 = (nb + FOLD_ROWS - 1) / FOLD_ROWS;
+        hipLaunchKernelGGL(partial_fold_kernel, dim3(nb2), dim3(256), 0, st, partial, nb, Cstride, C, fold);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(C), dim3(256), 0, st, fold, nb2, C, n, shift, gamma, beta, eps,
+                           momentum, rm, rv, nbt, a, b, mean, rstd);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(C), dim3(nb >= 2048 ? 1024 : 256), 0, st, partial, nb, Cstride, n, shift, gamma, beta, eps,
                        momentum, rm, rv, nbt, a, b, mean, rstd);
     return hipGetLastError();
 }
@@ -237,14 +282,15 @@ hipError_t launch_affine_act(const float *y, const float *a, const float *b, con
 // ------------------------------------------------------------------ BatchNorm backward finalise
 // partial: [nb][Cstride][2] = (sum d, sum d*y).  dy = P*d + Q*y + R with
 //   P = a, Q = -a*r*S2/n, R = -a*S1/n + a*r*mean*S2/n,  S2 = r*(sum d*y - mean*sum d);  dgamma = S2, dbeta = S1.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nb, int Cstride,
+template <typename T>
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const T *__restrict__ partial, int nb, int Cstride,
                                                               double n, const float *gamma, const float *mean,
                                                               const float *rstd, float *dgamma, float *dbeta,
                                                               float *coef /*[C][4]*/) {
     const int c = blockIdx.x;
     double s1 = 0, s2 = 0;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-        const float *p = partial + ((size_t)i * Cstride + c) * 2;
+        const T *p = partial + ((size_t)i * Cstride + c) * 2;
         s1 += p[0]; s2 += p[1];
     }
     __shared__ double sh[32];
@@ -267,8 +313,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
 }
 hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
                                   const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
-                                  hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(nb >= 2048 ? 1024 : 256), 0, st, partial, nb, Cstride, n, gamma, mean, rstd, dgamma,
+                                  hipStream_t st, double *fold) {
+    if (fold && nb >= FOLD_MIN_NB) {
+        const int nb2 = (nb + FOLD_ROWS - 1) / FOLD_ROWS;
+        hipLaunchKernelGGL(partial_fold_kernel, dim3(nb2), dim3(256), 0, st, partial, nb, Cstride, C, fold);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(C), dim3(256), 0, st, fold, nb2, C, n, gamma, mean, rstd, dgamma,
+                           dbeta, coef);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(C), dim3(nb >= 2048 ? 1024 : 256), 0, st, partial, nb, Cstride, n, gamma, mean, rstd, dgamma,
                        dbeta, coef);
     return hipGetLastError();
 }

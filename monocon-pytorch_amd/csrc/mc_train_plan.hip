@@ -135,6 +135,11 @@ struct TB {   // train plan builder
         return it->second;
     }
 
+    double *fold_scratch(int nb, int C) {
+        const size_t nd = partial_fold_doubles(nb, C);
+        return nd ? reinterpret_cast<double *>(alloc(nd * 2)) : nullptr;
+    }
+
     // ---------------------------------------------------------------- forward pieces
     void bn_train_ops(const Tensor &y, const float *stats, int nb, int cstride, const std::string &bn, float eps,
                       float mom, float *a, float *b, float *mean, float *rstd) {
@@ -142,8 +147,9 @@ struct TB {   // train plan builder
         long long *nbt = NBT(bn + ".num_batches_tracked");
         const double n = (double)y.B * y.H * y.W;
         const int C = y.C;
+        double *fold = fold_scratch(nb, C);
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_bn_finalize(stats, nb, cstride, n, C, rm, g, be, eps, mom, rm, rv, nbt, a, b, mean, rstd, st));
+            HIPCHK(hh, launch_bn_finalize(stats, nb, cstride, n, C, rm, g, be, eps, mom, rm, rv, nbt, a, b, mean, rstd, st, fold));
             return 0;
         });
     }
@@ -367,8 +373,9 @@ struct TB {   // train plan builder
             float *partial = alloc((size_t)nbp * cstride * 2);
             lc->stats = partial;
             lc->bm_y = yp; lc->bm_z = zp; lc->bm_a = fa; lc->bm_b = fb; lc->bm_relu = relu;
+            double *fold = fold_scratch(nbp, C);
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, cstride, n, C, gamma, mean, rstd, dg, db, coef, st));
+                HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, cstride, n, C, gamma, mean, rstd, dg, db, coef, st, fold));
                 HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, 0, dyp, gres, gmode, st));
                 return 0;
             });

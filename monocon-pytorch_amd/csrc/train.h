@@ -57,12 +57,14 @@ hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, c
                               const float *fb = nullptr);
 hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
                               const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
-                              long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st);
+                              long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st,
+                              double *fold = nullptr);
+size_t partial_fold_doubles(int nb, int C);   // scratch for `fold` (0: the partial list is short, no pre-pass)
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *z, hipStream_t st);
 hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
                                   const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
-                                  hipStream_t st);
+                                  hipStream_t st, double *fold = nullptr);
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st,
                              const float *fa = nullptr, const float *fb = nullptr);
