@@ -18,6 +18,21 @@ hipError_t launch_pack_stem_w(const float *w, float *dst, hipStream_t st);
 // deconv weights (C,1,4,4) -> [ky][kx][C]
 hipError_t launch_pack_deconv_w(const float *w, int C, float *dst, hipStream_t st);
 hipError_t launch_copy(const float *src, float *dst, size_t n, hipStream_t st);
+// up to COPY_BATCH_MAX small device-to-device copies in ONE launch (the per-step shuffling of head weights / gradients
+// between the parameter tensors and the fused-head layouts was ~70 separate 4-us copies)
+constexpr int COPY_BATCH_MAX = 32;
+struct CopyBatch {
+    const float *src[COPY_BATCH_MAX];
+    float *dst[COPY_BATCH_MAX];
+    int n[COPY_BATCH_MAX];
+    int count = 0;
+    bool add(const float *s, float *d, size_t nn) {
+        if (count >= COPY_BATCH_MAX || nn > 0x7fffffff) return false;
+        src[count] = s; dst[count] = d; n[count] = (int)nn; ++count;
+        return true;
+    }
+};
+hipError_t launch_copy_batch(const CopyBatch &cb, hipStream_t st);
 
 // ---- backbone / neck element kernels -----------------------------------------------------
 hipError_t launch_stem(const float *img_nchw, int B, int H, int W, const float *wpk, const float *scale,

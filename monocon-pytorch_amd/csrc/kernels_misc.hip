@@ -35,6 +35,23 @@ hipError_t launch_copy(const float *src, float *dst, size_t n, hipStream_t st) {
     return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
 }
 
+__global__ __launch_bounds__(256) void copy_batch_kernel(const CopyBatch cb) {
+    const int seg = blockIdx.y;                    // wave-uniform: the table is read through scalar loads
+    const float *s = cb.src[seg];
+    float *d = cb.dst[seg];
+    const int n = cb.n[seg];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
+}
+hipError_t launch_copy_batch(const CopyBatch &cb, hipStream_t st) {
+    if (cb.count <= 0) return hipSuccess;
+    int mx = 1;
+    for (int i = 0; i < cb.count; ++i) mx = cb.n[i] > mx ? cb.n[i] : mx;
+    int gx = (mx + 1023) / 1024;                   // ~4 elements per thread for the largest segment
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(copy_batch_kernel, dim3(gx, cb.count), dim3(256), 0, st, cb);
+    return hipGetLastError();
+}
+
 __global__ void fold_bn_kernel(const float *g, const float *b, const float *rm, const float *rv, float eps, int C,
                                float *scale, float *shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -583,6 +583,7 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
     const HeadRow *rows = head_rows();
     const int *rb = head_row_begin();
     (void)rows;
+    CopyBatch headcb;      // the 1x1 head weights / biases -> the fused [65][64] / [65] tables, one launch
     for (int hd = 0; hd < NUM_HEADS && has_head; ++hd) {
         const std::string pre = std::string("head.") + HEAD_NAMES[hd];
         NEEDP(w3, pre + ".0.weight", 64 * 64 * 9);
@@ -615,19 +616,20 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
             const int nr = rb[hd + 1] - rb[hd];
             NEEDP(w1, pre + ".3.weight", (int64_t)nr * 64);
             NEEDP(b1, pre + ".3.bias", nr);
-            HIPCHK(h, launch_copy(w1, h->head_w1 + (size_t)rb[hd] * HEAD_CH, (size_t)nr * 64, st));
-            HIPCHK(h, launch_copy(b1, h->head_b1 + rb[hd], nr, st));
+            if (!headcb.add(w1, h->head_w1 + (size_t)rb[hd] * HEAD_CH, (size_t)nr * 64) || !headcb.add(b1, h->head_b1 + rb[hd], nr))
+                return fail(h, "mc_pack_params: head copy table overflow");
         } else {
             NEEDP(wc, "head.dir_cls.0.weight", 12 * 64);
             NEEDP(bc, "head.dir_cls.0.bias", 12);
             NEEDP(wr, "head.dir_reg.0.weight", 12 * 64);
             NEEDP(br, "head.dir_reg.0.bias", 12);
-            HIPCHK(h, launch_copy(wc, h->head_w1 + (size_t)rb[8] * HEAD_CH, 12 * 64, st));
-            HIPCHK(h, launch_copy(wr, h->head_w1 + (size_t)(rb[8] + 12) * HEAD_CH, 12 * 64, st));
-            HIPCHK(h, launch_copy(bc, h->head_b1 + rb[8], 12, st));
-            HIPCHK(h, launch_copy(br, h->head_b1 + rb[8] + 12, 12, st));
+            if (!headcb.add(wc, h->head_w1 + (size_t)rb[8] * HEAD_CH, 12 * 64) ||
+                !headcb.add(wr, h->head_w1 + (size_t)(rb[8] + 12) * HEAD_CH, 12 * 64) || !headcb.add(bc, h->head_b1 + rb[8], 12) ||
+                !headcb.add(br, h->head_b1 + rb[8] + 12, 12))
+                return fail(h, "mc_pack_params: head copy table overflow");
         }
     }
+    HIPCHK(h, launch_copy_batch(headcb, st));
     // [65][64] -> [64][65]: the second head pass reads one input channel against all rows of a head
     if (has_head) HIPCHK(h, launch_nchw_to_nhwc(h->head_w1, 1, NUM_OUT_ROWS, 1, HEAD_CH, h->head_w1t, st));
 #undef NEEDP

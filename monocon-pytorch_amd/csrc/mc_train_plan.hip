@@ -573,15 +573,17 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
                                rb[hd], rb[hd + 1] - rb[hd]});
         segs.push_back(Seg{b.G("head.dir_cls.0.weight"), b.G("head.dir_cls.0.bias"), rb[8], 12});
         segs.push_back(Seg{b.G("head.dir_reg.0.weight"), b.G("head.dir_reg.0.bias"), rb[8] + 12, 12});
+        CopyBatch segcb;
+        for (const Seg &s : segs) {
+            if (!segcb.add(dw1 + (size_t)s.r0 * HEAD_CH, s.dst_w, (size_t)s.nr * HEAD_CH) || !segcb.add(db1 + s.r0, s.dst_b, s.nr))
+                ts->ok = false;
+        }
         {
             const float *xp = xh.p, *hp = hn.p, *w1 = h->head_w1;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 HIPCHK(hh, launch_head_bwd(draw, LD, hp, xp, w1, B, HW, nbr, dh, dw1p, partial, st));
                 HIPCHK(hh, launch_splitk_reduce(dw1p, nbr, 1, NUM_OUT_ROWS, HEAD_CH, dw1, st));
-                for (const Seg &s : segs) {
-                    HIPCHK(hh, hipMemcpyAsync(s.dst_w, dw1 + (size_t)s.r0 * HEAD_CH, (size_t)s.nr * HEAD_CH * 4, hipMemcpyDeviceToDevice, st));
-                    HIPCHK(hh, hipMemcpyAsync(s.dst_b, db1 + s.r0, (size_t)s.nr * 4, hipMemcpyDeviceToDevice, st));
-                }
+                HIPCHK(hh, launch_copy_batch(segcb, st));
                 return 0;
             });
         }
@@ -604,21 +606,19 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
             g3w.push_back(b.G(std::string("head.") + HN[hd] + ".0.weight"));
             g3b.push_back(b.G(std::string("head.") + HN[hd] + ".0.bias"));
         }
-        ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            for (int hd = 0; hd < NUM_HEADS; ++hd) {
-                HIPCHK(hh, hipMemcpyAsync(g3w[hd], dw3 + (size_t)hd * 64 * 64 * 9, (size_t)64 * 64 * 9 * 4, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hh, hipMemcpyAsync(g3b[hd], db3 + hd * 64, 64 * 4, hipMemcpyDeviceToDevice, st));
-            }
-            return 0;
-        });
+        CopyBatch g3cb;
+        for (int hd = 0; hd < NUM_HEADS; ++hd) {
+            if (!g3cb.add(dw3 + (size_t)hd * 64 * 64 * 9, g3w[hd], (size_t)64 * 64 * 9) || !g3cb.add(db3 + hd * 64, g3b[hd], 64))
+                ts->ok = false;
+        }
+        ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_copy_batch(g3cb, st)); return 0; });
         // dense OIHW (576,64,3,3) copy of the nine head convs for the dgrad panel
         std::vector<const float *> w3;
         for (int hd = 0; hd < NUM_HEADS; ++hd) w3.push_back(b.P(std::string("head.") + HN[hd] + ".0.weight"));
-        ts->pack_fns.push_back([=](mc_handle *hh, hipStream_t st) {
-            for (int hd = 0; hd < NUM_HEADS; ++hd)
-                HIPCHK(hh, hipMemcpyAsync(w3dense + (size_t)hd * 64 * 64 * 9, w3[hd], (size_t)64 * 64 * 9 * 4, hipMemcpyDeviceToDevice, st));
-            return 0;
-        });
+        CopyBatch w3cb;
+        for (int hd = 0; hd < NUM_HEADS; ++hd)
+            if (!w3cb.add(w3[hd], w3dense + (size_t)hd * 64 * 64 * 9, (size_t)64 * 64 * 9)) ts->ok = false;
+        ts->pack_fns.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_copy_batch(w3cb, st)); return 0; });
         b.emit_dgrad(w3dense, dxT, CP, 64, 3, 1, 0, feat, CP);
     }
     // ---- neck + backbone in reverse forward order
