@@ -42,7 +42,7 @@ struct ConvCfgB16 {
     static constexpr size_t LDS_BYTES = TILE_BYTES + PB * 16;
 };
 
-template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL>
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
 __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kernel(const ConvArgs a) {
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
     constexpr int PLANE = Cfg::PLANE_BYTES;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accm[tm][tn][r];
     }
-    conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
+    conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
 }
 
 // ---- weight packing: OIHW fp32 -> [tap][Cin/8][CoutP][8] bf16 (forward) and the dgrad variants
@@ -303,9 +303,14 @@ hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal,
 }
 
 // ---- dispatch
-template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL>
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
 static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
+    if constexpr (!BM && S == 1 && (KS == 3 || KS == 1)) {      // backward-statistics epilogue: own instantiation
+        if (a.bm_y) return launch_b16_one<KS, S, WM, WN, WTM, WTN, SPL, true>(a, st, resolved);
+    } else if constexpr (!BM) {
+        if (a.bm_y) return hipErrorInvalidValue;
+    }
     if (Cfg::LDS_BYTES > 160 * 1024) return hipErrorInvalidValue;
     a.ppr = (a.Wout + 7) / 8;
     a.ppi = a.ppr * ((a.Hout + 3) / 4);
@@ -313,7 +318,7 @@ static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved)
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
     static bool attr_set = false;
-    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL>;
+    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL, BM>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);

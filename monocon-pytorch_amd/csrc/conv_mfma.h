@@ -141,12 +141,12 @@ __device__ __forceinline__ int xcd_order(int b, int n) {
 // Epilogue shared by both kernel variants.  C/D layout of v_mfma_f32_32x32x2: column = lane&31,
 // row m = (r&3) + 8*(r>>2) + 4*(lane>>5); row m of a 4x8 patch is pixel (oy0 + (m>>3), ox0 + (m&7))
 // = (oy0 + (r>>2), ox0 + (r&3) + 4*(lane>>5)).
-template <int WM, int WN, int WTM, int WTN, int BNT>
+template <int WM, int WN, int WTM, int WTN, int BNT, bool BM = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[WTM][WTN], const int *pinfo,
                                               int patch0, int img, int n0, int wm, int wn, int g, int li) {
     const bool do_stats = a.stats != nullptr;
     const bool has_res = a.res != nullptr;
-    const bool bm = a.bm_y != nullptr;           // backward-statistics mode (see ConvArgs)
+    constexpr bool bm = BM;                      // backward-statistics mode (see ConvArgs): its own instantiation
     const int bm_relu = a.bm_relu;
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
     const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (size_t)img * a.o_img, (unsigned)a.o_img * 4u);
@@ -253,7 +253,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
     }
 }
 
-template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
+template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN, bool BM = false>
 __global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvArgs a) {
     using Cfg = ConvCfg<KS, S, CK, WM, WN, WTM, WTN>;
     constexpr int PB = Cfg::PB, BNT = Cfg::BNT, NT = Cfg::NT, PAD = Cfg::PAD;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvAr
         kbase += Cs;
     }
 
-    conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
+    conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
 }
 
 // ---- wave-specialised variant -------------------------------------------------------------

@@ -11,16 +11,23 @@ static ProfLast conv_cost(const ConvArgs &a, int ks) {
             4.0 * (px_in * a.Cin + px_out * a.Cout * (a.res ? 2 : 1) + taps * a.Cin * a.Cout)};
 }
 
-template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN>
+template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN, bool BM = false>
 static hipError_t launch_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     using Cfg = ConvCfg<KS, S, CK, WM, WN, WTM, WTN>;
+    if constexpr (!BM && S == 1 && (KS == 3 || KS == 1)) {
+        // backward-statistics epilogue (ConvArgs::bm_y): its own instantiation, so that every other launch keeps the
+        // lean epilogue (the y / z loads cost ~25 VGPRs)
+        if (a.bm_y) return launch_one<KS, S, CK, WM, WN, WTM, WTN, true>(a, st, resolved);
+    } else if constexpr (!BM) {
+        if (a.bm_y) return hipErrorInvalidValue;
+    }
     a.ppr = (a.Wout + 7) / 8;
     a.ppi = a.ppr * ((a.Hout + 3) / 4);
     a.chunks = (a.ppi + Cfg::PB - 1) / Cfg::PB;
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<KS, S, CK, WM, WN, WTM, WTN>;
+    auto kern = conv_mfma_kernel<KS, S, CK, WM, WN, WTM, WTN, BM>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
@@ -58,7 +65,7 @@ static hipError_t launch_one_ws(ConvArgs a, hipStream_t st, ConvArgs *resolved) 
 
 template <int KS, int S, int CK>
 static hipError_t launch_shape(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
-    if constexpr (KS == 3 || KS == 1) if (a.cfg & CFG_WS) {
+    if constexpr (KS == 3 || KS == 1) if ((a.cfg & CFG_WS) && !a.bm_y) {   // (the WS variant has no bm epilogue)
         switch (a.cfg & ~CFG_WS) {
             case CFG_128x128: return launch_one_ws<KS, S, CK, 2, 2, 2, 2>(a, st, resolved);
             case CFG_128x64: return launch_one_ws<KS, S, CK, 2, 2, 2, 1>(a, st, resolved);
@@ -69,7 +76,7 @@ static hipError_t launch_shape(const ConvArgs &a, hipStream_t st, ConvArgs *reso
             default: return hipErrorInvalidValue;
         }
     }
-    switch (a.cfg) {
+    switch (a.cfg & ~CFG_WS) {
         case CFG_128x128: return launch_one<KS, S, CK, 2, 2, 2, 2>(a, st, resolved);
         case CFG_128x64: return launch_one<KS, S, CK, 2, 2, 2, 1>(a, st, resolved);
         case CFG_128x64m: return launch_one<KS, S, CK, 4, 1, 1, 2>(a, st, resolved);
