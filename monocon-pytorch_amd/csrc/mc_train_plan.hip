@@ -366,6 +366,9 @@ struct TB {   // train plan builder
         }
         const double n = (double)B * rows;
         ConvArgs *lc = zn.last_conv;
+        if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
+            fprintf(stderr, "[plan] bn_backward %-40s %4d ch %4dx%-4d relu %d res %d last-writer-conv %d\n", bn.c_str(), C, r.y.H,
+                    r.y.W, relu, r.res >= 0, lc != nullptr);
         if (lc && lc->out == zn.g && lc->Cout == C && lc->out_ld == C && lc->Hout == r.y.H && lc->Wout == r.y.W && !lc->stats) {
             // the gradient of this map was completed by a data-gradient conv: its epilogue masks it and emits the
             // (sum d, sum d*y) partials per 4x8 patch -- no reduction pass, and the affine pass needs no mask
