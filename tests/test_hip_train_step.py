@@ -153,6 +153,32 @@ def test_train_forward_shape_sweep_vs_oracle(golden_sd, shape):
     assert abs(float(g.double().norm()) - ref_norm) <= 0.05 * ref_norm, (float(g.double().norm()), ref_norm)
 
 
+def test_image_without_objects_inside_a_batch(golden_sd):
+    """one image of the batch has no valid object (mask row all zero, stale label values left in place): the
+    regression losses average over the objects of the other images only, as in the reference (the batch as a whole
+    is not empty, so nothing raises)."""
+    from model import MonoConDetector
+    from oracle import monocon_oracle as O
+    batch = synth.make_batch(4242, 3, 64, 128)
+    batch["label"]["mask"][1] = 0
+    live = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+            for k, v in golden_sd.items()}
+    _, T, L, _ = O.train_forward(live, batch)
+    sum(L.values()).backward()
+    ref_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in live.values()
+                                    if getattr(p, "grad", None) is not None)))
+    m = MonoConDetector(34, pretrained_backbone=False)
+    m.load_state_dict(golden_sd, strict=True)
+    m = m.cuda().train()
+    _, loss = m(to_cuda(batch))
+    sum(loss.values()).backward()
+    for k, v in loss.items():
+        assert abs(float(v) - float(L[k])) <= 2e-3 * abs(float(L[k])) + 1e-4, (k, float(v), float(L[k]))
+    g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+    assert bool(torch.isfinite(g).all())
+    assert abs(float(g.double().norm()) - ref_norm) <= 0.05 * ref_norm, (float(g.double().norm()), ref_norm)
+
+
 def test_train_step_is_independent_of_the_conv_tiling(golden_sd):
     """losses, gradients and updated BN buffers are bit-identical whether the conv workgroup shapes are autotuned
     or forced to one tiling: the accumulation order of an output element and the per-patch statistics partials do
