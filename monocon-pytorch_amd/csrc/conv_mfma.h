@@ -125,12 +125,13 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, in
 // hint, never relied on for correctness).  xcd_order() renumbers the grid so that every XCD walks ONE contiguous
 // range of logical workgroups: neighbouring pixel chunks (shared halo rows) and the column tiles of a chunk (same
 // input) then meet in the same 4 MB L2 instead of being fetched once per XCD.  Bijective for any grid size.
-// MEASURED (A/B on one box, B=32): train step 106.6 vs 106.6-107.1 ms, eval forward 28.9 vs 29.4-29.6 ms with the
-// remap -- these kernels are MFMA-bound at 0.5-1.2 TB/s of HBM traffic and the default round-robin order spreads
-// the halo re-reads over all eight L2s and HBM channel groups, so the remap is compiled out by default
-// (-DMC_XCD_ORDER=1 turns it on in the conv, data-gradient and weight-gradient kernels).
+// MEASURED (A/B on one box, B=32; scratch/traffic_ab.sh): HBM read traffic per launch 458 -> 264 MB for the conv /
+// data-gradient kernels (algorithmic: ~240 MB of reads), 700 -> 373 MB for the weight gradients, 1421 -> 1080 MB for
+// the 16-channel row kernel -- i.e. the halo and column-tile re-reads that used to go out to the fabric once per
+// XCD now hit in L2.  These kernels are MFMA-bound, so the time barely moves (train step 105.3-106.0 vs 105.6-105.9
+// ms, eval forward B=32 +1 %, B=8 -1 %); the remap is kept for the traffic (-DMC_XCD_ORDER=0 compiles it out).
 #ifndef MC_XCD_ORDER
-#define MC_XCD_ORDER 0
+#define MC_XCD_ORDER 1
 #endif
 __device__ __forceinline__ int xcd_order(int b, int n) {
     if (!MC_XCD_ORDER) return b;
