@@ -46,6 +46,23 @@ def test_targets_other_resolution_vs_oracle(eng):
             assert (got - v).abs().max() < 2e-7, k
 
 
+@pytest.mark.parametrize("max_objs,max_gen", [(8, 8), (50, 50)], ids=["all_8_slots_used", "50_slots"])
+def test_targets_other_max_objs_vs_oracle(eng, max_objs, max_gen):
+    """MODEL.HEAD.MAX_OBJS other than 30 (every slot filled / many overlapping splats on one map): the per-slot
+    ranks, the integer max-splat and all masks stay bit-exact."""
+    from oracle import monocon_oracle as O
+    lab = synth.make_labels(91, 2, 192, 384, max_objs=max_objs, min_objs=max_gen, max_gen=max_gen)
+    assert int(lab["mask"].sum()) == 2 * max_gen
+    T = eng.make_targets({k: torch.from_numpy(v).cuda() for k, v in lab.items()}, (192, 384), (48, 96), max_objs=max_objs)
+    ref = O.make_targets({k: torch.from_numpy(v) for k, v in lab.items()}, (192, 384), (2, 64, 48, 96), max_objs=max_objs)
+    for k, v in ref.items():
+        got = T[k].cpu()
+        if v.dtype in (torch.long, torch.bool):
+            assert torch.equal(got, v), k
+        else:
+            assert (got - v).abs().max() < 2e-7, k
+
+
 def _train_case(seed=GOLDEN_SEED + 4):
     """predictions from the oracle's train-mode forward (the reference-pinned fixture inputs)."""
     from oracle import monocon_oracle as O
