@@ -95,6 +95,18 @@ def test_decode_fewer_positive_maxima_than_k(eng):
         assert torch.equal(R["cls"].cpu(), ref["cls"].to(R["cls"].dtype))
 
 
+def test_decode_max_k_vs_oracle(eng):
+    """K = 1024 (the C-ABI maximum, every LDS slot of the select kernel in use) on a 3x48x96 map."""
+    from oracle import monocon_oracle as O
+    d = synth.make_decode_inputs(31, 2, 48, 96, topk=1024)
+    R = run(eng, d, 1024, pad_hw=(192, 384))
+    ref = O.decode({k: torch.from_numpy(v) for k, v in d.items()}, np.stack([synth.KITTI_P2] * 2), (192, 384),
+                   topk=1024, thres=0.4)
+    assert torch.equal(R["flat_index"].cpu(), ref["flat_index"])
+    assert torch.equal(R["scores"].cpu(), ref["scores"])
+    assert torch.equal(R["box_mask"].cpu(), ref["box_mask"])
+
+
 def test_decode_k_limits(eng):
     from hipmonocon.lib import MonoconHipError
     d = synth.make_decode_inputs(5, 1, 8, 8, topk=4)
