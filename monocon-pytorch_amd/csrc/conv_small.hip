@@ -30,7 +30,6 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
-    const int R = a.B * a.Hout;
 
     // ---- the filter, once per wave: wreg[tap][kg][nt][jj] = W[n = nt*16 + li][c = kg*16 + 4*kq + jj][tap]
     f32x4 wreg[9][KG][NTN];
@@ -57,29 +56,38 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
 
     const int vx = (li * S * CIN + kq * 4) * 4;                     // input lane offset inside a group
-    for (int row = xcd_order(blockIdx.x, gridDim.x) * 4 + wave; row < R; row += gridDim.x * 4) {
-        const int img = row / a.Hout, oy = row - img * a.Hout;
-        __amdgpu_buffer_rsrc_t r_x[3];
+    constexpr int NR = (S == 1 && CIN == 16) ? 2 : 1;               // output rows per pass: a pair shares 2 of its 4 input rows
+    constexpr int NI = (NR - 1) * S + 3;                            // input rows per pass
+    const int hp = (a.Hout + NR - 1) / NR;
+    const int RP = a.B * hp;
+    for (int pr = xcd_order(blockIdx.x, gridDim.x) * 4 + wave; pr < RP; pr += gridDim.x * 4) {
+        const int img = pr / hp, oy = (pr - img * hp) * NR;
+        __amdgpu_buffer_rsrc_t r_x[NI], r_out[NR], r_res[NR];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < NI; ++r) {
             const int iy = oy * S + r - 1;
             const bool ok = iy >= 0 && iy < a.Hin;
             r_x[r] = make_rsrc(a.src[0].p + ((size_t)img * a.Hin + (ok ? iy : 0)) * a.Win * CIN,
                                ok ? (unsigned)(a.Win * CIN) * 4u : 0u);
         }
-        const __amdgpu_buffer_rsrc_t r_out =
-            make_rsrc(a.out + (size_t)row * a.Wout * a.out_ld, (unsigned)(a.Wout * a.out_ld) * 4u);
-        const __amdgpu_buffer_rsrc_t r_res =
-            make_rsrc(has_res ? a.res + (size_t)row * a.Wout * a.res_ld : a.out,
-                      has_res ? (unsigned)(a.Wout * a.res_ld) * 4u : 0u);
-        float ssum[NTN], ssq[NTN];
 #pragma unroll
-        for (int nt = 0; nt < NTN; ++nt) ssum[nt] = ssq[nt] = 0.f;
+        for (int q = 0; q < NR; ++q) {
+            const bool ok = oy + q < a.Hout;                       // the odd last row of an image: stores dropped
+            const size_t row = (size_t)img * a.Hout + (ok ? oy + q : oy);
+            r_out[q] = make_rsrc(a.out + row * a.Wout * a.out_ld, ok ? (unsigned)(a.Wout * a.out_ld) * 4u : 0u);
+            r_res[q] = make_rsrc(has_res ? a.res + row * a.Wout * a.res_ld : a.out,
+                                 (has_res && ok) ? (unsigned)(a.Wout * a.res_ld) * 4u : 0u);
+        }
+        float ssum[NR][NTN], ssq[NR][NTN];
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) ssum[q][nt] = ssq[q][nt] = 0.f;
 
         auto group = [&](int x0, bool edge) {
-            f32x4 av[9][KG];
+            f32x4 av[NI * 3][KG];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < NI; ++r)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -92,9 +100,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
                                 r_x[r], (px >= 0 && px < a.Win) ? (px * CIN + kg * 16 + kq * 4) * 4 : BUF_OOB, 0);
                         }
                     }
-            f32x4v acc[NTN];
+            f32x4v acc[NR][NTN];
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) acc[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < NR; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) acc[q][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -103,31 +113,36 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
                     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                         for (int nt = 0; nt < NTN; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kg][jj], wreg[t][kg][nt][jj], acc[nt], 0, 0, 0);
+#pragma unroll
+                            for (int q = 0; q < NR; ++q)
+                                acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t + 3 * q * S][kg][jj], wreg[t][kg][nt][jj],
+                                                                                  acc[q][nt], 0, 0, 0);
             // D layout: column (n) = lane & 15, row (pixel) = 4*(lane>>4) + q
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) {
-                const int n = nt * 16 + li;
-                const int v_out = nok[nt] ? ((4 * kq) * a.out_ld + a.out_coff + n) * 4 : BUF_OOB;
-                const int v_res = nok[nt] ? ((4 * kq) * a.res_ld + n) * 4 : BUF_OOB;
-                float rv[4];
-                if (has_res) {
+            for (int q = 0; q < NR; ++q)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) rv[q] = buf_load1(r_res, v_res, (x0 + q) * a.res_ld * 4);
-                }
+                for (int nt = 0; nt < NTN; ++nt) {
+                    const int n = nt * 16 + li;
+                    const int v_out = nok[nt] ? ((4 * kq) * a.out_ld + a.out_coff + n) * 4 : BUF_OOB;
+                    const int v_res = nok[nt] ? ((4 * kq) * a.res_ld + n) * 4 : BUF_OOB;
+                    float rv[4];
+                    if (has_res) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v = acc[nt][q] * sc[nt] + bi[nt];
-                    if (has_res) v += rv[q];
-                    if (do_stats) {
-                        const float d = v - sh[nt];
-                        ssum[nt] += d;
-                        ssq[nt] += d * d;
+                        for (int e = 0; e < 4; ++e) rv[e] = buf_load1(r_res[q], v_res, (x0 + e) * a.res_ld * 4);
                     }
-                    v = fmaxf(v, floor_v);
-                    buf_store1(v, r_out, v_out, (x0 + q) * a.out_ld * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[q][nt][e] * sc[nt] + bi[nt];
+                        if (has_res) v += rv[e];
+                        if (do_stats) {
+                            const float d = v - sh[nt];
+                            ssum[q][nt] += d;
+                            ssq[q][nt] += d * d;
+                        }
+                        v = fmaxf(v, floor_v);
+                        buf_store1(v, r_out[q], v_out, (x0 + e) * a.out_ld * 4);
+                    }
                 }
-            }
         };
         group(0, true);
         for (int x0 = 16; x0 < a.Wout - 16; x0 += 16) group(x0, false);
@@ -135,14 +150,18 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
 
         if (do_stats) {
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) {
-                float s1 = ssum[nt], s2 = ssq[nt];
-                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (kq == 0 && nok[nt]) {
-                    float *dst = a.stats + ((size_t)row * a.CoutP + nt * 16 + li) * 2;
-                    dst[0] = s1;
-                    dst[1] = s2;
+            for (int q = 0; q < NR; ++q) {
+                if (oy + q >= a.Hout) continue;
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) {
+                    float s1 = ssum[q][nt], s2 = ssq[q][nt];
+                    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    if (kq == 0 && nok[nt]) {
+                        float *dst = a.stats + ((((size_t)img * a.Hout + oy + q)) * a.CoutP + nt * 16 + li) * 2;
+                        dst[0] = s1;
+                        dst[1] = s2;
+                    }
                 }
             }
         }
@@ -161,7 +180,8 @@ bool conv_small_ok(const ConvArgs &a, int ks, int stride) {
 }
 
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st) {
-    const int rows = a.B * a.Hout;
+    const int nr = (stride == 1 && a.Cin == 16) ? 2 : 1;             // rows per wave pass (see the kernel)
+    const int rows = a.B * ((a.Hout + nr - 1) / nr);
     int blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
 #define CS_LAUNCH(S_, CIN_, NTN_) hipLaunchKernelGGL((conv_small_kernel<S_, CIN_, NTN_>), dim3(blocks), dim3(256), 0, st, a)
