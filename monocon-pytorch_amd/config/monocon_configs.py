@@ -1,47 +1,41 @@
-"""Default configuration tree -- same keys and values as reference config/monocon_configs.py:4-64."""
+"""Default configuration tree.  Keys and default values are those of the reference's yacs tree
+(config/monocon_configs.py:4-64) so its YAML files merge unchanged; kept here as one nested table."""
 from config.cfgnode import CfgNode as CN
 
-_C = CN()
-_C.VERSION = 'v1.0.3'
-_C.DESCRIPTION = "MonoCon Default Configuration"
-_C.OUTPUT_DIR = ""
-_C.SEED = -1
-_C.GPU_ID = 0
-_C.USE_BENCHMARK = True
+_DEFAULTS = {
+    "VERSION": "v1.0.3",
+    "DESCRIPTION": "MonoCon Default Configuration",
+    "OUTPUT_DIR": "",
+    "SEED": -1,
+    "GPU_ID": 0,
+    "USE_BENCHMARK": True,
+    "DATA": {
+        # 'synthetic' selects the built-in KITTI-shaped synthetic dataset; anything else is a KITTI root directory
+        "ROOT": r"/home/user/SSD/KITTI",
+        "BATCH_SIZE": 8,
+        "NUM_WORKERS": 4,
+        "TRAIN_SPLIT": "train",
+        "TEST_SPLIT": "val",
+        "FILTER": {"MIN_HEIGHT": 25, "MIN_DEPTH": 2, "MAX_DEPTH": 65, "MAX_TRUNCATION": 0.5, "MAX_OCCLUSION": 2},
+    },
+    "MODEL": {
+        "BACKBONE": {"NUM_LAYERS": 34, "IMAGENET_PRETRAINED": True},
+        "HEAD": {"NUM_CLASSES": 3, "MAX_OBJS": 30},
+    },
+    "SOLVER": {
+        "OPTIM": {"LR": 2.25e-4, "WEIGHT_DECAY": 1e-5, "NUM_EPOCHS": 200},
+        "SCHEDULER": {"ENABLE": True},
+        "CLIP_GRAD": {"ENABLE": True, "NORM_TYPE": 2.0, "MAX_NORM": 35},
+    },
+    "PERIOD": {"EVAL_PERIOD": 10, "LOG_PERIOD": 50},
+}
 
-_C.DATA = CN()
-_C.DATA.ROOT = r'/home/user/SSD/KITTI'        # 'synthetic' selects the built-in KITTI-shaped synthetic dataset
-_C.DATA.BATCH_SIZE = 8
-_C.DATA.NUM_WORKERS = 4
-_C.DATA.TRAIN_SPLIT = 'train'
-_C.DATA.TEST_SPLIT = 'val'
-_C.DATA.FILTER = CN()
-_C.DATA.FILTER.MIN_HEIGHT = 25
-_C.DATA.FILTER.MIN_DEPTH = 2
-_C.DATA.FILTER.MAX_DEPTH = 65
-_C.DATA.FILTER.MAX_TRUNCATION = 0.5
-_C.DATA.FILTER.MAX_OCCLUSION = 2
 
-_C.MODEL = CN()
-_C.MODEL.BACKBONE = CN()
-_C.MODEL.BACKBONE.NUM_LAYERS = 34
-_C.MODEL.BACKBONE.IMAGENET_PRETRAINED = True
-_C.MODEL.HEAD = CN()
-_C.MODEL.HEAD.NUM_CLASSES = 3
-_C.MODEL.HEAD.MAX_OBJS = 30
+def _tree(table):
+    node = CN()
+    for key, value in table.items():
+        node[key] = _tree(value) if isinstance(value, dict) else value
+    return node
 
-_C.SOLVER = CN()
-_C.SOLVER.OPTIM = CN()
-_C.SOLVER.OPTIM.LR = 2.25E-04
-_C.SOLVER.OPTIM.WEIGHT_DECAY = 1E-05
-_C.SOLVER.OPTIM.NUM_EPOCHS = 200
-_C.SOLVER.SCHEDULER = CN()
-_C.SOLVER.SCHEDULER.ENABLE = True
-_C.SOLVER.CLIP_GRAD = CN()
-_C.SOLVER.CLIP_GRAD.ENABLE = True
-_C.SOLVER.CLIP_GRAD.NORM_TYPE = 2.0
-_C.SOLVER.CLIP_GRAD.MAX_NORM = 35
 
-_C.PERIOD = CN()
-_C.PERIOD.EVAL_PERIOD = 10
-_C.PERIOD.LOG_PERIOD = 50
+_C = _tree(_DEFAULTS)

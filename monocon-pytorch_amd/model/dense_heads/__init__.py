@@ -1,3 +1,4 @@
+"""MonoCon dense heads: prediction maps, targets + losses, top-K decode."""
 from .monocon_heads import MonoConDenseHeads
 
-__all__ = ['MonoConDenseHeads']
+__all__ = ("MonoConDenseHeads",)

@@ -1,3 +1,4 @@
+"""The detector that ties backbone, neck and dense heads to the fused HIP plans."""
 from .monocon_detector import MonoConDetector
 
-__all__ = ['MonoConDetector']
+__all__ = ("MonoConDetector",)

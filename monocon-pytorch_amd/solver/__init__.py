@@ -1,4 +1,5 @@
-from .cyclic_scheduler import CyclicScheduler
+"""One-cycle LR / momentum schedule and the fused clip + AdamW step."""
 from .fused_adamw import AdamW
+from .cyclic_scheduler import CyclicScheduler
 
-__all__ = ['CyclicScheduler', 'AdamW']
+__all__ = ("AdamW", "CyclicScheduler")
