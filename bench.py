@@ -135,8 +135,16 @@ def main():
     if args.gpus != world and dist_on:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and not dist_on:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                         % (args.gpus, args.gpus))
+        # plain `python bench.py --gpus N`: re-launch as N ranks (one process per GPU) under torch.distributed.run
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        _phase("--gpus %d without a torchrun environment: re-launching as %s" % (args.gpus, " ".join(cmd[1:9])))
+        raise SystemExit(subprocess.call(cmd))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # test hook (1-GPU box): MONOCON_BENCH_BACKEND=gloo runs all ranks on device 0 over gloo, to exercise the
     # N > 1 control flow (barriers, max over ranks, gradient all-reduce) where RCCL refuses a shared device
@@ -338,7 +346,9 @@ def main():
             "metric": "images/sec (384x1280) fwd+bwd",
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "n_gpus": world, "world_size": dist.get_world_size() if dist_on else 1,
+            "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist_on else None,
+            "steps": args.steps, "warmup": max(args.warmup, 1),
             "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

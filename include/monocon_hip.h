@@ -155,6 +155,13 @@ int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS],
 int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, int B, int H, int W,
                      int max_objs, float *const preds[MC_NUM_PREDS], float *losses, void *stream);
 int mc_backward(mc_handle *h, const float *grad_losses, void *stream);
+/* The train plan keeps ONE set of saved activations: mc_backward always differentiates the latest
+ * mc_forward_train of the handle.  *generation = id of that forward (0 before the first one; every
+ * forward gets a new id).  A caller that may interleave forwards and backwards (gradient accumulation
+ * over micro-batches, backward on an older loss -- autograd allows both, engine/monocon_engine.py:84-86
+ * never does) records the id after its forward and compares before mc_backward; the Python binding
+ * raises on a mismatch instead of back-propagating through the wrong activations. */
+int mc_train_generation(mc_handle *h, unsigned long long *generation);
 /* Debugging aid: activation (which=0) or gradient (which=1) of node `node` of the train plan as NCHW. */
 int mc_train_debug_node(mc_handle *h, int node, int which, float *out_nchw, int dims[4], void *stream);
 

@@ -76,11 +76,16 @@ __global__ __launch_bounds__(256) void make_targets_kernel(const TargetArgs a) {
     const float bh = (bb[3] - bb[1]) * hr, bw = (bb[2] - bb[0]) * wr;
     const int rad = max(0, (int)gaussian_radius_ref(bh, bw));
     const int cls = (int)(long long)a.gt_labels[(size_t)b * a.max_objs + slot];
-    splat(a.center_heatmap + ((size_t)b * a.num_classes + cls) * HW, a.fh, a.fw, xi, yi, rad, tid, blockDim.x);
+    // A centre outside the map or a class id outside [0, num_classes) makes the reference fail with an index error
+    // (target_generator.py:70-75); the Python boundary raises before launching (hipmonocon/train.py).  For direct
+    // C-ABI callers the kernel stays memory-safe: no splat for such an object, gather index clamped into the map.
+    const bool centre_ok = xi >= 0 && xi < a.fw && yi >= 0 && yi < a.fh && cls >= 0 && cls < a.num_classes;
+    if (centre_ok)
+        splat(a.center_heatmap + ((size_t)b * a.num_classes + cls) * HW, a.fh, a.fw, xi, yi, rad, tid, blockDim.x);
     const size_t row = (size_t)b * a.max_objs + o;
     const float *b3 = a.gt_bboxes_3d + ((size_t)b * a.max_objs + slot) * 7;
     if (tid == 0) {
-        a.indices[row] = (long long)yi * a.fw + xi;
+        a.indices[row] = (long long)min(max(yi, 0), a.fh - 1) * a.fw + min(max(xi, 0), a.fw - 1);
         a.wh[row * 2 + 0] = bw; a.wh[row * 2 + 1] = bh;
         a.offset[row * 2 + 0] = ctx - (float)xi; a.offset[row * 2 + 1] = cty - (float)yi;
         a.dim[row * 3 + 0] = b3[3]; a.dim[row * 3 + 1] = b3[4]; a.dim[row * 3 + 2] = b3[5];

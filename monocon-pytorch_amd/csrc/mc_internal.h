@@ -110,6 +110,7 @@ struct mc_handle {
     // train-step plan (mc_train_plan.hip)
     TrainState *train = nullptr;
     size_t train_bytes = 0;   // device memory owned by the train plan
+    unsigned long long train_generation = 0;   // id of the forward whose activations the train plan holds (0: none)
     void (*train_free)(TrainState *) = nullptr;
     unsigned long long bind_gen = 0;
     bool pack_clean = false;   // packed panels match the bound parameters (cleared by bind / optimizer step)

@@ -82,6 +82,10 @@ struct TrainState {
     bool ok = true;
 };
 
+// generation of the activations the plan currently holds: bumped by every mc_forward_train on the handle (the plan
+// keeps ONE set of saved activations, so mc_backward always differentiates the LATEST forward)
+static unsigned long long g_train_generation = 0;
+
 static void train_free(TrainState *t) {
     if (!t) return;
     for (hipEvent_t e : t->side_ev) (void)hipEventDestroy(e);
@@ -732,8 +736,16 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
             HIPCHK(h, launch_pack_conv_w_dgrad_bf16(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls,
                                                     h->prec == 2 ? 3 : 1, j.dst16, st));
     }
+    ++g_train_generation;
+    h->train_generation = g_train_generation;
     for (auto &f : ts->fwd)
         if (f(h, st)) return -1;
+    return 0;
+}
+
+int mc_train_generation(mc_handle *h, unsigned long long *out) {
+    if (!h || !out) return -1;
+    *out = h->train_generation;
     return 0;
 }
 

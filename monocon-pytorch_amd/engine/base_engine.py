@@ -48,6 +48,8 @@ class BaseEngine:
         self.train_dataset, self.train_loader = self.build_loader(is_train=True) if not is_test else (None, None)
         self.test_dataset, self.test_loader = self.build_loader(is_train=False)
         self.model = self.build_model()
+        # data parallelism averages gradients only: every replica starts from rank 0's weights and buffers
+        hdist.sync_module_state(self.model)
         self.optimizer, self.scheduler = self.build_solver() if not is_test else (None, None)
 
         self.root = cfg.OUTPUT_DIR
@@ -110,8 +112,12 @@ class BaseEngine:
             if self.val_period > 0 and epoch % self.val_period == 0:
                 self.model.eval()
                 self._say("Evaluating on Epoch %d..." % epoch, indent=True)
-                eval_dict = self.evaluate()
-                self._update_dict_to_writer(eval_dict, tag='eval')
+                # rank 0 evaluates (result export / the AP evaluator write files); the others wait at the barrier
+                if self.is_main:
+                    eval_dict = self.evaluate()
+                    self._update_dict_to_writer(eval_dict, tag='eval')
+                if hdist.is_distributed():
+                    torch.distributed.barrier()
                 self.model.train()
                 self.save_checkpoint(post_fix=None)
         self.save_checkpoint(post_fix='final')
@@ -151,6 +157,7 @@ class BaseEngine:
         sd = d['state_dict']
         if sd['model'] is not None and self.model is not None:
             self.model.load_state_dict(sd['model'])
+            hdist.sync_module_state(self.model)
         if sd['optimizer'] is not None and self.optimizer is not None:
             self.optimizer.load_state_dict(sd['optimizer'])
         if sd['scheduler'] is not None and self.scheduler is not None:

@@ -3,6 +3,12 @@ the MI355X hot path.  ``train_one_epoch`` is the reference's step sequence -- ze
 ``self.model(data_dict)``, ``sum(losses).backward()``, clip, ``optimizer.step()``,
 ``scheduler.step()``, periodic logging -- with the clip folded into the fused HIP AdamW and, under
 ``torch.distributed.run``, a sharded sampler + the in-backward RCCL gradient all-reduce.
+
+Data-parallel policy (N ranks): ``DATA.BATCH_SIZE`` is the PER-RANK batch (global batch = N x BATCH_SIZE),
+the sampler shards the training set so an epoch has 1/N as many steps and the one-cycle schedule's
+``total_steps`` shrinks with it; ``SOLVER.OPTIM.LR`` is used exactly as configured -- nothing is scaled
+automatically, scale it in the config if the larger global batch calls for it.  All ranks start from rank 0's
+weights (``hipmonocon.dist.sync_module_state``); rank 0 alone evaluates and writes checkpoints.
 """
 import os
 from typing import Dict, List
@@ -52,7 +58,14 @@ class MonoconEngine(BaseEngine):
         else:
             # the KITTI file dataset (cv2 / pandas IO + augmentation) is outside the hot path;
             # it is taken from the reference tree when that is importable
-            from dataset.monocon_dataset import MonoConDataset
+            try:
+                from dataset.monocon_dataset import MonoConDataset
+            except ImportError as e:
+                from hipmonocon.lib import MonoconHipError
+                raise MonoconHipError(
+                    "DATA.ROOT=%r needs the KITTI file dataset (dataset/monocon_dataset.py, cv2 + pandas IO), which this "
+                    "package does not ship: put the reference tree on PYTHONPATH, or run with `DATA.ROOT synthetic` "
+                    "(import failed with: %s)" % (self.cfg.DATA.ROOT, e)) from e
             dataset = MonoConDataset(base_root=self.cfg.DATA.ROOT,
                                      split=self.cfg.DATA.TRAIN_SPLIT if is_train else self.cfg.DATA.TEST_SPLIT,
                                      max_objs=self.cfg.MODEL.HEAD.MAX_OBJS,

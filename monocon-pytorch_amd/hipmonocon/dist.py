@@ -42,6 +42,60 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def broadcast_seed(seed, src=0):
+    """Every rank adopts rank ``src``'s seed (a per-rank random seed would initialise each replica differently)."""
+    if not is_distributed():
+        return int(seed)
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
+@torch.no_grad()
+def sync_module_state(module, src=0):
+    """Broadcast every parameter and buffer of ``module`` from rank ``src`` (after construction and after a
+    checkpoint load): data parallelism only averages gradients, so replicas must START identical.  Floating-point
+    tensors travel in one flat buffer per dtype; returns the number of tensors synchronised."""
+    if not is_distributed():
+        return 0
+    import torch.distributed as dist
+    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
+    groups = {}
+    for t in tensors:
+        groups.setdefault((t.dtype, t.device), []).append(t)
+    for (_, _), ts in groups.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    return len(tensors)
+
+
+def state_checksum(module):
+    """Order-independent fp64 checksum of all parameters and buffers (test / assertion aid: equal across ranks)."""
+    tot = 0.0
+    for t in list(module.parameters()) + list(module.buffers()):
+        tot += float(t.detach().double().sum()) + 1e-3 * float(t.detach().double().abs().sum())
+    return tot
+
+
+def all_ranks_ok(ok, device=None):
+    """Logical AND of a per-rank flag, so that an assertion fires on every rank together instead of leaving the
+    others hanging in the next collective."""
+    if not is_distributed():
+        return bool(ok)
+    import torch.distributed as dist
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 class FlatGrads:
     """One contiguous buffer holding the gradients of ``named`` (name, tensor-like with .shape/.numel)
     in order; ``views[name]`` aliases the slice of each tensor.  Slices start at multiples of 4

@@ -228,3 +228,43 @@ def make_decode_inputs(seed, batch, feat_h=96, feat_w=320, topk=100):
         "alpha_offset_pred": normalish(seed, "dec.aoff", (batch, 12, feat_h, feat_w), 0, 0.3).astype(np.float32),
     }
     return d
+
+
+# --------------------------------------------------------------------------- conditioned train fixtures
+# Gradient-parity fixtures (tests/golden/train_cond_*.npz).  make_state_dict()/make_batch() are built for
+# test *power*; for gradient parity they are badly conditioned in two ways that have nothing to do with the
+# kernels: (1) head output logits of O(1) drive the depth / uncertainty losses into e^{-s} * 1/sigmoid(x)
+# regimes with gradient norms of 1e6..1e11, (2) i.i.d. noise images have identical per-image channel
+# statistics, so the BatchNorm over the batch inside AttnBN normalises round-off.  The conditioned variant
+# keeps every code path but uses small head output weights (as the reference initialiser does,
+# monocon_heads.py:134-146) and gives every image its own contrast / brightness.
+HEAD_OUT_SCALE = np.float32(0.02)
+
+
+def is_head_output_weight(key):
+    return key.startswith("head.") and (key.endswith(".3.weight") or key.endswith("dir_cls.0.weight")
+                                        or key.endswith("dir_reg.0.weight"))
+
+
+def make_conditioned_state_dict(seed=0, bn_stats=None, as_torch=True):
+    sd = make_state_dict(seed, bn_stats=bn_stats, as_torch=False)
+    for k in sd:
+        if is_head_output_weight(k):
+            sd[k] = (sd[k] * HEAD_OUT_SCALE).astype(np.float32)
+    if as_torch:
+        import torch
+        return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    return sd
+
+
+def make_conditioned_batch(seed, batch, height, width, as_torch=True):
+    d = make_batch(seed, batch, height, width, as_torch=False)
+    t = (np.arange(batch, dtype=np.float64) / max(batch - 1, 1))
+    sc = (0.4 + 1.2 * t).astype(np.float32).reshape(batch, 1, 1, 1)
+    sh = ((t - 0.5).reshape(batch, 1) * np.array([1.0, -0.5, 0.3])).astype(np.float32).reshape(batch, 3, 1, 1)
+    d["img"] = (d["img"] * sc + sh).astype(np.float32)          # two IEEE fp32 roundings, identical on every box
+    if as_torch:
+        import torch
+        d["img"] = torch.from_numpy(d["img"])
+        d["label"] = {k: torch.from_numpy(v) for k, v in d["label"].items()}
+    return d

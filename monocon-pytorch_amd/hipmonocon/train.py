@@ -75,6 +75,9 @@ class _HipTrainStep(torch.autograd.Function):
                                           C.c_void_p(losses.data_ptr()),
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(eng.h, rc, "mc_forward_train")
+        gen = C.c_ulonglong(0)
+        _lib.check(eng.h, eng.lib.mc_train_generation(eng.h, C.byref(gen)), "mc_train_generation")
+        ctx.generation = gen.value
         torch.autograd.graph.increment_version(tb.buffers)        # running statistics were updated in place
         ctx.eng, ctx.tb, ctx.keep = eng, tb, (img, keep, preds)
         ctx.mark_non_differentiable(*preds)
@@ -83,6 +86,13 @@ class _HipTrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_losses, *unused):
         eng, tb = ctx.eng, ctx.tb
+        gen = C.c_ulonglong(0)
+        _lib.check(eng.h, eng.lib.mc_train_generation(eng.h, C.byref(gen)), "mc_train_generation")
+        if gen.value != ctx.generation:
+            raise _lib.MonoconHipError(
+                "backward of train forward #%d, but the handle's saved activations belong to forward #%d: the HIP train "
+                "plan keeps one set of activations, so call backward() before the next forward (for gradient "
+                "accumulation run forward+backward per micro-batch)" % (ctx.generation, gen.value))
         g = grad_losses.contiguous().float()
         with torch.cuda.device(g.device):
             rc = eng.lib.mc_backward(eng.h, C.c_void_p(g.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -102,15 +112,33 @@ class _HipTrainStep(torch.autograd.Function):
         return (None, None, None, None, None, None, *out)
 
 
-def _require_objects(detector, mask):
-    """The reference asserts on empty targets (losses/l1_loss.py:15, README.MD:208-210); so does this path, before
-    anything is launched.  Reading the count back is a host sync, so a mask tensor that was already validated
-    (the SAME tensor object, unmodified: a resident batch stepped repeatedly) is not read back again."""
+def _require_objects(detector, label, pad_hw, num_classes=3):
+    """The reference asserts on empty targets (losses/l1_loss.py:15, README.MD:208-210) and fails with an index
+    error for an object whose centre falls outside the feature map or whose class id is out of range
+    (utils/target_generator.py:70-75: the heat-map / gather index is out of bounds); so does this path, before
+    anything is launched.  Reading the verdict back is a host sync, so a label set that was already validated
+    (the SAME mask tensor object, unmodified: a resident batch stepped repeatedly) is not read back again."""
+    mask = label["mask"]
     seen = getattr(detector, "_mask_validated", None)
     if seen is not None and seen[0]() is mask and seen[1] == mask._version:
         return
-    if float(mask.sum()) == 0:
+    H, W = pad_hw
+    fh, fw = H // 4, W // 4
+    bb, cls = label["gt_bboxes"], label["gt_labels"]
+    # same fp32 arithmetic as make_targets_kernel: centre = (x1 + x2) * (fw / W) / 2, truncated toward zero
+    wr = torch.tensor(fw / W, dtype=torch.float32, device=bb.device)
+    hr = torch.tensor(fh / H, dtype=torch.float32, device=bb.device)
+    xi = ((bb[..., 0] + bb[..., 2]) * wr / 2.0).trunc()
+    yi = ((bb[..., 1] + bb[..., 3]) * hr / 2.0).trunc()
+    bad = ((xi < 0) | (xi >= fw) | (yi < 0) | (yi >= fh) | (cls < 0) | (cls >= num_classes)) & (mask != 0)
+    n_valid, n_bad = torch.stack([mask.sum(), bad.sum().to(mask.dtype)]).tolist()
+    if not _dist.all_ranks_ok(n_valid != 0, mask.device):
+        # data parallel: every rank raises together (a lone raise would leave the others in the all-reduce)
         raise AssertionError("no valid objects in the batch: l1_loss requires target.numel() > 0")
+    if not _dist.all_ranks_ok(n_bad == 0, mask.device):
+        raise IndexError("%d labelled object(s) with a box centre outside the %dx%d feature map or a class id outside "
+                         "[0, %d): the reference's target generator indexes out of bounds for such labels"
+                         % (int(n_bad), fh, fw, num_classes))
     object.__setattr__(detector, "_mask_validated", (weakref.ref(mask), mask._version))
 
 
@@ -119,7 +147,7 @@ def forward_train(detector, data_dict):
     if not img.is_cuda:
         raise _lib.MonoconHipError("img must live on a HIP device; libmonocon_hip has no CPU path")
     label = data_dict["label"]
-    _require_objects(detector, label["mask"])
+    _require_objects(detector, label, img.shape[-2:])
     tb = _binding(detector)
     for n, p in tb.live:
         # a .grad that still aliases the flat buffer (zero_grad(set_to_none=False)) would be overwritten

@@ -26,19 +26,44 @@ class AdamW(Optimizer):
         self.max_grad_norm = max_grad_norm
         self._engine = engine
         self._bound_sig = None
-        self._steps = 0
         self.last_grad_norm = None      # device scalar of the most recent pre-clip norm
 
     def set_engine(self, engine):
         self._engine = engine
         self._bound_sig = None
 
+    def load_state_dict(self, state_dict):
+        """Restores the moments and the per-parameter ``step`` (torch.optim.AdamW's checkpoint layout, which
+        is what the reference saves, engine/base_engine.py:155-219).  The kernels hold raw pointers to the moment
+        tensors, which torch replaces here: the binding is dropped and rebuilt on the next step()."""
+        super().load_state_dict(state_dict)
+        self._bound_sig = None
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._bound_sig = None
+
+    def _common_step(self, plist):
+        """The bias-correction step lives in ``state[p]['step']`` only (so it survives state_dict round trips);
+        the fused kernel applies one step number to all tensors, as they always share it in this train loop."""
+        steps = {int(self.state[p]['step']) for p in plist}
+        if len(steps) != 1:
+            raise NotImplementedError("fused AdamW: parameters at different step counts %s" % sorted(steps))
+        return steps.pop()
+
     def _bind(self, plist):
         eng = self._engine
         if eng is None:
             from hipmonocon.engine import Engine
             eng = self._engine = Engine(plist[0].device.index)
-        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        for p in plist:
+            st = self.state[p]
+            if len(st) == 0:
+                st['step'] = torch.tensor(0.0)
+                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr(),
+                     self.state[p]['exp_avg_sq'].data_ptr()) for p in plist)
         if sig == self._bound_sig:
             return eng
         n = len(plist)
@@ -48,10 +73,11 @@ class AdamW(Optimizer):
             if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or not p.grad.is_contiguous():
                 raise _lib.MonoconHipError("fused AdamW needs contiguous float32 HIP parameters and gradients")
             st = self.state[p]
-            if len(st) == 0:
-                st['step'] = torch.tensor(0.0)
-                st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            for key in ('exp_avg', 'exp_avg_sq'):
+                m = st[key]
+                if m.dtype != torch.float32 or m.device != p.device or not m.is_contiguous():
+                    raise _lib.MonoconHipError("fused AdamW: state['%s'] must be a contiguous float32 tensor on the "
+                                               "parameter's device" % key)
             P[i], G[i], M[i], V[i] = p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
             N[i] = p.numel()
         _lib.check(eng.h, eng.lib.mc_optim_bind(eng.h, n, P, G, M, V, N), "mc_optim_bind")
@@ -69,7 +95,7 @@ class AdamW(Optimizer):
         if not plist:
             return loss
         eng = self._bind(plist)
-        self._steps += 1
+        step = self._common_step(plist) + 1
         for p in plist:
             self.state[p]['step'] += 1
         if self.last_grad_norm is None:
@@ -78,7 +104,7 @@ class AdamW(Optimizer):
         with torch.cuda.device(plist[0].device):
             rc = eng.lib.mc_clip_adamw_step(eng.h, float(group['lr']), float(beta1), float(beta2), float(group['eps']),
                                             float(group['weight_decay']),
-                                            float(self.max_grad_norm) if self.max_grad_norm else 0.0, self._steps,
+                                            float(self.max_grad_norm) if self.max_grad_norm else 0.0, step,
                                             C.c_void_p(self.last_grad_norm.data_ptr()),
                                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(eng.h, rc, "mc_clip_adamw_step")

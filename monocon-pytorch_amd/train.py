@@ -19,7 +19,10 @@ if args.opts:
     import yaml
     cfg.set_new_allowed(True)
     cfg.merge_from_list([yaml.safe_load(v) if i % 2 else v for i, v in enumerate(args.opts)])
-seed = generate_random_seed(cfg.get('SEED', -1))
+from hipmonocon import dist as hdist                                              # noqa: E402
+hdist.init_from_env()
+# one seed for all ranks: the replicas must start from the same weights (rank 0's draw is broadcast)
+seed = hdist.broadcast_seed(generate_random_seed(cfg.get('SEED', -1)))
 set_random_seed(seed)
 cfg.SEED = seed
 tprint("Using Random Seed %d" % seed)

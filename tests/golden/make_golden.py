@@ -231,7 +231,148 @@ def main():
         save("decode_k%d.npz" % K, **out)
 
     json.dump(META, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
+    cond_train(sd_stats=stats)
+    dp_shards(sd_stats=stats)
+    init_pins()
+
+
+# ==================================================================== round-2 additions
+def _grads(sd, batch, double):
+    m = ref_model(sd, train=True, double=double)
+    if double:
+        batch = dict(batch)
+        batch["img"] = batch["img"].double()
+    pred, loss = m(batch)
+    sum(v for v in loss.values()).backward()
+    g = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    return g, {k: (v.detach() if torch.is_tensor(v) else torch.tensor(float(v))) for k, v in loss.items()}, m, pred
+
+
+def sample_step(numel, target=2048):
+    """stride that keeps <= ~2048 evenly spaced elements of a tensor (tests use the same rule)."""
+    return max(1, numel // target)
+
+
+def gsample(t):
+    """float32 strided sample of a (possibly fp64) gradient tensor: parity is judged at 1e-4..1e-3, fp32 storage
+    (6e-8) is ample and keeps a fixture under 2 MB."""
+    return t.detach().reshape(-1)[::sample_step(t.numel())].float().clone()
+
+
+def _tensor_errs(ga, gb):
+    return {n: float((ga[n].double() - gb[n].double()).norm() / max(float(gb[n].double().norm()), 1e-30)) for n in gb}
+
+
+COND_CASES = ((4, 64, 64), (8, 32, 64), (4, 64, 64), (8, 32, 64))   # (B, H, W) of fixture 0, 1, 2, 3
+
+
+def cond_train(sd_stats):
+    """(4b) conditioned gradient fixtures, selected free of ReLU / max-pool decision flips.
+
+    A ReLU whose pre-activation sits within round-off of zero flips between two correct fp32
+    implementations; one flip on a 24x40 map moves every upstream gradient tensor by ~4e-4 relative L2
+    (measured with the reference itself), so any fixed fixture bounds gradient parity
+    by sqrt(#flips / #activations), not by kernel accuracy.  Like the tie-free decode fixtures, these are
+    therefore *selected*: a seed is kept only if (a) the reference's fp64 gradients move < 1e-4 on every
+    tensor when the image is perturbed by 3e-7 relative noise (5 fp32 ulps: no decision within a few
+    round-offs of its threshold) and (b) the reference's own fp32 run (8 threads and 1 thread) agrees with its fp64 run
+    to < 2e-4 on every tensor."""
+    sd = synth.make_conditioned_state_dict(SEED, bn_stats={k: v.numpy() for k, v in sd_stats.items()})
+    seed, picked = 400, []
+    for case, (B, H, W) in enumerate(COND_CASES):
+        for _attempt in range(200):
+            seed += 1
+            b = synth.make_conditioned_batch(seed, B, H, W)
+            g64, l64, m64, _ = _grads(sd, b, True)
+            noise = torch.from_numpy(synth.uniform(seed, "cond.noise", tuple(b["img"].shape), -1.0, 1.0))
+            bp = dict(b)
+            bp["img"] = (b["img"].double() * (1.0 + 3e-7 * noise))
+            g64p = _grads(sd, bp, True)[0]
+            e_margin = max(_tensor_errs(g64p, g64).values())
+            if e_margin >= 1e-4:
+                print("  cond case %d seed %d rejected: perturbed-fp64 max %.1e" % (case, seed, e_margin)); continue
+            g32, l32, m32, pred32 = _grads(sd, b, False)
+            torch.set_num_threads(1)
+            g32s = _grads(sd, b, False)[0]
+            torch.set_num_threads(META["threads"])
+            e32 = max(max(_tensor_errs(g32, g64).values()), max(_tensor_errs(g32s, g64).values()))
+            if e32 >= 2e-4:
+                print("  cond case %d seed %d rejected: fp32 max %.1e" % (case, seed, e32)); continue
+            break
+        else:
+            raise RuntimeError("no flip-free seed found for case %d" % case)
+        print("cond case %d: B=%d %dx%d seed %d  perturbed-fp64 %.1e  ref fp32-vs-fp64 %.1e" % (case, B, H, W, seed, e_margin, e32))
+        out = {"seed": seed, "shape": np.array([B, H, W]), "ref32_max_err": e32, "margin_err": e_margin}
+        for k in l64:
+            out["f64." + k] = l64[k]
+            out[k] = l32[k]
+        for n in g64:
+            out["gnorm64." + n] = g64[n].norm()
+            out["g64." + n] = gsample(g64[n])
+            out["gnorm." + n] = g32[n].double().norm()
+        new64 = m64.state_dict()
+        for k in new64:
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                out["buf64." + k] = new64[k]
+        save("train_cond_%d.npz" % case, **out)
+        picked.append(seed)
+    return picked
+
+
+def dp_shards(sd_stats):
+    """(8) data parallelism: N-rank gradients == mean over ranks of the per-shard gradients (each loss is
+    normalised by its *local* object count).  Global batch of 8 at 64x64 split into 2 shards of 4
+    and into 4 shards of 2; reference fp64 and fp32, strided samples + norms of the mean gradient, and the
+    per-shard losses."""
+    sd = synth.make_conditioned_state_dict(SEED, bn_stats={k: v.numpy() for k, v in sd_stats.items()})
+    gb = synth.make_conditioned_batch(SEED + 60, 8, 64, 64)
+    out = {"seed": SEED + 60, "shape": np.array([8, 64, 64])}
+    for world in (2, 4):
+        per = 8 // world
+        mean64, mean32 = None, None
+        for r in range(world):
+            sl = slice(r * per, (r + 1) * per)
+            b = {"img": gb["img"][sl].clone(), "label": {k: v[sl].clone() for k, v in gb["label"].items()},
+                 "img_metas": {k: v[sl] for k, v in gb["img_metas"].items()}, "calib": gb["calib"][sl]}
+            g64, l64, _, _ = _grads(sd, b, True)
+            g32, l32, _, _ = _grads(sd, b, False)
+            for k in l64:
+                out["w%d.r%d.f64.%s" % (world, r, k)] = l64[k]
+            mean64 = g64 if mean64 is None else {n: mean64[n] + g64[n] for n in g64}
+            mean32 = g32 if mean32 is None else {n: mean32[n] + g32[n] for n in g32}
+        for n in mean64:
+            out["w%d.gnorm64.%s" % (world, n)] = (mean64[n] / world).norm()
+            out["w%d.g64.%s" % (world, n)] = gsample(mean64[n] / world)
+            out["w%d.gerr32.%s" % (world, n)] = _tensor_errs({n: mean32[n]}, {n: mean64[n]})[n]
+    save("dp_shards.npz", **out)
+
+
+def init_pins():
+    """(9) initialisers: the reference detector built under torch.manual_seed(5) --
+    mean / std / min / max and a CRC-32 of the raw bytes of all 449 state_dict entries.  The product's
+    ``init_weights`` consume the torch generator in the reference's order, so on the same torch build the
+    tensors are bit-identical (CRC) and on any build the moments agree."""
+    import zlib
+    torch.manual_seed(5)
+    m = MonoConDetector(34, pretrained_backbone=False)
+    out = {"torch_seed": 5}
+    names, crc, mom = [], [], []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        crc.append(zlib.crc32(v.detach().contiguous().numpy().tobytes()))
+        f = v.detach().double().reshape(-1)
+        mom.append([float(f.mean()), float(f.std()) if f.numel() > 1 else 0.0, float(f.min()), float(f.max())])
+    out["names"] = np.array(names)
+    out["crc32"] = np.array(crc, dtype=np.int64)
+    out["moments"] = np.array(mom, dtype=np.float64)
+    save("init_pins.npz", **out)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
+        cond_train(sd_stats=_stats)
+        dp_shards(sd_stats=_stats)
+        init_pins()
+    else:
+        main()

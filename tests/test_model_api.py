@@ -50,6 +50,32 @@ def test_init_distributions_follow_reference():
     assert torch.equal(up[0], up[17])
 
 
+def test_initialisers_pinned_to_the_reference():
+    """all 449 state_dict entries of a freshly built detector against the reference built under
+    the same torch seed (tests/golden/init_pins.npz): moments always, raw bytes (CRC-32) on the torch build that
+    made the golden -- init_weights draws from the generator in the reference's order."""
+    import zlib
+    g = load_golden("init_pins.npz")
+    torch.manual_seed(int(g["torch_seed"]))
+    from model import MonoConDetector
+    m = MonoConDetector(34, pretrained_backbone=False)
+    sd = m.state_dict()
+    assert list(sd.keys()) == g["names"].tolist()
+    same_build = torch.__version__ == __import__("json").load(open(__import__("os").path.join(
+        __import__("os").path.dirname(__file__), "golden", "meta.json")))["torch"]
+    for i, (k, v) in enumerate(sd.items()):
+        f = v.detach().double().reshape(-1)
+        mom = np.array([float(f.mean()), float(f.std()) if f.numel() > 1 else 0.0, float(f.min()), float(f.max())])
+        ref = g["moments"][i]
+        if same_build:
+            assert zlib.crc32(v.detach().contiguous().numpy().tobytes()) == int(g["crc32"][i]), k
+            assert np.array_equal(mom, ref), k
+        else:   # another torch build may draw different normals: distribution-level agreement
+            n = max(f.numel(), 1)
+            assert abs(mom[0] - ref[0]) <= 6 * max(ref[1], 1e-6) / n ** 0.5 + 1e-6, k
+            assert abs(mom[1] - ref[1]) <= 0.1 * ref[1] + 6 * ref[1] / n ** 0.5 + 1e-6, k
+
+
 def test_cpu_forward_is_a_loud_error(golden_sd):
     from hipmonocon.lib import MonoconHipError
     m = build(golden_sd).eval()

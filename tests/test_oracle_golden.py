@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err, GOLDEN_SEED
+from conftest import load_golden, rel_err, grad_rel_l2, GOLDEN_SEED
 from hipmonocon import synth, netspec
 from oracle import monocon_oracle as O
 
@@ -146,3 +146,61 @@ def test_decode(K):
         assert rel_err(R["box2d"][i][mk], g["box2d.%d" % i]) < 1e-6
         assert rel_err(R["box3d_shift"][i][mk], g["box3d.%d" % i]) < 1e-5
         assert np.array_equal(R["cls"][i][mk].numpy(), g["label.%d" % i])
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_conditioned_train_fixture(cond_sd, case):
+    """the oracle's fp32 train step on a flip-free fixture (make_golden.py cond_train): every loss within 1e-4 of
+    the reference's fp64 run, every one of the 236 gradient tensors within 1e-3 relative L2."""
+    g = load_golden("train_cond_%d.npz" % case)
+    B, H, W = (int(x) for x in g["shape"])
+    batch = synth.make_conditioned_batch(int(g["seed"]), B, H, W)
+    roles = netspec.state_shapes()
+    sd = {k: v.clone() for k, v in cond_sd.items()}
+    for k, v in sd.items():
+        if roles[k][2] == "param":
+            v.requires_grad_(True)
+    _, _, L, newbuf = O.train_forward(sd, batch)
+    sum(L.values()).backward()
+    for k, v in L.items():
+        assert abs(float(v) - float(g["f64." + k])) <= 1e-4 * abs(float(g["f64." + k])) + 1e-7, k
+    worst = 0.0
+    n = 0
+    for k, v in sd.items():
+        if roles[k][2] != "param" or k in netspec.DEAD_PARAMS:
+            continue
+        e = grad_rel_l2(v.grad, g["g64." + k], g["gnorm64." + k], v.numel())
+        worst = max(worst, e)
+        n += 1
+        assert e < 1e-3, (k, e)
+    assert n == 236
+    for k, v in newbuf.items():
+        if not k.endswith("num_batches_tracked"):
+            assert rel_err(v, g["buf64." + k]) < 1e-4, k
+
+
+def test_dp_shard_goldens_world2(cond_sd):
+    """mean over 2 shards of the oracle's gradients == the reference's (SURVEY 8c golden 8)."""
+    g = load_golden("dp_shards.npz")
+    B, H, W = (int(x) for x in g["shape"])
+    gb = synth.make_conditioned_batch(int(g["seed"]), B, H, W)
+    roles = netspec.state_shapes()
+    mean = None
+    for r in range(2):
+        sl = slice(r * 4, r * 4 + 4)
+        sd = {k: v.clone() for k, v in cond_sd.items()}
+        for k, v in sd.items():
+            if roles[k][2] == "param":
+                v.requires_grad_(True)
+        b = {"img": gb["img"][sl], "label": {k: v[sl] for k, v in gb["label"].items()},
+             "img_metas": {k: v[sl] for k, v in gb["img_metas"].items()}}
+        _, _, L, _ = O.train_forward(sd, b)
+        for k, v in L.items():
+            assert abs(float(v) - float(g["w2.r%d.f64.%s" % (r, k)])) <= 1e-4 * abs(float(g["w2.r%d.f64.%s" % (r, k)])) + 1e-7
+        sum(L.values()).backward()
+        gr = {k: v.grad.double() for k, v in sd.items() if roles[k][2] == "param" and k not in netspec.DEAD_PARAMS}
+        mean = gr if mean is None else {k: mean[k] + gr[k] for k in gr}
+    for k in mean:
+        e = grad_rel_l2(mean[k] / 2, g["w2.g64." + k], g["w2.gnorm64." + k], mean[k].numel())
+        # shards are not selected flip-free: bound = the reference's own fp32 deviation on this tensor, x4
+        assert e <= 4.0 * float(g["w2.gerr32." + k]) + 2e-3, (k, e, float(g["w2.gerr32." + k]))
