@@ -138,6 +138,12 @@ int mc_losses(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_tar
 int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS],
                        const mc_targets *targets, int B, int max_objs, int feat_h, int feat_w,
                        const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream);
+/* The same gradient with respect to the prediction maps THEMSELVES (the tensors _get_losses receives:
+ * post sigmoid+clamp heat-maps, transformed depth) -- what autograd hands back from
+ * MonoConDenseHeads._get_losses(pred_dict, target_dict) (model/dense_heads/monocon_heads.py:203-310). */
+int mc_losses_backward_pred(mc_handle *h, const float *const preds[MC_NUM_PREDS],
+                            const mc_targets *targets, int B, int max_objs, int feat_h, int feat_w,
+                            const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream);
 
 /* ---- training step ---------------------------------------------------------------------
  * mc_forward_train replaces `pred_dict, loss_dict = model(data_dict)` in train mode

@@ -173,7 +173,7 @@ __global__ void focal_final_kernel(const float *partial, int nblocks, float *los
 // d loss / d logit through clamp(sigmoid(x), 1e-4, 1-1e-4):  p is the clamped prediction
 __global__ __launch_bounds__(256) void focal_grad_kernel(const float *__restrict__ p, const float *__restrict__ t,
                                                          size_t n, const float *aux, const float *gscale, int gidx,
-                                                         float *__restrict__ dlogit) {
+                                                         float *__restrict__ dlogit, int wrt_pred) {
     const float np = aux[0];
     const float k = -gscale[gidx] / (np == 0.f ? 1.f : np);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void focal_grad_kernel(const float *__restrict
             d = (-pv * pv / (1.f - pv + 1e-12f) + 2.f * pv * logf(1.f - pv + 1e-12f)) * (q2 * q2);
         }
         const bool inside = pv > 1e-4f && pv < 1.f - 1e-4f;
-        dlogit[i] = inside ? k * d * pv * (1.f - pv) : 0.f;
+        dlogit[i] = wrt_pred ? k * d : (inside ? k * d * pv * (1.f - pv) : 0.f);
     }
 }
 
@@ -198,8 +198,8 @@ hipError_t launch_focal(const float *p, const float *t, size_t n, float *partial
     return hipGetLastError();
 }
 hipError_t launch_focal_grad(const float *p, const float *t, size_t n, const float *aux, const float *gscale, int gidx,
-                             float *dlogit, hipStream_t st) {
-    hipLaunchKernelGGL(focal_grad_kernel, dim3(2048), dim3(256), 0, st, p, t, n, aux, gscale, gidx, dlogit);
+                             float *dlogit, hipStream_t st, int wrt_pred) {
+    hipLaunchKernelGGL(focal_grad_kernel, dim3(2048), dim3(256), 0, st, p, t, n, aux, gscale, gidx, dlogit, wrt_pred);
     return hipGetLastError();
 }
 int focal_partial_floats() { return FOCAL_BLOCKS * 3; }
@@ -309,7 +309,8 @@ __global__ __launch_bounds__(1024) void gathered_loss_kernel(const GatherLossArg
             const float gd = g_dep * e * sgnf(d - a.depth[r]);
             // d = 1/(sigmoid(x)+eps) - 1  =>  dd/dx = -sig(1-sig)/(sig+eps)^2 with sig = 1/(d+1) - eps
             const float sig = 1.f / (d + 1.f) - 1e-12f;
-            atomicAdd(&a.dpred[7][P(7, 2, b, 0, ind)], gd * (-sig * (1.f - sig) / ((sig + 1e-12f) * (sig + 1e-12f))));
+            atomicAdd(&a.dpred[7][P(7, 2, b, 0, ind)],
+                      a.wrt_pred ? gd : gd * (-sig * (1.f - sig) / ((sig + 1e-12f) * (sig + 1e-12f))));
             atomicAdd(&a.dpred[7][P(7, 2, b, 1, ind)], g_dep * (1.f - e * fabsf(d - a.depth[r])));
         }
         for (int c = 0; c < 18; ++c) {

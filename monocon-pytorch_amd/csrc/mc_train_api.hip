@@ -109,8 +109,9 @@ int mc_losses(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_tar
     return 0;
 }
 
-int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *t, int B, int max_objs,
-                       int fh, int fw, const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream) {
+static int losses_backward_impl(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *t, int B, int max_objs,
+                                int fh, int fw, const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream,
+                                int wrt_pred) {
     if (!h) return -1;
     if (!preds || !dpreds || !grad_losses) return fail(h, "mc_losses_backward: null argument");
     for (int i = 0; i < MC_NUM_PREDS; ++i)
@@ -132,12 +133,23 @@ int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS], con
     } else {
         for (int i = 2; i < 10; ++i) HIPCHK(h, hipMemsetAsync(dpreds[i], 0, (size_t)B * PC[i] * HW * 4, st));
     }
-    HIPCHK(h, mc::launch_focal_grad(preds[0], t->center_heatmap_target, (size_t)B * 3 * HW, aux + 0, grad_losses, 0, dpreds[0], st));
-    HIPCHK(h, mc::launch_focal_grad(preds[1], t->kpt_heatmap_target, (size_t)B * 9 * HW, aux + 1, grad_losses, 5, dpreds[1], st));
+    HIPCHK(h, mc::launch_focal_grad(preds[0], t->center_heatmap_target, (size_t)B * 3 * HW, aux + 0, grad_losses, 0, dpreds[0], st, wrt_pred));
+    HIPCHK(h, mc::launch_focal_grad(preds[1], t->kpt_heatmap_target, (size_t)B * 9 * HW, aux + 1, grad_losses, 5, dpreds[1], st, wrt_pred));
     mc::GatherLossArgs g{};
     fill_gather_args(g, preds, dpreds, t, B, max_objs, (int)HW, scratch_losses, aux + 2, grad_losses);
+    g.wrt_pred = wrt_pred;
     HIPCHK(h, mc::launch_gathered_losses(g, 1, st));
     return 0;
+}
+
+int mc_losses_backward(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *t, int B, int max_objs,
+                       int fh, int fw, const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream) {
+    return losses_backward_impl(h, preds, t, B, max_objs, fh, fw, grad_losses, dpreds, stream, 0);
+}
+
+int mc_losses_backward_pred(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *t, int B, int max_objs,
+                            int fh, int fw, const float *grad_losses, float *const dpreds[MC_NUM_PREDS], void *stream) {
+    return losses_backward_impl(h, preds, t, B, max_objs, fh, fw, grad_losses, dpreds, stream, 1);
 }
 
 int mc_op_conv_wgrad(mc_handle *h, const float *const src[], const int src_channels[], int nsrc, int B, int Hin, int Win,

@@ -26,7 +26,7 @@ hipError_t launch_make_targets(const TargetArgs &a, hipStream_t st);
 hipError_t launch_focal(const float *p, const float *t, size_t n, float *partial, float *loss_out, float *aux,
                         hipStream_t st);
 hipError_t launch_focal_grad(const float *p, const float *t, size_t n, const float *aux, const float *gscale, int gidx,
-                             float *dlogit, hipStream_t st);
+                             float *dlogit, hipStream_t st, int wrt_pred = 0);
 int focal_partial_floats();
 
 struct GatherLossArgs {
@@ -39,6 +39,7 @@ struct GatherLossArgs {
     float *losses;               // [10] LOSS order
     float *aux;                  // [1] number of valid objects
     const float *gscale;         // [10] upstream gradient of each loss (mode 1)
+    int wrt_pred;                // mode 1: 0 = gradient wrt the raw 1x1 outputs, 1 = wrt the prediction maps themselves
 };
 hipError_t launch_gathered_losses(const GatherLossArgs &a, int mode, hipStream_t st);
 

@@ -264,8 +264,9 @@ class Engine:
         _lib.check(self.h, rc, "mc_losses")
         return out
 
-    def losses_backward(self, pred, T, grad_losses, max_objs=30):
-        """gradient of sum(grad_losses * losses) wrt the raw 1x1 outputs behind each prediction map."""
+    def losses_backward(self, pred, T, grad_losses, max_objs=30, wrt_pred=False):
+        """gradient of sum(grad_losses * losses) wrt the raw 1x1 outputs behind each prediction map, or
+        (``wrt_pred``) wrt the prediction maps themselves."""
         heat = _need_cuda(pred["center_heatmap_pred"], "center_heatmap_pred")
         B, _, fh, fw = heat.shape
         arr = (C.c_void_p * _lib.NUM_PREDS)(*[_need_cuda(pred[k], k).data_ptr() for k in PRED_KEYS])
@@ -274,7 +275,8 @@ class Engine:
         st = self._targets_struct(T)
         g = _need_cuda(grad_losses, "grad_losses")
         with torch.cuda.device(heat.device):
-            rc = self.lib.mc_losses_backward(self.h, arr, C.byref(st), B, max_objs, fh, fw, _ptr(g), darr, _stream())
+            fn = self.lib.mc_losses_backward_pred if wrt_pred else self.lib.mc_losses_backward
+            rc = fn(self.h, arr, C.byref(st), B, max_objs, fh, fw, _ptr(g), darr, _stream())
         _lib.check(self.h, rc, "mc_losses_backward")
         return dict(zip(PRED_KEYS, d))
 

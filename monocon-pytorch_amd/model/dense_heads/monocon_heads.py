@@ -25,6 +25,23 @@ PI = np.pi
 DEFAULT_TEST_CFG = {'topk': 30, 'local_maximum_kernel': 3, 'max_per_img': 30, 'test_thres': 0.4}
 
 
+class _HipLosses(torch.autograd.Function):
+    """(10,) loss vector of ten prediction maps; backward returns d(sum_i g_i * loss_i) / d pred_k."""
+
+    @staticmethod
+    def forward(ctx, eng, T, max_objs, *preds):
+        from hipmonocon import netspec
+        keys = [k for k, _ in netspec.PRED_KEYS]
+        pd = {k: p.detach().contiguous() for k, p in zip(keys, preds)}
+        ctx.eng, ctx.T, ctx.pd, ctx.max_objs = eng, T, pd, max_objs
+        return eng.losses(pd, T, max_objs=max_objs)
+
+    @staticmethod
+    def backward(ctx, grad_losses):
+        d = ctx.eng.losses_backward(ctx.pd, ctx.T, grad_losses.contiguous().float(), max_objs=ctx.max_objs, wrt_pred=True)
+        return (None, None, None, *[d[k] for k in ctx.pd])
+
+
 class MonoConDenseHeads(nn.Module):
     def __init__(self, in_ch: int = 64, feat_ch: int = 64, num_kpts: int = 9, num_alpha_bins: int = 12,
                  num_classes: int = 3, max_objs: int = 30, test_config: Dict[str, Any] = None):
@@ -93,6 +110,26 @@ class MonoConDenseHeads(nn.Module):
         if self.training:
             raise NotImplementedError("stand-alone head prediction is eval-only; training runs through MonoConDetector")
         return self._engine().head_forward(feat.contiguous())
+
+    # ------------------------------------------------------------------ losses
+    def _get_losses(self, pred_dict: Dict[str, torch.Tensor], target_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """reference monocon_heads.py:203-310: the ten losses of a prediction dict against a target dict (as produced
+        by the reference's TargetGenerator or ``hipmonocon.Engine.make_targets``), autograd-connected to the
+        prediction tensors: forward = ``mc_losses`` (two focal reductions + one gather kernel), backward =
+        ``mc_losses_backward_pred`` (gradient wrt the maps in ``pred_dict``)."""
+        from hipmonocon import netspec
+        eng = self._engine()
+        keys = [k for k, _ in netspec.PRED_KEYS]
+        T = {}
+        for k, v in target_dict.items():
+            if k in ("indices", "indices_kpt"):
+                T[k] = v.to(torch.int64).contiguous()
+            elif k == "mask_target":
+                T[k] = v.to(torch.bool).contiguous()
+            else:
+                T[k] = v.to(torch.float32).contiguous()
+        losses = _HipLosses.apply(eng, T, self.max_objs, *[pred_dict[k] for k in keys])
+        return {k: losses[i] for i, k in enumerate(netspec.LOSS_KEYS)}
 
     # ------------------------------------------------------------------ decode
     @staticmethod

@@ -38,6 +38,12 @@ class AdamW(Optimizer):
         tensors, which torch replaces here: the binding is dropped and rebuilt on the next step()."""
         super().load_state_dict(state_dict)
         self._bound_sig = None
+        # torch hands the caller's own 'step' (and same-device moment) tensors through uncopied; step() updates
+        # them in place, so take private copies -- loading one checkpoint dict into two optimizers stays safe
+        for st in self.state.values():
+            for key in ('step', 'exp_avg', 'exp_avg_sq'):
+                if key in st and torch.is_tensor(st[key]):
+                    st[key] = st[key].clone()
 
     def __setstate__(self, state):
         super().__setstate__(state)

@@ -6,10 +6,36 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, rel_err, GOLDEN_SEED
+from conftest import load_golden, rel_err, grad_rel_l2, GOLDEN_SEED
 from hipmonocon import netspec, synth
 
 pytestmark = pytest.mark.gpu
+
+# The parity tests below run in both fp32 modes of the library: "fp32" = v_mfma_f32_32x32x2_f32 (native fp32 matrix
+# pipe), "bf16x3" = fp32 emulated on the bf16 matrix pipe (each fp32 operand split into three bf16 pieces, six partial
+# products, fp32 accumulation).  Both must meet the SAME fp32 tolerances.
+PRECISIONS = ("fp32", "bf16x3")
+LOSS_TOL = 1e-4          # BASELINE.json north_star: fp32 losses within 1e-4 relative (judged against the fp64 reference)
+
+
+def build(sd, precision="fp32"):
+    from model import MonoConDetector
+    m = MonoConDetector(34, pretrained_backbone=False)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    m.set_precision(precision)
+    return m
+
+
+def oracle_losses_fp64(sd, batch):
+    """the CPU oracle's train forward in float64: the yard-stick for loss parity at arbitrary shapes"""
+    from oracle import monocon_oracle as O
+    sd64 = {k: (v.double().clone() if v.dtype == torch.float32 else v.clone()) for k, v in sd.items()}
+    b64 = dict(batch)
+    b64["img"] = batch["img"].double()
+    with torch.no_grad():
+        _, _, L, _ = O.train_forward(sd64, b64)
+    return {k: float(v) for k, v in L.items()}
 
 
 def to_cuda(batch):
@@ -19,12 +45,9 @@ def to_cuda(batch):
     return d
 
 
-@pytest.fixture(scope="module")
-def stepped(golden_sd):
-    from model import MonoConDetector
-    m = MonoConDetector(34, pretrained_backbone=False)
-    m.load_state_dict(golden_sd, strict=True)
-    m = m.cuda().train()
+@pytest.fixture(scope="module", params=PRECISIONS)
+def stepped(golden_sd, request):
+    m = build(golden_sd, request.param)
     batch = to_cuda(synth.make_batch(GOLDEN_SEED + 4, 2, 192, 384))
     pred, loss = m(batch)
     total = sum(v for v in loss.values())
@@ -37,10 +60,13 @@ def test_losses_match_reference(stepped):
     m, pred, loss, total = stepped
     g = load_golden("train_step.npz")
     assert list(loss.keys()) == list(netspec.LOSS_KEYS)
+    tot64 = 0.0
     for k, v in loss.items():
         assert v.dim() == 0 and v.requires_grad
-        assert abs(float(v) - float(g[k])) <= 2e-4 * abs(float(g[k])) + 1e-6, (k, float(v), float(g[k]))
-    assert abs(float(total) - float(g["total"])) <= 2e-4 * abs(float(g["total"]))
+        ref64 = float(g["f64." + k])                 # the reference run in float64 (measured: <= 4.4e-5)
+        tot64 += ref64
+        assert abs(float(v.detach()) - ref64) <= LOSS_TOL * abs(ref64) + 1e-7, (k, float(v.detach()), ref64)
+    assert abs(float(total.detach()) - tot64) <= LOSS_TOL * abs(tot64)
     for k, v in pred.items():
         assert rel_err(v.detach().cpu().reshape(-1)[::31], g["pred." + k + ".sample"]) < 2e-4, k
 
@@ -74,8 +100,10 @@ def test_gradients_match_reference(stepped):
     # amplified on the way down: the reference's OWN fp32 CPU gradients sit 1e-5 (heads) .. 2.5e-2
     # (backbone) from its fp64 gradients, and which tensor lands where is arbitrary.  The HIP kernels
     # accumulate each output in one long fp32 FMA chain (MKLDNN blocks its sums), which measures as
-    # 1.2-2.5x the CPU's fp32 noise at equal algorithm.  Bounds: every tensor within 6x the worst
-    # reference-fp32 deviation of its section; section medians within 3x the reference medians.
+    # 1.0-2.6x the CPU's fp32 noise at equal algorithm (measured, both precision modes).  Bounds: every
+    # tensor within 3x the worst reference-fp32 deviation of its section; section medians within 2.5x the
+    # reference medians.  (The cause is ReLU / max-pool decisions flipping under round-off -- see
+    # test_conditioned_gradients_vs_reference_fp64 for the flip-free fixtures that are held to 1e-3.)
     rows = []
     for n, p in m.named_parameters():
         if n in dead:
@@ -95,9 +123,54 @@ def test_gradients_match_reference(stepped):
         print("%-9s tensors %3d  ref32-vs-fp64 max %.2e med %.2e | hip-vs-fp64 max %.2e med %.2e"
               % (sec, len(sel), ref_max, ref_med, max(r[2] for r in sel), hip_med))
         for r in sel:
-            assert r[2] <= 6.0 * ref_max + 1e-3, r
-            assert r[4] <= 6.0 * ref_max + 2e-3, r
-        assert hip_med <= 3.0 * ref_med + 1e-4, (sec, hip_med, ref_med)
+            assert r[2] <= 3.0 * ref_max + 1e-3, r
+            assert r[4] <= 3.0 * ref_max + 2e-3, r
+        assert hip_med <= 2.5 * ref_med + 1e-4, (sec, hip_med, ref_med)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_conditioned_gradients_vs_reference_fp64(cond_sd, case, precision):
+    """Gradient parity on well-conditioned fixtures (tests/golden/train_cond_*.npz, make_golden.py cond_train):
+    small head output weights (no e^{-s}/sigmoid blow-up in the depth loss), per-image contrast (the BatchNorm over
+    the batch inside AttnBN is not normalising round-off), and seeds SELECTED so that the reference itself has no
+    ReLU / max-pool decision within a few fp32 round-offs of its threshold -- its own fp32 run then sits <= 1.4e-4
+    from its fp64 run on every tensor, instead of the 1e-2 a single flipped decision causes.
+
+    Fixtures 0 and 1: every loss within 1e-4 and EVERY one of the 236 gradient tensors within 1e-3 relative L2 of the
+    reference's fp64 gradients (measured: <= 3.4e-4 fp32, <= 2.2e-4 bf16x3).  Fixtures 2 and 3 document the flip
+    mechanism: the HIP kernels round differently from MKLDNN, one decision lands on the other side (fixture 3: in
+    both precision modes), and all upstream tensors shift together (max 1.1e-2) while the losses, the BN buffers
+    and the median tensor stay at the 1e-5 level; for those two only the statistical bounds are asserted."""
+    g = load_golden("train_cond_%d.npz" % case)
+    B, H, W = (int(x) for x in g["shape"])
+    m = build(cond_sd, precision)
+    _, loss = m(to_cuda(synth.make_conditioned_batch(int(g["seed"]), B, H, W)))
+    sum(loss.values()).backward()
+    torch.cuda.synchronize()
+    for k, v in loss.items():
+        ref = float(g["f64." + k])
+        assert abs(float(v.detach()) - ref) <= LOSS_TOL * abs(ref) + 1e-7, (k, float(v.detach()), ref)
+    errs = {}
+    for n, p in m.named_parameters():
+        if n in netspec.DEAD_PARAMS:
+            assert p.grad is None, n
+            continue
+        errs[n] = grad_rel_l2(p.grad, g["g64." + n], g["gnorm64." + n], p.numel())
+    assert len(errs) == 236
+    e = np.array(list(errs.values()))
+    worst = max(errs, key=errs.get)
+    print("cond fixture %d %s: max %.2e (%s) median %.2e, reference fp32-vs-fp64 max %.2e"
+          % (case, precision, e.max(), worst, np.median(e), float(g["ref32_max_err"])))
+    assert float(np.median(e)) <= 1e-4, np.median(e)
+    if case in (0, 1):
+        assert e.max() <= 1e-3, (worst, e.max())
+    else:
+        assert e.max() <= 3e-2, (worst, e.max())
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert rel_err(sd[k].cpu(), g["buf64." + k]) < 1e-4, k
 
 
 def test_train_step_with_fused_optimizer_reduces_loss(golden_sd):
@@ -126,8 +199,9 @@ def test_train_step_with_fused_optimizer_reduces_loss(golden_sd):
     assert all(torch.isfinite(v).all() for v in out.values())
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("shape", [(3, 64, 128), (2, 128, 512), (5, 96, 160), (2, 96, 1248)], ids=lambda s: "B%d_%dx%d" % s)
-def test_train_forward_shape_sweep_vs_oracle(golden_sd, shape):
+def test_train_forward_shape_sweep_vs_oracle(golden_sd, shape, precision):
     """odd batches / other resolutions through the train plan (autotuned conv shapes, 16-channel row kernels
     where the width allows, parity-class stride-2 data gradients): losses vs the CPU oracle's train forward,
     gradients finite and of the oracle's total norm."""
@@ -141,13 +215,12 @@ def test_train_forward_shape_sweep_vs_oracle(golden_sd, shape):
     sum(L.values()).backward()
     ref_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in live.values()
                                     if getattr(p, "grad", None) is not None)))
-    m = MonoConDetector(34, pretrained_backbone=False)
-    m.load_state_dict(golden_sd, strict=True)
-    m = m.cuda().train()
+    L64 = oracle_losses_fp64(golden_sd, batch)
+    m = build(golden_sd, precision)
     _, loss = m(to_cuda(batch))
     sum(loss.values()).backward()
-    for k, v in loss.items():
-        assert abs(float(v) - float(L[k])) <= 2e-3 * abs(float(L[k])) + 1e-4, (k, float(v), float(L[k]))
+    for k, v in loss.items():       # measured: <= 5.7e-5 (the oracle's own fp32 run sits up to 6.3e-5 from its fp64 run)
+        assert abs(float(v.detach()) - L64[k]) <= LOSS_TOL * abs(L64[k]) + 1e-7, (k, float(v.detach()), L64[k])
     g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
     assert bool(torch.isfinite(g).all())
     assert abs(float(g.double().norm()) - ref_norm) <= 0.05 * ref_norm, (float(g.double().norm()), ref_norm)
@@ -167,13 +240,12 @@ def test_image_without_objects_inside_a_batch(golden_sd):
     sum(L.values()).backward()
     ref_norm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in live.values()
                                     if getattr(p, "grad", None) is not None)))
-    m = MonoConDetector(34, pretrained_backbone=False)
-    m.load_state_dict(golden_sd, strict=True)
-    m = m.cuda().train()
+    L64 = oracle_losses_fp64(golden_sd, batch)
+    m = build(golden_sd)
     _, loss = m(to_cuda(batch))
     sum(loss.values()).backward()
     for k, v in loss.items():
-        assert abs(float(v) - float(L[k])) <= 2e-3 * abs(float(L[k])) + 1e-4, (k, float(v), float(L[k]))
+        assert abs(float(v.detach()) - L64[k]) <= LOSS_TOL * abs(L64[k]) + 1e-7, (k, float(v.detach()), L64[k])
     g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
     assert bool(torch.isfinite(g).all())
     assert abs(float(g.double().norm()) - ref_norm) <= 0.05 * ref_norm, (float(g.double().norm()), ref_norm)
