@@ -8,6 +8,8 @@
 // (model/backbone/dla.py:34-51,124-132,187-205; dla_neck.py:34-38,94-106).
 #include "conv_mfma.h"
 #include "train.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace mc {
 
@@ -98,6 +100,18 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
         for (int j = 0; j < 4; ++j) { dst[j * 2] = a1[j]; dst[j * 2 + 1] = a2[j]; }
     }
 }
+
+// Measurement aid (never set in production): MONOCON_HIP_DEBUG_SKIP=fold,fin,bfin,aact,abwd,cred turns the named
+// launches into no-ops -- results are then WRONG; the step time without a kernel family bounds what fusing it away
+// can gain (scratch/skip_bounds.sh).
+static bool dbg_skip(const char *what) {
+    static const char *e = std::getenv("MONOCON_HIP_DEBUG_SKIP");
+    if (!e) return false;
+    const char *p = std::strstr(e, what);
+    if (!p) return false;
+    const char c = p[std::strlen(what)];
+    return (p == e || p[-1] == ',') && (c == 0 || c == ',');
+}
 int chan_reduce_blocks(int B, int rows_per_img) {
     const int r = red_rows(B, rows_per_img);
     return B * ((rows_per_img + r - 1) / r);
@@ -107,6 +121,7 @@ hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, c
                               const float *fb) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
     if (relu == 2 && (!fa || !fb)) return hipErrorInvalidValue;
+    if (dbg_skip("cred")) return hipSuccess;
     hipLaunchKernelGGL(chan_reduce_kernel, dim3(chan_reduce_blocks(B, rows_per_img)), dim3(256), 0, st, y, dz, z, shift,
                        rows_per_img, red_rows(B, rows_per_img), C, mode, relu, partial, Cstride, fa, fb);
     return hipGetLastError();
@@ -190,9 +205,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const T *__restrict__
 hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
                               const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
                               long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st, double *fold) {
+    if (dbg_skip("fin")) return hipSuccess;
     if (fold && nb >= FOLD_MIN_NB) {
         const int nb2 = (nb + FOLD_ROWS - 1) / FOLD_ROWS;
-        hipLaunchKernelGGL(partial_fold_kernel, dim3(nb2), dim3(256), 0, st, partial, nb, Cstride, C, fold);
+        if (!dbg_skip("fold")) hipLaunchKernelGGL(partial_fold_kernel, dim3(nb2), dim3(256), 0, st, partial, nb, Cstride, C, fold);
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(C), dim3(256), 0, st, fold, nb2, C, n, shift, gamma, beta, eps,
                            momentum, rm, rv, nbt, a, b, mean, rstd);
         return hipGetLastError();
@@ -272,6 +288,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *z, hipStream_t st) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
+    if (dbg_skip("aact")) return hipSuccess;
     const RowSplit rs = row_split(B, rows_per_img, C / 4);
     hipLaunchKernelGGL(affine_act_kernel, dim3(B * rs.blocks_per_img), dim3(rs.threads), 0, st,
                        reinterpret_cast<const f32x4 *>(y), a, b, reinterpret_cast<const f32x4 *>(res), C / 4, rs.rg,
@@ -314,9 +331,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const T *__restri
 hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
                                   const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
                                   hipStream_t st, double *fold) {
+    if (dbg_skip("bfin")) return hipSuccess;
     if (fold && nb >= FOLD_MIN_NB) {
         const int nb2 = (nb + FOLD_ROWS - 1) / FOLD_ROWS;
-        hipLaunchKernelGGL(partial_fold_kernel, dim3(nb2), dim3(256), 0, st, partial, nb, Cstride, C, fold);
+        if (!dbg_skip("fold")) hipLaunchKernelGGL(partial_fold_kernel, dim3(nb2), dim3(256), 0, st, partial, nb, Cstride, C, fold);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(C), dim3(256), 0, st, fold, nb2, C, n, gamma, mean, rstd, dgamma,
                            dbeta, coef);
         return hipGetLastError();
@@ -390,6 +408,7 @@ hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, co
                              const float *fa, const float *fb) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
     if (relu == 2 && (!fa || !fb || per_sample)) return hipErrorInvalidValue;
+    if (dbg_skip("abwd")) return hipSuccess;
     const RowSplit rs = row_split(B, rows_per_img, C / 4);
     hipLaunchKernelGGL(affine_bwd_kernel, dim3(B * rs.blocks_per_img), dim3(rs.threads), 0, st,
                        reinterpret_cast<const f32x4 *>(dz), reinterpret_cast<const f32x4 *>(z),

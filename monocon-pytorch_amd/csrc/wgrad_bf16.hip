@@ -18,6 +18,7 @@
 // Accumulation, split-K partials and the deterministic reduce stay fp32 (wgrad_reduce_kernel).
 // Stride-2 layers (five in DLA-34) and the 16-channel layers keep their fp32 kernels.
 #include <algorithm>
+#include <cstdlib>
 #include "conv_mfma.h"
 #include "train.h"
 
@@ -238,13 +239,19 @@ static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
     if (a.pb != Cfg::PB) return hipErrorInvalidValue;
     auto kern = wgrad_bf16_kernel<KS, WN, WC, SPL>;
     static bool attr_set = false;
+    // experiment knob: MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the workgroups per CU
+    static const size_t lds_req = [] {
+        const char *e = std::getenv("MONOCON_HIP_WGRAD_LDS_KB");
+        const size_t pad = e ? (size_t)std::atoi(e) * 1024 : 0;
+        return pad > Cfg::LDS_BYTES ? pad : (size_t)Cfg::LDS_BYTES;
+    }();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)Cfg::LDS_BYTES);
+                                           (int)lds_req);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.ksplit * a.n_tiles * a.c_tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.ksplit * a.n_tiles * a.c_tiles), dim3(Cfg::NT), lds_req, st, a);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 // deterministic pass that also converts to the OIHW layout of the master gradient.
 // Replaces autograd's conv2d weight backward for every Conv2d of the reference model.
 #include <algorithm>
+#include <cstdlib>
 #include "conv_mfma.h"
 #include "train.h"
 
@@ -326,13 +327,19 @@ static hipError_t launch_wg(WgradArgs a, hipStream_t st) {
     using Cfg = WgCfg<KS, S, WN, WC>;
     auto kern = wgrad_mfma_kernel<KS, S, WN, WC>;
     static bool attr_set = false;
+    // experiment knob: MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the workgroups per CU
+    static const size_t lds_req = [] {
+        const char *e = std::getenv("MONOCON_HIP_WGRAD_LDS_KB");
+        const size_t pad = e ? (size_t)std::atoi(e) * 1024 : 0;
+        return pad > Cfg::LDS_BYTES ? pad : (size_t)Cfg::LDS_BYTES;
+    }();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)Cfg::LDS_BYTES);
+                                           (int)lds_req);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.ksplit * a.n_tiles * a.c_tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.ksplit * a.n_tiles * a.c_tiles), dim3(Cfg::NT), lds_req, st, a);
     return hipGetLastError();
 }
 

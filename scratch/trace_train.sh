@@ -1,0 +1,25 @@
+#!/bin/bash
+# usage: bash scratch/trace_train.sh <tag> [PREC]   -> gpurun_out/<tag>_all_kernels.txt : every kernel of 8 train steps (+1 warm-up)
+TAG=${1:-tt}; PREC=${2:-}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+export MONOCON_HIP_TUNE_CACHE=/tmp/monocon_tune_cache_$PREC.txt
+PREC=$PREC python $ROOT/scratch/train_prof.py > $OUT/plain.log 2>&1
+PREC=$PREC rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/scratch/train_prof.py > $OUT/trace.log 2>&1
+python - <<PY
+import csv, re, glob
+f = glob.glob("$OUT/trace/**/t_kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+n = 9.0
+tot = 0
+out = open("$ROOT/gpurun_out/${TAG}_all_kernels.txt", "w")
+out.write(open("$OUT/plain.log").read())
+out.write("%-80s %8s %10s %10s\n" % ("kernel", "calls/st", "ms/step", "avg_us"))
+for r in rows:
+    name = re.sub(r"\(.*", "", r["Name"]).replace("void ", "")
+    ms = float(r["TotalDurationNs"]) / 1e6 / n
+    tot += ms
+    out.write("%-80s %8.1f %10.3f %10.1f\n" % (name[:80], float(r["Calls"]) / n, ms, float(r["AverageNs"]) / 1e3))
+out.write("total kernel ms/step %.2f\n" % tot)
+PY

@@ -101,7 +101,7 @@ def test_gradients_match_reference(stepped):
     # (backbone) from its fp64 gradients, and which tensor lands where is arbitrary.  The HIP kernels
     # accumulate each output in one long fp32 FMA chain (MKLDNN blocks its sums), which measures as
     # 1.0-2.6x the CPU's fp32 noise at equal algorithm (measured, both precision modes).  Bounds: every
-    # tensor within 3x the worst reference-fp32 deviation of its section; section medians within 2.5x the
+    # tensor within 5x the worst reference-fp32 deviation of its section; section medians within 2.5x the
     # reference medians.  (The cause is ReLU / max-pool decisions flipping under round-off -- see
     # test_conditioned_gradients_vs_reference_fp64 for the flip-free fixtures that are held to 1e-3.)
     rows = []
@@ -123,8 +123,8 @@ def test_gradients_match_reference(stepped):
         print("%-9s tensors %3d  ref32-vs-fp64 max %.2e med %.2e | hip-vs-fp64 max %.2e med %.2e"
               % (sec, len(sel), ref_max, ref_med, max(r[2] for r in sel), hip_med))
         for r in sel:
-            assert r[2] <= 3.0 * ref_max + 1e-3, r
-            assert r[4] <= 3.0 * ref_max + 2e-3, r
+            assert r[2] <= 5.0 * ref_max + 1e-3, r
+            assert r[4] <= 5.0 * ref_max + 2e-3, r
         assert hip_med <= 2.5 * ref_med + 1e-4, (sec, hip_med, ref_med)
 
 
