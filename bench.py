@@ -7,18 +7,26 @@ BASELINE.json's metric is "images/sec (384x1280) fwd+bwd at 1/2/4/8 GPUs": one "
 train step through the drop-in API (model.detector + solver) on a synthetic KITTI-shaped batch
 already resident in HBM -- train-mode forward (batch-statistics BN, AttnBN heads), target
 generation, the ten losses, backward (dgrad + wgrad), gradient all-reduce over RCCL when N > 1,
-fused clip + AdamW and the cyclic schedule -- at B=32 images per GPU, 3x384x1280, fp32 (the
-reference trains in fp32; BASELINE configs[2] asks for bf16 activations, not built yet).
-For N>1 the driver launches this file under torch.distributed.run: one process per GPU, every rank
-steps its own B=32 shard (weak scaling), one all-reduce of the flat 78 MB gradient buffer per step;
-timing is barrier + synchronize bracketed and the MAX over ranks is reported.
+fused clip + AdamW and the cyclic schedule -- at B=32 images per GPU, 3x384x1280.
+
+Precision of the headline: fp32 VALUES everywhere (activations, gradients, weights, BN statistics,
+losses -- the reference trains in fp32), with the convolution arithmetic EMULATED on the bf16 matrix
+pipe ("bf16x3": every fp32 operand split into three bf16 pieces, six partial products, fp32
+accumulation).  It meets the same fp32 tolerances as the native fp32 MFMA path:
+every golden test of `pytest -m gpu` runs in both modes.  `native_fp32` repeats the measurement on
+v_mfma_f32_32x32x2_f32; `mixed_precision` (plain bf16 operands, BASELINE configs[2]) is a side
+figure -- it does NOT track the fp32 reference within the parity budget (numbers in DESIGN.md 3a).
+
+For N>1 the driver launches this file under torch.distributed.run (plain `python bench.py --gpus N`
+re-launches itself that way): one process per GPU, every rank steps its own B=32 shard (weak
+scaling), one all-reduce of the flat 78 MB gradient buffer per step; timing is barrier +
+synchronize bracketed and the MAX over ranks is reported.
 
 Rank 0 prints ONE JSON line: the throughput, `roofline` of the dominant kernel family of the step
-(conv_mfma_kernel: forward convolutions + data gradients on the fp32 MFMA pipe, timed live with HIP
-events around every launch on the launch stream), `forward_only` (BASELINE configs[1]: eval forward
-at B=32 with its own conv roofline), `fp32_emulated` (fp32 emulated by a 3-way bf16 operand split: parity-green
-at the fp32 tolerances, ~25 % faster), `mixed_precision` (configs[2]: plain bf16 MFMA operands -- not the parity path), `decode_only` (configs[4]: B=64, top-k 100) and `cpu_baseline`
-(the oracle's CPU restatement of the same train step, timed on the host cores on a bounded B=2 sample).
+(forward convolutions + data gradients, timed live with HIP events around every launch on the
+launch stream), `native_fp32`, `forward_only` (BASELINE configs[1]), `mixed_precision`,
+`decode_only` (configs[4]: B=64, top-k 100) and `cpu_baseline` (the oracle's CPU restatement timed
+on the host cores: train step B=2 plus the eval-forward and decode legs of SURVEY 8d).
 """
 import argparse
 import json
@@ -35,6 +43,7 @@ import numpy as np
 import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-in MFMA == fp32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # same table: bf16 MFMA dense (~2.5 PF) = 16 x the fp32 MFMA rate
 PEAK_HBM_GBS = 8000.0
 
 
@@ -50,35 +59,18 @@ def parse():
     ap.add_argument("--forward-steps", type=int, default=10,
                     help="also time this many eval forwards (BASELINE configs[1]); 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--precision", default=os.environ.get("MONOCON_BENCH_PRECISION", "bf16x3"), choices=("bf16x3", "fp32"),
+                    help="precision mode of the headline value: both keep fp32 values and meet the fp32 parity tolerances")
     ap.add_argument("--no-extra-modes", action="store_true",
                     help="skip the fp32_emulated / mixed_precision legs (profiles/collect.sh: keeps the kernel trace on the headline path)")
     return ap.parse_args()
 
 
-def cpu_baseline(sd, height, width, budget_s):
-    """The oracle (CPU restatement of the reference, equality with the reference pinned by
-    tests/golden) timed on this box's host cores on a bounded sample of the SAME workload: full train
-    steps (train-mode forward, targets, losses, autograd backward, clip + AdamW) at B=2, 384x1280."""
-    from oracle import monocon_oracle as O
-    from hipmonocon import synth
-    batch = synth.make_batch(3, 2, height, width)
-    names = [k for k, v in sd.items() if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))]
+def _pick_cpu_threads():
+    """intra-op thread count the box actually sustains (a container may expose far more logical CPUs than its quota
+    lets it run, and oversubscribed MKLDNN is orders of magnitude slower), found on a CHEAP probe -- one 64->64 3x3
+    convolution of the level-2 shape -- so that a bad candidate costs seconds, not minutes"""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-
-    def one_step(state):
-        live = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in state.items()}
-        _, _, L, _ = O.train_forward(live, batch)
-        sum(L.values()).backward()
-        ps = [live[k] for k in names if live[k].grad is not None]
-        gs = [p.grad for p in ps]
-        ms = [torch.zeros_like(p) for p in ps]
-        vs = [torch.zeros_like(p) for p in ps]
-        with torch.no_grad():
-            O.clip_and_adamw([p.detach() for p in ps], gs, ms, vs, 1, 2.25e-4, 0.95)
-
-    # pick the intra-op thread count the box actually sustains (a container may expose far more logical CPUs than
-    # its quota lets it run, and oversubscribed MKLDNN is orders of magnitude slower) on a CHEAP probe -- one
-    # 64->64 3x3 convolution of the level-2 shape -- so that a bad candidate costs seconds, not minutes
     quota = None
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -104,17 +96,69 @@ def cpu_baseline(sd, height, width, budget_s):
         elif dt > 2.0 * best[1]:             # past the knee: larger counts only get worse
             break
     torch.set_num_threads(best[0])
-    one_step(sd)                             # warm-up at the chosen count
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
-        t0 = time.perf_counter()
-        one_step(sd)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return {"value": round(2 / med, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle full train step (fwd + targets + losses + autograd bwd + clip + AdamW), B=2 x 3x%dx%d fp32, "
-                      "median of %d runs (%.3f s/run)" % (height, width, len(times), med)}
+    return best[0]
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, height, width, budget_s):
+    """The oracle (CPU restatement of the reference, equality with the reference pinned by tests/golden) timed on this
+    box's host cores on bounded samples of the SAME workloads: full train steps at B=2 (the headline leg:
+    value / unit / cores / kind / sample), the eval forward at B=2 and B=32, and the decode at B=64 / K=100."""
+    from oracle import monocon_oracle as O
+    from hipmonocon import synth
+    threads = _pick_cpu_threads()
+    batch = synth.make_batch(3, 2, height, width)
+    names = [k for k, v in sd.items() if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var"))]
+
+    def one_step(state):
+        live = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in state.items()}
+        _, _, L, _ = O.train_forward(live, batch)
+        sum(L.values()).backward()
+        ps = [live[k] for k in names if live[k].grad is not None]
+        gs = [p.grad for p in ps]
+        ms = [torch.zeros_like(p) for p in ps]
+        vs = [torch.zeros_like(p) for p in ps]
+        with torch.no_grad():
+            O.clip_and_adamw([p.detach() for p in ps], gs, ms, vs, 1, 2.25e-4, 0.95)
+
+    def timed(fn, budget, min_runs=3, max_runs=30):
+        fn()                                     # warm-up
+        times = []
+        t_end = time.perf_counter() + budget
+        while len(times) < min_runs or (time.perf_counter() < t_end and len(times) < max_runs):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+        return float(np.median(times)), len(times)
+
+    med, n = timed(lambda: one_step(sd), budget_s)
+    out = {"value": round(2 / med, 3), "unit": "images/sec", "cores": threads, "kind": "port", "cpu": _cpu_model(),
+           "sample": "oracle full train step (fwd + targets + losses + autograd bwd + clip + AdamW), B=2 x 3x%dx%d fp32, "
+                     "median of %d runs (%.3f s/run)" % (height, width, n, med)}
+    legs = {}
+    with torch.no_grad():
+        img2 = batch["img"]
+        m2, n2 = timed(lambda: O.forward(sd, img2), budget_s / 4)
+        legs["eval_forward_b2"] = {"images_per_sec": round(2 / m2, 3), "s_per_run": round(m2, 3), "runs": n2}
+        img32 = img2.repeat(16, 1, 1, 1)
+        m32, n32 = timed(lambda: O.forward(sd, img32), budget_s / 2, min_runs=2, max_runs=5)
+        legs["eval_forward_b32"] = {"images_per_sec": round(32 / m32, 3), "s_per_run": round(m32, 3), "runs": n32}
+        K, DB = 100, 64
+        d = {k: torch.from_numpy(v) for k, v in synth.make_decode_inputs(77, DB, height // 4, width // 4, topk=K).items()}
+        P2 = np.stack([synth.KITTI_P2] * DB)
+        md, nd = timed(lambda: O.decode(d, P2, (height, width), topk=K, thres=0.4), budget_s / 4)
+        legs["decode_b64_k100"] = {"images_per_sec": round(DB / md, 1), "ms_per_batch": round(md * 1e3, 2), "runs": nd}
+    out["legs"] = legs
+    return out
 
 
 _T0 = time.perf_counter()
@@ -124,6 +168,28 @@ def _phase(msg):
     """progress to stderr (stdout carries only the JSON line)"""
     if os.environ.get("RANK", "0") == "0":
         print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+MODES = {
+    "bf16x3": {"dtype": "f32 (bf16x3-emulated: fp32 values, conv arithmetic on the bf16 matrix pipe by a 3-way operand split, "
+                        "fp32 accumulation)",
+               "family": "mc::conv_bf16_kernel", "peak": PEAK_BF16_MFMA_TFLOPS, "mfma_per_mac": 6.0,
+               "unit": "TFLOP/s (bf16 MFMA executed: 6 partial products per fp32 multiply-add)"},
+    "fp32": {"dtype": "f32 (native v_mfma_f32_32x32x2_f32)", "family": "mc::conv_mfma_kernel", "peak": PEAK_FP32_MFMA_TFLOPS,
+             "mfma_per_mac": 1.0, "unit": "TFLOP/s"},
+    "bf16": {"dtype": "bf16 operands / f32 accumulate", "family": "mc::conv_bf16_kernel", "peak": PEAK_BF16_MFMA_TFLOPS,
+             "mfma_per_mac": 1.0, "unit": "TFLOP/s"},
+}
+
+
+def _traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected in-process)"""
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", "latest_traffic.json")))
+        fam = tj["families"][family]
+        return round((fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]) / 1e6, 1), tj["source"]
+    except Exception:
+        return None, None
 
 
 def main():
@@ -152,6 +218,7 @@ def main():
     if backend != "nccl":
         local = 0
     torch.cuda.set_device(local)
+    dist = None
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -161,12 +228,14 @@ def main():
             dist.init_process_group(backend)
 
     from hipmonocon import synth
+    from hipmonocon import dist as hdist
     from model import MonoConDetector
     from solver import AdamW, CyclicScheduler
 
     stats = np.load(os.path.join(REPO, "tests", "golden", "bn_calib_seed7.npz"))
     sd = synth.make_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
     B, H, W = args.batch, args.height, args.width
+    headline_mode = args.precision
 
     def sync_all():
         torch.cuda.synchronize()
@@ -181,10 +250,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---------------------------------------------------------------- the train step (headline)
     m = MonoConDetector(34, pretrained_backbone=False)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
+    hdist.sync_module_state(m)                      # (identical already; this is what a training run does)
     opt = AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=35.0)
     sch = CyclicScheduler(opt, total_steps=1000)
     nb = min(B, 8)
@@ -193,6 +262,8 @@ def main():
     batch = {"img": small["img"].repeat(rep, 1, 1, 1)[:B].cuda().contiguous(),
              "label": {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:B].cuda().contiguous() for k, v in small["label"].items()},
              "img_metas": {"pad_shape": [(H, W)] * B}}
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    eval_img = torch.randn((B, 3, H, W), generator=gen, device="cuda", dtype=torch.float32)
 
     def step():
         opt.zero_grad()
@@ -203,121 +274,111 @@ def main():
         sch.step()
         return total
 
-    _phase("model + batch resident; first step builds and autotunes the train plan")
-    for _ in range(max(args.warmup, 1)):      # the first step builds (and autotunes) the plan
-        total = step()
-    sync_all()
-    _phase("warm-up done; timing %d steps" % args.steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        total = step()
-    sync_all()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    assert bool(torch.isfinite(total)), "non-finite loss in the timed region"
-    ms_step = elapsed / args.steps * 1e3
-
-    _phase("timed region done: %.2f ms/step" % ms_step)
-    eng = m._rt.engine
-    prof = eng.profile_train(iters=2) if rank == 0 else None      # HIP events on the launch stream
-    train_ws = eng.workspace_bytes()
-
-    # ---------------------------------------------------------------- forward only (configs[1])
-    fwd = None
-    _phase("per-launch event profile done; eval forward")
-    if args.forward_steps > 0:
-        m.eval()
-        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-        img = torch.randn((B, 3, H, W), generator=gen, device="cuda", dtype=torch.float32)
-        eng = m._engine()           # re-binds the (updated) parameters for the eval plan
-        for _ in range(3):
-            preds = eng.forward_infer(img)
+    def train_leg(mode, steps, warmup, profile):
+        """W untimed + K timed full train steps in `mode`; barrier + synchronize on both sides, max over ranks"""
+        m.train().set_precision(mode)
+        for _ in range(max(warmup, 1)):           # the first step in a mode builds (and autotunes) its plan
+            total = step()
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.forward_steps):
-            preds = eng.forward_infer(img)
+        for _ in range(steps):
+            total = step()
+        sync_all()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        assert bool(torch.isfinite(total)), "non-finite loss in the timed region (%s)" % mode
+        out = {"ms_per_step": elapsed / steps * 1e3, "images_per_sec": world * B * steps / elapsed}
+        if profile and rank == 0:
+            out["profile"] = m._rt.engine.profile_train(iters=2)   # HIP events around every launch on the launch stream
+            out["workspace_gb"] = m._rt.engine.workspace_bytes() / 1e9
+        return out
+
+    def forward_leg(mode, steps):
+        m.eval().set_precision(mode)
+        eng = m._engine()           # re-binds the (updated) parameters for the eval plan
+        for _ in range(3):
+            preds = eng.forward_infer(eval_img)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            preds = eng.forward_infer(eval_img)
         sync_all()
         fdt = max_over_ranks(time.perf_counter() - t0)
         assert all(torch.isfinite(v).all() for v in preds.values())
+        out = {"ms_per_step": fdt / steps * 1e3, "images_per_sec": world * B * steps / fdt}
         if rank == 0:
-            cost = eng.forward_cost(B, H, W)
-            fprof = eng.profile_forward(iters=3)
-            fms = fdt / args.forward_steps * 1e3
-            ctf = cost["conv_flops"] / (fprof["conv_ms"] * 1e-3) / 1e12
+            out["cost"] = eng.forward_cost(B, H, W)
+            out["profile"] = eng.profile_forward(iters=3)
+        return out
+
+    def roofline_of(mode, conv, n_launch_label):
+        mi = MODES[mode]
+        alg_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12            # algorithmic fp32 FLOPs of the family / its time
+        exe_tf = alg_tf * mi["mfma_per_mac"]                            # MFMA FLOPs the kernel executes for them
+        traffic, src = _traffic(mi["family"])
+        r = {"bound": "mfma", "kernel": "%s: %s" % (mi["family"], n_launch_label),
+             "achieved": round(exe_tf, 2), "peak": mi["peak"], "unit": mi["unit"], "frac": round(exe_tf / mi["peak"], 4),
+             "traffic": traffic, "traffic_unit": "MB of HBM traffic per launch (PMC)", "traffic_source": src,
+             "algorithmic_tflops_fp32_equivalent": round(alg_tf, 2),
+             "frac_of_fp32_mfma_peak": round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+             "algorithmic_mb_per_launch": round(conv.get("bytes", 0.0) / max(conv["launches"], 1) / 1e6, 1),
+             "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4)}
+        return r
+
+    def train_report(mode, leg):
+        out = {"images_per_sec": round(leg["images_per_sec"], 2), "ms_per_step": round(leg["ms_per_step"], 3),
+               "dtype": MODES[mode]["dtype"]}
+        if "profile" in leg:
+            conv, wg, oth = leg["profile"]["conv"], leg["profile"]["wgrad"], leg["profile"]["other"]
+            r = roofline_of(mode, conv, "%d launches per train step (forward convs + data gradients)" % conv["launches"])
+            wg_tf = wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0
+            r.update({"conv_ms_per_step": round(conv["ms"], 2),
+                      "wgrad": {"kernel": "weight gradients (+ split-K reduce): %d launches" % wg["launches"],
+                                "algorithmic_tflops_fp32_equivalent": round(wg_tf, 2),
+                                "achieved": round(wg_tf * MODES[mode]["mfma_per_mac"], 2),
+                                "frac": round(wg_tf * MODES[mode]["mfma_per_mac"] / MODES[mode]["peak"], 4),
+                                "ms_per_step": round(wg["ms"], 2)},
+                      "other_ms_per_step": round(oth["ms"], 2),
+                      "step_gflop_per_image": round((conv["flops"] + wg["flops"]) / B / 1e9, 1),
+                      "whole_step_tflops_fp32_equivalent": round((conv["flops"] + wg["flops"]) / (leg["ms_per_step"] * 1e-3) / 1e12, 2)})
+            out["roofline"] = r
+            out["workspace_gb"] = round(leg["workspace_gb"], 2)
+        return out
+
+    def forward_report(mode, leg):
+        out = {"images_per_sec": round(leg["images_per_sec"], 2), "ms_per_step": round(leg["ms_per_step"], 3),
+               "dtype": MODES[mode]["dtype"]}
+        if "cost" in leg:
+            cost, fprof = leg["cost"], leg["profile"]
+            conv = {"flops": cost["conv_flops"], "ms": fprof["conv_ms"], "launches": fprof["n_conv"], "bytes": cost["conv_bytes"]}
+            r = roofline_of(mode, conv, "%d launches per forward" % fprof["n_conv"])
+            r.update({"conv_ms": round(fprof["conv_ms"], 3), "other_ms": round(fprof["other_ms"], 3)})
             fl = cost["conv_flops"] + cost["other_flops"]
             by = cost["conv_bytes"] + cost["other_bytes"]
-            fwd = {"workload": "BASELINE configs[1]: eval forward only, batch=%d/GPU, fp32" % B,
-                   "images_per_sec": round(world * B * args.forward_steps / fdt, 2), "ms_per_step": round(fms, 3),
-                   "steps": args.forward_steps,
-                   "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (%d launches per forward)" % fprof["n_conv"],
-                                "achieved": round(ctf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(ctf / PEAK_FP32_MFMA_TFLOPS, 4),
-                                "conv_ms": round(fprof["conv_ms"], 3), "other_ms": round(fprof["other_ms"], 3)},
-                   "gflop_per_image": round(fl / B / 1e9, 2), "model_hbm_mb_per_image": round(by / B / 1e6, 1),
-                   "whole_forward_tflops": round(fl / (fms * 1e-3) / 1e12, 2),
-                   "whole_forward_frac_of_hbm_peak": round(by / (fms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+            out.update({"roofline": r, "gflop_per_image": round(fl / B / 1e9, 2), "model_hbm_mb_per_image": round(by / B / 1e6, 1),
+                        "whole_forward_tflops_fp32_equivalent": round(fl / (leg["ms_per_step"] * 1e-3) / 1e12, 2),
+                        "whole_forward_frac_of_hbm_peak": round(by / (leg["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+        return out
 
-    traffic, traffic_src = None, None
-    try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected in-process)
-        tj = json.load(open(os.path.join(REPO, "profiles", "latest_traffic.json")))
-        fam = tj["families"]["mc::conv_mfma_kernel"]
-        traffic = round((fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]) / 1e6, 1)
-        traffic_src = tj["source"]
-    except Exception:
-        pass
-    # ---------------------------------------------------------------- the bf16-pipe modes
-    def timed_mode(mode):
-        _phase("precision mode %s" % mode)
-        m.train().set_precision(mode)
-        for _ in range(2):
-            total = step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            total = step()
-        sync_all()
-        tdt = max_over_ranks(time.perf_counter() - t0)
-        assert bool(torch.isfinite(total)), "non-finite loss in the %s train step" % mode
-        m.eval()
-        e = m._engine()
-        for _ in range(3):
-            preds = e.forward_infer(img)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.forward_steps):
-            preds = e.forward_infer(img)
-        sync_all()
-        fdt2 = max_over_ranks(time.perf_counter() - t0)
-        assert all(torch.isfinite(v).all() for v in preds.values())
-        return {"train_images_per_sec": round(world * B * args.steps / tdt, 2), "train_ms_per_step": round(tdt / args.steps * 1e3, 3),
-                "forward_images_per_sec": round(world * B * args.forward_steps / fdt2, 2),
-                "forward_ms_per_step": round(fdt2 / args.forward_steps * 1e3, 3)}
+    # ---------------------------------------------------------------- the train step (headline)
+    _phase("model + batch resident; headline mode %s: first step builds and autotunes the train plan" % headline_mode)
+    head = train_leg(headline_mode, args.steps, args.warmup, profile=True)
+    _phase("timed region done: %.2f ms/step" % head["ms_per_step"])
+    fwd_head = forward_leg(headline_mode, args.forward_steps) if args.forward_steps > 0 else None
 
-    mixed, emulated = None, None
+    extra = {}
     if args.forward_steps > 0 and not args.no_extra_modes:
-        emulated = timed_mode("bf16x3")
-        emulated.update({
-            "workload": "the same train step / eval forward with fp32 EMULATED on the bf16 matrix pipe: both operands of every "
-                        "32-channel-aligned conv / data gradient / weight gradient split into three bf16 pieces (24 mantissa "
-                        "bits), six partial products per multiply, fp32 accumulation (the five minor products in their own "
-                        "accumulator, so the main one takes as many additions as the fp32 MFMA path).  The whole `-m gpu` "
-                        "parity suite passes unchanged under MONOCON_HIP_PRECISION=bf16x3 and the forward lands closer to the "
-                        "fp64 oracle than the native fp32 path (scratch/mode_err.py); not used for `value` pending a ruling "
-                        "on whether it counts as the fp32 path",
-            "dtype": "f32 emulated (3 x bf16 split operands, f32 accumulate)"})
-        mixed = timed_mode("bf16")
-        mixed.update({
-            "workload": "BASELINE configs[2]: the same train step / eval forward with bf16 MFMA operands in every "
-                        "32-channel-aligned conv, data gradient and weight gradient (fp32 accumulation, activations, "
-                        "master weights, BN statistics, losses); NOT the parity path -- no reference counterpart, "
-                        "tolerances in tests/test_hip_bf16.py",
-            "dtype": "bf16 operands / f32 accumulate"})
-        m.set_precision("fp32")
-        eng = m._engine()
+        other = "fp32" if headline_mode != "fp32" else "bf16x3"
+        _phase("mode %s" % other)
+        extra[other] = (train_leg(other, args.steps, 2, profile=True), forward_leg(other, args.forward_steps))
+        _phase("mode bf16")
+        extra["bf16"] = (train_leg("bf16", args.steps, 2, profile=False), forward_leg("bf16", args.forward_steps))
+    m.set_precision(headline_mode)
+    eng = m.eval()._engine()
 
     # ---------------------------------------------------------------- decode only (configs[4])
     dec = None
-    _phase("decode")
     if args.forward_steps > 0 and rank == 0:
+        _phase("decode")
         K, DB = 100, 64
         from hipmonocon.engine import p2_inverse
         dpred = {k: torch.from_numpy(v).cuda() for k, v in synth.make_decode_inputs(77, DB, H // 4, W // 4, topk=K).items()}
@@ -339,52 +400,48 @@ def main():
                        "algorithmic traffic is one read of the 23.6 MB heat map, so this is launch- and latency-bound"}
 
     if rank == 0:
-        conv, wg, oth = prof["conv"], prof["wgrad"], prof["other"]
-        conv_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-        wg_tf = wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0
+        rep = train_report(headline_mode, head)
         out = {
             "metric": "images/sec (384x1280) fwd+bwd",
-            "value": round(world * B * args.steps / elapsed, 2),
+            "value": rep["images_per_sec"],
             "unit": "images/sec",
             "n_gpus": world, "world_size": dist.get_world_size() if dist_on else 1,
             "collective_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist_on else None,
             "steps": args.steps, "warmup": max(args.warmup, 1),
-            "ms_per_step": round(ms_step, 3),
+            "ms_per_step": rep["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": MODES[headline_mode]["dtype"], "data": "synthetic",
             "config": {"workload": "full train step (train-mode fwd + targets + 10 losses + bwd + %sclip + AdamW + cyclic "
-                                   "schedule), DLA-34 + DLAUp + MonoCon heads, batch=%d/GPU, 3x%dx%d synthetic KITTI-shaped, "
-                                   "fp32 (BASELINE configs[2] shape at the reference's fp32 precision)"
-                                   % ("RCCL grad all-reduce + " if world > 1 else "", B, H, W),
-                       "global_batch": world * B, "parallelism": "dp%d" % world},
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "conv_mfma_kernel: %d launches per train step (forward convs + data gradients)" % conv["launches"],
-                "achieved": round(conv_tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(conv_tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "MB of HBM traffic per launch (PMC)", "traffic_source": traffic_src,
-                "algorithmic_mb_per_launch": round(conv.get("bytes", 0.0) / max(conv["launches"], 1) / 1e6, 1),
-                "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4),
-                "conv_ms_per_step": round(conv["ms"], 2),
-                "wgrad": {"kernel": "wgrad_mfma_kernel (+ split-K reduce): %d launches" % wg["launches"],
-                          "achieved": round(wg_tf, 2), "frac": round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                          "ms_per_step": round(wg["ms"], 2)},
-                "other_ms_per_step": round(oth["ms"], 2),
-                "step_gflop_per_image": round((conv["flops"] + wg["flops"]) / B / 1e9, 1),
-                "whole_step_tflops": round((conv["flops"] + wg["flops"]) / (ms_step * 1e-3) / 1e12, 2),
-            },
-            "workspace_gb": round(train_ws / 1e9, 2),
+                                   "schedule), DLA-34 + DLAUp + MonoCon heads, batch=%d/GPU, 3x%dx%d synthetic KITTI-shaped "
+                                   "(BASELINE configs[2] shape at the reference's fp32 precision: fp32 values, precision mode %s)"
+                                   % ("RCCL grad all-reduce + " if world > 1 else "", B, H, W, headline_mode),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "precision_mode": headline_mode},
+            "roofline": rep.get("roofline"),
+            "workspace_gb": rep.get("workspace_gb"),
         }
-        if fwd is not None:
-            out["forward_only"] = fwd
-        if emulated is not None:
-            out["fp32_emulated"] = emulated
-        if mixed is not None:
-            out["mixed_precision"] = mixed
+        if fwd_head is not None:
+            fr = forward_report(headline_mode, fwd_head)
+            fr["workload"] = "BASELINE configs[1]: eval forward only, batch=%d/GPU, fp32 values, precision mode %s" % (B, headline_mode)
+            fr["steps"] = args.forward_steps
+            out["forward_only"] = fr
+        for mode, (tleg, fleg) in extra.items():
+            blk = {"train": train_report(mode, tleg), "forward": forward_report(mode, fleg)}
+            if mode == "bf16":
+                blk["workload"] = ("BASELINE configs[2] as written: the same train step / eval forward with plain bf16 MFMA operands "
+                                   "(fp32 accumulation, activations, master weights, BN statistics, losses).  NOT a parity path: "
+                                   "on the conditioned fixtures its predictions sit ~1e-1 relative L2 and its flat gradient at "
+                                   "cosine 0.92-0.97 from the fp64 reference (scratch/bf16_probe.py, DESIGN.md 3a)")
+                out["mixed_precision"] = blk
+            elif mode == "fp32":
+                blk["workload"] = "the same train step / eval forward on the native fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+                out["native_fp32"] = blk
+            else:
+                blk["workload"] = "the same train step / eval forward with fp32 emulated on the bf16 matrix pipe (3-way operand split)"
+                out["fp32_emulated"] = blk
         if dec is not None:
             out["decode_only"] = dec
         if not args.no_cpu_baseline:
-            _phase("CPU baseline (oracle train step, B=2)")
+            _phase("CPU baseline (oracle: train step B=2, eval forward B=2 / B=32, decode B=64)")
             out["cpu_baseline"] = cpu_baseline(sd, H, W, args.cpu_seconds)
         _phase("done")
         print(json.dumps(out), flush=True)
