@@ -168,6 +168,15 @@ int mc_backward(mc_handle *h, const float *grad_losses, void *stream);
  * never does) records the id after its forward and compares before mc_backward; the Python binding
  * raises on a mismatch instead of back-propagating through the wrong activations. */
 int mc_train_generation(mc_handle *h, unsigned long long *generation);
+/* The dense heads on their own: replaces MonoConDenseHeads.forward_train(feat, data_dict)
+ * (model/dense_heads/monocon_heads.py:150-157: target generation, train-mode predictions of the nine heads --
+ * Conv3x3 + AttnBatchNorm2d on batch statistics + ReLU + Conv1x1 -- and the ten losses) for a caller that runs
+ * its own backbone / neck.  feat: (B,64,pad_h/4,pad_w/4) fp32 NCHW, the neck output; only the "head." keys need
+ * to be bound (and their "#grad" buffers).  mc_head_backward writes the head parameters' gradients and, when
+ * grad_feat is not NULL, d(sum_i grad_losses[i] * loss_i)/d feat as (B,64,pad_h/4,pad_w/4) NCHW. */
+int mc_head_forward_train(mc_handle *h, const float *feat, const mc_labels *labels, int B, int pad_h, int pad_w,
+                          int max_objs, float *const preds[MC_NUM_PREDS], float *losses, void *stream);
+int mc_head_backward(mc_handle *h, const float *grad_losses, float *grad_feat, void *stream);
 /* Debugging aid: activation (which=0) or gradient (which=1) of node `node` of the train plan as NCHW. */
 int mc_train_debug_node(mc_handle *h, int node, int which, float *out_nchw, int dims[4], void *stream);
 

@@ -76,6 +76,11 @@ struct TrainState {
     float *losses = nullptr;
     const float *grad_losses = nullptr;
     int pad_h = 0, pad_w = 0, max_objs = 30;
+    // head-only plan (mc_head_forward_train): the neck output comes in as an external NCHW tensor, its gradient
+    // goes out the same way
+    bool head_only = false;
+    const float *feat_ext = nullptr;
+    float *gfeat_ext = nullptr;
     // plan-owned
     mc_targets targets{};
     float *dpred[10] = {nullptr};
@@ -403,12 +408,23 @@ struct TB {   // train plan builder
 }  // namespace
 
 // ------------------------------------------------------------------------------------ build
-static TrainState *build_train(mc_handle *h, int B, int H, int W) {
+static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only = false) {
     std::unique_ptr<TrainState, void (*)(TrainState *)> tsp(new TrainState(), train_free);
     TrainState *ts = tsp.get();
-    ts->B = B; ts->H = H; ts->W = W; ts->bind_gen = h->bind_gen;
+    ts->B = B; ts->H = H; ts->W = W; ts->bind_gen = h->bind_gen; ts->head_only = head_only;
     TB b{h, ts};
     const int fh = H / 4, fw = W / 4, HW = fh * fw;
+    int feat = -1;
+    if (head_only) {
+        // the heads on their own (MonoConDenseHeads.forward_train, monocon_heads.py:150-157): the neck output is an
+        // external NCHW tensor, copied into the plan's NHWC node; its gradient is copied out after the backward
+        feat = b.node(B, fh, fw, 64);
+        float *fp = ts->nodes[feat].t.p;
+        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
+            HIPCHK(hh, launch_nchw_to_nhwc(ts->feat_ext, B, 64, fh, fw, fp, st));
+            return 0;
+        });
+    } else {
 
     // ---- stem (raw conv -> batch stats -> normalise + ReLU)
     Rec stem;
@@ -454,7 +470,8 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
             layers[j + t] = b.conv_bn(b.L(pre + "node_" + tsn + ".conv"), {layers[j + t - 1], u}, -1, true);
         }
     }
-    const int feat = layers[3];
+    feat = layers[3];
+    }   // !head_only
 
     // ---- heads
     const int CP = NUM_HEADS * HEAD_CH, LD = 80;
@@ -679,6 +696,13 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
             ts->bwd_side.resize(ts->bwd.size(), 1);
         }
     }
+    if (head_only) {
+        const float *gp = ts->nodes[feat].g;
+        ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
+            if (ts->gfeat_ext) HIPCHK(hh, launch_nhwc_to_nchw(gp, B, 64, fh, fw, ts->gfeat_ext, st));
+            return 0;
+        });
+    }
     if (!ts->ok) return nullptr;
     ts->bwd_side.resize(ts->bwd.size(), 0);
     if (const char *e = std::getenv("MONOCON_HIP_DUAL_STREAM")) ts->dual = std::atoi(e) != 0;
@@ -698,32 +722,34 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W) {
 // ====================================================================================== C ABI
 extern "C" {
 
-int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, int B, int H, int W, int max_objs,
-                     float *const preds[MC_NUM_PREDS], float *losses, void *stream) {
+static int forward_train_impl(mc_handle *h, const float *img, const mc_labels *labels, int B, int H, int W, int max_objs,
+                              float *const preds[MC_NUM_PREDS], float *losses, void *stream, bool head_only) {
     if (!h) return -1;
-    if (!img || !labels || !preds || !losses) return fail(h, "mc_forward_train: null argument");
-    if (B < 2 || B > 64) return fail(h, "mc_forward_train: batch %d (2..64 per GPU; BatchNorm over the attention vector needs >= 2)", B);
-    if (H < 32 || W < 32 || (H % 32) || (W % 32)) return fail(h, "mc_forward_train: H, W must be multiples of 32");
-    if (max_objs != 30) return fail(h, "mc_forward_train: max_objs=%d (the MonoCon configuration uses 30)", max_objs);
-    if (h->packed_groups != 7) return fail(h, "mc_forward_train: bind all parameters and call mc_pack_params first");
+    const char *fn = head_only ? "mc_head_forward_train" : "mc_forward_train";
+    if (!img || !labels || !preds || !losses) return fail(h, "%s: null argument", fn);
+    if (B < 2 || B > 64) return fail(h, "%s: batch %d (2..64 per GPU; BatchNorm over the attention vector needs >= 2)", fn, B);
+    if (H < 32 || W < 32 || (H % 32) || (W % 32)) return fail(h, "%s: H, W must be multiples of 32", fn);
+    if (max_objs != 30) return fail(h, "%s: max_objs=%d (the MonoCon configuration uses 30)", fn, max_objs);
+    if (head_only ? !(h->packed_groups & 4) : h->packed_groups != 7)
+        return fail(h, "%s: bind all %sparameters and call mc_pack_params first", fn, head_only ? "head. " : "");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     TrainState *ts = h->train;
-    if (!ts || ts->B != B || ts->H != H || ts->W != W || ts->bind_gen != h->bind_gen) {
+    if (!ts || ts->B != B || ts->H != H || ts->W != W || ts->bind_gen != h->bind_gen || ts->head_only != head_only) {
         if (ts && h->train_free) h->train_free(ts);
         h->train = nullptr;
         h->tgt_arena = h->dp_arena = nullptr;
         h->train_bytes = 0;
         h->tgt_arena_bytes = h->dp_arena_bytes = 0;
-        ts = build_train(h, B, H, W);
+        ts = build_train(h, B, H, W, head_only);
         if (!ts) return -1;
         h->train = ts;
         h->train_bytes = ts->bytes;
         h->train_free = train_free;
     }
-    ts->img = img; ts->labels = *labels; ts->losses = losses; ts->pad_h = H; ts->pad_w = W; ts->max_objs = max_objs;
+    ts->img = img; ts->feat_ext = img; ts->labels = *labels; ts->losses = losses; ts->pad_h = H; ts->pad_w = W; ts->max_objs = max_objs;
     for (int i = 0; i < MC_NUM_PREDS; ++i) {
-        if (!preds[i]) return fail(h, "mc_forward_train: preds[%d] is NULL", i);
+        if (!preds[i]) return fail(h, "%s: preds[%d] is NULL", fn, i);
         ts->preds[i] = preds[i];
     }
     // refresh derived weights: forward panels (no BN folding in train mode), dgrad panels
@@ -741,6 +767,16 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
     for (auto &f : ts->fwd)
         if (f(h, st)) return -1;
     return 0;
+}
+
+int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, int B, int H, int W, int max_objs,
+                     float *const preds[MC_NUM_PREDS], float *losses, void *stream) {
+    return forward_train_impl(h, img, labels, B, H, W, max_objs, preds, losses, stream, false);
+}
+
+int mc_head_forward_train(mc_handle *h, const float *feat, const mc_labels *labels, int B, int pad_h, int pad_w, int max_objs,
+                          float *const preds[MC_NUM_PREDS], float *losses, void *stream) {
+    return forward_train_impl(h, feat, labels, B, pad_h, pad_w, max_objs, preds, losses, stream, true);
 }
 
 int mc_train_generation(mc_handle *h, unsigned long long *out) {
@@ -792,6 +828,14 @@ int mc_backward(mc_handle *h, const float *grad_losses, void *stream) {
         HIPCHK(h, hipStreamWaitEvent(st, ts->side_done, 0));
     }
     return 0;
+}
+
+int mc_head_backward(mc_handle *h, const float *grad_losses, float *grad_feat, void *stream) {
+    if (!h) return -1;
+    TrainState *ts = h->train;
+    if (!ts || !ts->head_only || !ts->feat_ext) return fail(h, "mc_head_backward: call mc_head_forward_train first");
+    ts->gfeat_ext = grad_feat;
+    return mc_backward(h, grad_losses, stream);
 }
 
 int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], double bytes[3], int launches[3],

@@ -14,7 +14,7 @@ NUM_PREDS = 10
 
 EXPORTS = (
     "mc_create", "mc_destroy", "mc_last_error", "mc_version", "mc_bind_params", "mc_pack_params",
-    "mc_forward_infer", "mc_backbone_forward", "mc_neck_forward", "mc_head_forward", "mc_decode", "mc_make_targets", "mc_losses", "mc_losses_backward", "mc_losses_backward_pred", "mc_forward_train", "mc_backward", "mc_train_generation", "mc_train_debug_node", "mc_optim_bind", "mc_clip_adamw_step", "mc_op_conv", "mc_op_conv_wgrad", "mc_op_conv_dgrad", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
+    "mc_forward_infer", "mc_backbone_forward", "mc_neck_forward", "mc_head_forward", "mc_decode", "mc_make_targets", "mc_losses", "mc_losses_backward", "mc_losses_backward_pred", "mc_forward_train", "mc_backward", "mc_train_generation", "mc_head_forward_train", "mc_head_backward", "mc_train_debug_node", "mc_optim_bind", "mc_clip_adamw_step", "mc_op_conv", "mc_op_conv_wgrad", "mc_op_conv_dgrad", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
     "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_forward_cost",
     "mc_preprocess", "mc_profile_forward", "mc_profile_train", "mc_set_precision", "mc_set_conv_cfg", "mc_bench_conv", "mc_bench_mfma_peak",
 )
@@ -76,6 +76,8 @@ def load():
     lib.mc_losses_backward_pred.argtypes = lib.mc_losses_backward.argtypes
     lib.mc_forward_train.argtypes = [vp, vp, C.POINTER(Labels), i, i, i, i, C.POINTER(vp), vp, vp]
     lib.mc_backward.argtypes = [vp, vp, vp]
+    lib.mc_head_forward_train.argtypes = [vp, vp, C.POINTER(Labels), i, i, i, i, C.POINTER(vp), vp, vp]
+    lib.mc_head_backward.argtypes = [vp, vp, vp, vp]
     lib.mc_train_generation.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     lib.mc_train_debug_node.argtypes = [vp, i, i, vp, C.POINTER(i), vp]
     d = C.c_double

@@ -161,3 +161,97 @@ def forward_train(detector, data_dict):
     pred_dict = dict(zip(PRED_KEYS, preds))
     loss_dict = {k: losses[i] for i, k in enumerate(netspec.LOSS_KEYS)}
     return pred_dict, loss_dict
+
+
+# ----------------------------------------------------------------------------- heads on their own
+class _HeadBinding:
+    """gradient buffers of a stand-alone MonoConDenseHeads, bound as 'head.<key>#grad'"""
+
+    def __init__(self, heads):
+        self.named = [("head." + n, p) for n, p in heads.named_parameters()]
+        self.flat = _dist.FlatGrads(self.named, self.named[0][1].device)
+        self.grads = self.flat.views
+        self.buffers = [b for _, b in heads.named_buffers()]
+        self.sig = tuple(p.data_ptr() for _, p in self.named)
+
+    def state(self, heads):
+        st = {"head." + k: v for k, v in heads.state_dict(keep_vars=True).items()}
+        for n, g in self.grads.items():
+            st[n + "#grad"] = g
+        return st
+
+
+class _HipHeadTrainStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tb, eng, feat, label, pad_hw, max_objs, *params):
+        B, _, fh, fw = feat.shape
+        preds = [torch.empty((B, c, fh, fw), dtype=torch.float32, device=feat.device) for c in PRED_CH]
+        losses = torch.zeros(10, dtype=torch.float32, device=feat.device)
+        lab = _lib.Labels()
+        keep = []
+        for f in LABEL_FIELDS:
+            t = label[f]
+            if not (t.is_cuda and t.dtype == torch.float32):
+                raise _lib.MonoconHipError("label.%s must be a float32 HIP tensor (collate_fn contract)" % f)
+            t = t.contiguous()
+            keep.append(t)
+            setattr(lab, f, t.data_ptr())
+        arr = (C.c_void_p * _lib.NUM_PREDS)(*[p.data_ptr() for p in preds])
+        with torch.cuda.device(feat.device):
+            rc = eng.lib.mc_head_forward_train(eng.h, C.c_void_p(feat.data_ptr()), C.byref(lab), B, int(pad_hw[0]), int(pad_hw[1]),
+                                               int(max_objs), arr, C.c_void_p(losses.data_ptr()),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(eng.h, rc, "mc_head_forward_train")
+        gen = C.c_ulonglong(0)
+        _lib.check(eng.h, eng.lib.mc_train_generation(eng.h, C.byref(gen)), "mc_train_generation")
+        ctx.generation = gen.value
+        torch.autograd.graph.increment_version(tb.buffers)
+        ctx.eng, ctx.tb, ctx.keep, ctx.feat_shape = eng, tb, (feat, keep, preds), feat.shape
+        ctx.mark_non_differentiable(*preds)
+        return (losses, *preds)
+
+    @staticmethod
+    def backward(ctx, grad_losses, *unused):
+        eng, tb = ctx.eng, ctx.tb
+        gen = C.c_ulonglong(0)
+        _lib.check(eng.h, eng.lib.mc_train_generation(eng.h, C.byref(gen)), "mc_train_generation")
+        if gen.value != ctx.generation:
+            raise _lib.MonoconHipError("backward of head forward #%d, but the handle's saved activations belong to forward "
+                                       "#%d: call backward() before the next forward_train" % (ctx.generation, gen.value))
+        g = grad_losses.contiguous().float()
+        gfeat = torch.empty(ctx.feat_shape, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(g.device):
+            rc = eng.lib.mc_head_backward(eng.h, C.c_void_p(g.data_ptr()), C.c_void_p(gfeat.data_ptr() if gfeat is not None else None),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(eng.h, rc, "mc_head_backward")
+        out = []
+        for n, p in tb.named:
+            gb = tb.grads[n]
+            out.append(gb.detach() if p.grad is None else gb.clone())
+        return (None, None, gfeat, None, None, None, *out)
+
+
+def head_forward_train(heads, feat, data_dict):
+    """``MonoConDenseHeads.forward_train(feat, data_dict)`` of the reference (monocon_heads.py:150-157): targets,
+    train-mode predictions and the ten losses from a neck output, autograd-connected to ``feat`` and to the head's
+    parameters.  (Inside MonoConDetector the whole network runs as one plan; this is the stand-alone entry.)"""
+    if not feat.is_cuda:
+        raise _lib.MonoconHipError("feat must live on a HIP device; libmonocon_hip has no CPU path")
+    label = data_dict["label"]
+    pad_hw = data_dict["img_metas"]["pad_shape"][0]
+    if tuple(feat.shape[1:]) != (64, int(pad_hw[0]) // 4, int(pad_hw[1]) // 4):
+        raise _lib.MonoconHipError("feat %s does not match pad_shape %s (expected (B,64,H/4,W/4))" % (tuple(feat.shape), tuple(pad_hw)))
+    _require_objects(heads, label, pad_hw)
+    tb = getattr(heads, "_train_binding", None)
+    sig = tuple(p.data_ptr() for _, p in heads.named_parameters())
+    if tb is None or tb.sig != sig:
+        tb = _HeadBinding(heads)
+        object.__setattr__(heads, "_train_binding", tb)
+    for n, p in tb.named:
+        if p.grad is not None and p.grad.data_ptr() == tb.grads[n].data_ptr():
+            p.grad = p.grad.clone()
+    eng = heads._rt.get(tb.state(heads))
+    params = [p for _, p in tb.named]
+    out = _HipHeadTrainStep.apply(tb, eng, feat.contiguous().float(), label, pad_hw, heads.max_objs, *params)
+    losses, preds = out[0], out[1:]
+    return dict(zip(PRED_KEYS, preds)), {k: losses[i] for i, k in enumerate(netspec.LOSS_KEYS)}

@@ -97,8 +97,12 @@ class MonoConDenseHeads(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward_train(self, feat: torch.Tensor, data_dict: Dict[str, Any]):
-        raise NotImplementedError("the training pass is driven by MonoConDetector (fused HIP plan); "
-                                  "stand-alone head.forward_train is not available")
+        """reference monocon_heads.py:150-157: ``(pred_dict, loss_dict)`` from a neck output -- target generation,
+        train-mode predictions (AttnBatchNorm2d on batch statistics, running buffers updated) and the ten losses in
+        one HIP plan (``mc_head_forward_train``); ``sum(loss_dict.values()).backward()`` fills the head parameters'
+        ``.grad`` and the gradient of ``feat`` (``mc_head_backward``)."""
+        from hipmonocon.train import head_forward_train
+        return head_forward_train(self, feat, data_dict)
 
     def forward_test(self, feat: torch.Tensor) -> Dict[str, torch.Tensor]:
         return self._get_predictions(feat)

@@ -189,6 +189,53 @@ def test_heads_get_losses_standalone_with_autograd(golden_sd):
         assert rel_err(cl[k].grad.cpu(), leaf[k].grad) < 2e-4, (k, rel_err(cl[k].grad.cpu(), leaf[k].grad))
 
 
+def test_heads_forward_train_standalone(cond_sd):
+    """MonoConDenseHeads.forward_train(feat, data_dict) (reference monocon_heads.py:150-157) on its own: the ten
+    losses, the gradient with respect to ``feat`` and the gradients of all head parameters vs torch autograd through
+    the oracle's head (fp64), and the AttnBN running buffers ticked as the reference's."""
+    from oracle import monocon_oracle as O
+    from model import MonoConDenseHeads
+    B, H, W = 4, 64, 128
+    batch = synth.make_conditioned_batch(812, B, H, W)
+    feat = torch.from_numpy(synth.normalish(5, "feat", (B, 64, H // 4, W // 4)).astype(np.float32)).abs()   # post-ReLU-like
+    # oracle in float64: head only
+    sd64 = {k: (v.double().clone() if v.dtype == torch.float32 else v.clone()) for k, v in cond_sd.items()}
+    for k, v in sd64.items():
+        if k.startswith("head.") and v.dtype == torch.float64 and "running" not in k:
+            v.requires_grad_(True)
+    f64 = feat.double().clone().requires_grad_(True)
+    cx = O._Ctx(sd64, True)
+    preds = O.head_predictions(cx, f64)
+    T = O.make_targets(batch["label"], (H, W), tuple(f64.shape))
+    L = O.losses(preds, T)
+    sum(L.values()).backward()
+    heads = MonoConDenseHeads(test_config=None)
+    heads.load_state_dict({k[5:]: v for k, v in cond_sd.items() if k.startswith("head.")}, strict=True)
+    heads = heads.cuda().train()
+    fc = feat.clone().cuda().requires_grad_(True)
+    data = {"label": {k: v.cuda() for k, v in batch["label"].items()}, "img_metas": batch["img_metas"]}
+    pd, ld = heads.forward_train(fc, data)
+    assert list(ld.keys()) == list(netspec.LOSS_KEYS) and set(pd) == {k for k, _ in netspec.PRED_KEYS}
+    for k, v in ld.items():
+        assert abs(float(v.detach()) - float(L[k])) <= 1e-4 * abs(float(L[k])) + 1e-7, (k, float(v.detach()), float(L[k]))
+    for k, v in pd.items():
+        assert rel_err(v.detach().cpu(), preds[k].detach()) < 1e-4, k
+    sum(ld.values()).backward()
+    e = float((fc.grad.cpu().double() - f64.grad).norm() / f64.grad.norm())
+    assert e < 1e-3, e
+    for n, p in heads.named_parameters():
+        ref = sd64["head." + n].grad
+        assert p.grad is not None and ref is not None, n
+        scale = max(float(ref.norm()), 1e-12)
+        assert float((p.grad.cpu().double() - ref).norm()) / scale < 2e-3, (n, float((p.grad.cpu().double() - ref).norm()) / scale)
+    sdh = heads.state_dict()
+    for k, v in cx.new_buffers.items():
+        if k.startswith("head.") and not k.endswith("num_batches_tracked"):
+            assert rel_err(sdh[k[5:]].cpu(), v) < 1e-4, k
+    with pytest.raises(Exception):
+        heads.forward_train(fc[:, :32], data)
+
+
 # ------------------------------------------------------------------------------------- guards
 def test_backward_of_a_stale_forward_raises(golden_sd):
     from hipmonocon.lib import MonoconHipError
