@@ -35,12 +35,20 @@ struct WgB16Cfg {
     static constexpr int PAD = KS / 2;
     static constexpr int IH = 3 + KS, IW = 7 + KS;              // 6 x 10 (3x3) or 4 x 8 (1x1)
     static constexpr int XROW = KS == 3 ? 32 : 16;              // bytes per staged halo row (16 / 8 pixels)
-    static constexpr int XCH = IH * XROW + 16;                  // bytes per channel (+16: spreads the b128 reads over banks)
-    static constexpr int DCH = 4 * 16 + 16;                     // bytes per dY channel
+    // Bytes per channel row.  The staging writes of a wave go to 16 channel groups x 4 pixel pairs: with 16-byte aligned
+    // rows the 4-channel stride is a multiple of 16 banks whatever the padding, i.e. 4 distinct banks for 16 lanes (a
+    // 4-way conflict on every ds_write_b32; PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.75).  Every group of 16
+    // channels is therefore skewed by another 16 bytes (lds_skew): the 16 channel groups land on 16 distinct multiples
+    // of 4 banks and the pixel pairs fill the gaps -- conflict-free writes; the fragment reads (8 lanes = 8 consecutive
+    // channels, same skew) keep their disjoint banks.  Rows grow by the largest skew (48 bytes).
+    static constexpr int XCH = IH * XROW + 48;                  // 240 (3x3) / 112 (1x1)
+    static constexpr int DCH = 4 * 16 + 48;                     // bytes per dY channel: 112
     static constexpr int X_PLANE = PB * CB * XCH, D_PLANE = PB * NB * DCH;   // one bf16 piece of each tile
     static constexpr int X_BYTES = SPL * X_PLANE, D_BYTES = SPL * D_PLANE;
     static constexpr size_t LDS_BYTES = X_BYTES + D_BYTES;
 };
+
+__device__ __forceinline__ int lds_skew(int channel) { return ((channel >> 4) & 3) * 16; }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     bf16x2 v;
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
         const int iy = item / XPAIRS, ix = (item % XPAIRS) * 2;
         x_ix[i] = (xc_ok && e < XP) ? ix - PAD : DEAD;
         x_stat[i] = (((iy - PAD) * a.Win + ix - PAD) * Cs + cs0 + xc4 * 4) * 4;
-        x_dst[i] = (xc4 * 4) * XCH + iy * XROW + ix * 2;
+        x_dst[i] = (xc4 * 4) * XCH + lds_skew(xc4 * 4) + iy * XROW + ix * 2;
     }
     int d_stat[NID], d_mx[NID], d_dst[NID];
 #pragma unroll
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
         const int my = item / 4, mx = (item % 4) * 2;
         d_mx[i] = (dn_ok && e < DP) ? mx : -DEAD;
         d_stat[i] = ((my * a.Wout + mx) * a.dy_ld + n0 + dn4 * 4) * 4;
-        d_dst[i] = (dn4 * 4) * DCH + my * 16 + mx * 2;
+        d_dst[i] = (dn4 * 4) * DCH + lds_skew(dn4 * 4) + my * 16 + mx * 2;
     }
 
     f32x4 xv[PB][NIX][2], dv[PB][NID][2];
@@ -162,8 +170,8 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
             if (NT * (i + 1) <= DP || tid + NT * i < DP) put(dyt + p * NB * DCH + d_dst[i], DPL, dv[p][i][0], dv[p][i][1], DCH);
     };
 
-    const unsigned char *a_base = dyt + (wn * 32 + li) * DCH + g * 16;
-    const unsigned char *b_base = xt + (wc * 32 + li) * XCH + g * XROW;
+    const unsigned char *a_base = dyt + (wn * 32 + li) * DCH + lds_skew(wn * 32 + li) + g * 16;
+    const unsigned char *b_base = xt + (wc * 32 + li) * XCH + lds_skew(wc * 32 + li) + g * XROW;
 
     if (g_begin < g_end) {
 #pragma unroll

@@ -10,7 +10,7 @@ def short(n): return re.sub(r"\(.*", "", n).replace("void ", "")
 # ---- kernel trace stats (rocprofv3 --kernel-trace --stats)
 rows = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
 with open(os.path.join(dst, tag + "_kernel_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --forward-steps 2 --no-cpu-baseline --no-extra-modes (B=32, 384x1280, fp32)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --forward-steps 2 --no-cpu-baseline --no-extra-modes (B=32, 384x1280; headline precision mode of bench.py)\n")
     f.write("# trace = 1 warm-up + 2 timed + 2 event-profiled train steps, then 3 warm-up + 2 timed + 3 event-profiled eval forwards\n")
     f.write("# (plus the one-off plan-build autotuning launches unless MONOCON_HIP_TUNE_CACHE pointed at a warm cache)\n")
     f.write("%-70s %7s %14s %12s %7s\n" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
