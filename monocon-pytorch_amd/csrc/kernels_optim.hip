@@ -2,9 +2,16 @@
 // Replaces torch.nn.utils.clip_grad_norm_(35, L2) + torch.optim.AdamW.step of the reference's
 // train loop (engine/monocon_engine.py:94-102): two launches per step instead of several
 // hundred per-tensor kernels; 16 B/param of traffic (p, g, m, v read; p, m, v written).
+#include <stdint.h>
+#include "conv_mfma.h"
 #include "train.h"
 
 namespace mc {
+
+// Every tensor of the table starts 16-byte aligned (FlatGrads pads each gradient to a multiple of 4 floats, torch
+// allocations are 256-byte aligned) and every chunk starts at a multiple of 65536 elements, so a chunk is walked as
+// float4 with a scalar tail: the passes run at the HBM roof instead of at the dword-load issue rate.
+__device__ __forceinline__ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 __global__ __launch_bounds__(256) void gradnorm_partial_kernel(const OptTensor *tab, const OptChunk *chunks, int nchunks,
                                                                float *partial) {
@@ -12,7 +19,17 @@ __global__ __launch_bounds__(256) void gradnorm_partial_kernel(const OptTensor *
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const OptChunk ck = chunks[c];
         const float *g = tab[ck.tensor].g + ck.begin;
-        for (int i = threadIdx.x; i < ck.count; i += 256) s += g[i] * g[i];
+        int i0 = 0;
+        if (aligned16(g)) {
+            const int n4 = ck.count >> 2;
+            const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+            for (int i = threadIdx.x; i < n4; i += 256) {
+                const f32x4 v = g4[i];
+                s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            }
+            i0 = n4 << 2;
+        }
+        for (int i = i0 + threadIdx.x; i < ck.count; i += 256) s += g[i] * g[i];
     }
     __shared__ float red[4];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -33,22 +50,42 @@ __global__ void gradnorm_final_kernel(const float *partial, int n, float max_nor
     }
 }
 
+__device__ __forceinline__ void adamw_one(float &p, float g, float &m, float &v, float coef, const AdamHyper &hp) {
+    g *= coef;
+    p *= hp.decay;                               // p *= 1 - lr*wd   (decoupled weight decay)
+    m = m * hp.beta1 + g * hp.one_minus_beta1;
+    v = v * hp.beta2 + g * g * hp.one_minus_beta2;
+    const float denom = sqrtf(v) / hp.sqrt_bc2 + hp.eps;
+    p -= hp.step_size * (m / denom);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(const OptTensor *tab, const OptChunk *chunks, int nchunks,
                                                     const float *normcoef, AdamHyper hp) {
     const float coef = normcoef[1];
     for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const OptChunk ck = chunks[c];
         const OptTensor t = tab[ck.tensor];
-        for (int i = threadIdx.x; i < ck.count; i += 256) {
-            const int j = ck.begin + i;
-            const float g = t.g[j] * coef;
-            float p = t.p[j] * hp.decay;                 // p *= 1 - lr*wd   (decoupled weight decay)
-            const float m = t.m[j] * hp.beta1 + g * hp.one_minus_beta1;
-            const float v = t.v[j] * hp.beta2 + g * g * hp.one_minus_beta2;
-            const float denom = sqrtf(v) / hp.sqrt_bc2 + hp.eps;
-            p -= hp.step_size * (m / denom);
-            t.p[j] = p; t.m[j] = m; t.v[j] = v;
+        float *p = t.p + ck.begin, *m = t.m + ck.begin, *v = t.v + ck.begin;
+        const float *g = t.g + ck.begin;
+        int i0 = 0;
+        if (aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
+            const int n4 = ck.count >> 2;
+            for (int i = threadIdx.x; i < n4; i += 256) {
+                f32x4 p4 = reinterpret_cast<f32x4 *>(p)[i], m4 = reinterpret_cast<f32x4 *>(m)[i], v4 = reinterpret_cast<f32x4 *>(v)[i];
+                const f32x4 g4 = reinterpret_cast<const f32x4 *>(g)[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float pj = p4[j], mj = m4[j], vj = v4[j];
+                    adamw_one(pj, g4[j], mj, vj, coef, hp);
+                    p4[j] = pj; m4[j] = mj; v4[j] = vj;
+                }
+                reinterpret_cast<f32x4 *>(p)[i] = p4;
+                reinterpret_cast<f32x4 *>(m)[i] = m4;
+                reinterpret_cast<f32x4 *>(v)[i] = v4;
+            }
+            i0 = n4 << 2;
         }
+        for (int i = i0 + threadIdx.x; i < ck.count; i += 256) adamw_one(p[i], g[i], m[i], v[i], coef, hp);
     }
 }
 
