@@ -551,19 +551,27 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
     const bool has_neck = h->bound.count("neck.ida_0.proj_1.conv.weight") != 0;
     const bool has_head = h->bound.count("head.heatmap_head.0.weight") != 0;
     if (!has_bb && !has_neck && !has_head) return fail(h, "mc_pack_params: no backbone./neck./head. parameters bound");
+    const bool rebuild = h->pack_tab_gen != h->bind_gen || h->pack_tab_prec != h->prec;
+    if (rebuild) { h->fwd_pack.clear(); h->folds.clear(); }
+    auto add_fwd = [&](const float *w, int Cout, int Cin, int ks, float *dst32, void *dst16, int CinPanel, int CoutP, int n_off) {
+        mc::PackJobDesc j{};
+        j.w = w; j.dst32 = dst32; j.dst16 = (h->prec >= 1 && CinPanel % 8 == 0) ? dst16 : nullptr;
+        j.kind = 0; j.Cout = Cout; j.Cin = Cin; j.k = ks; j.CinTotal = CinPanel; j.CoutP = CoutP; j.n_off = n_off; j.c_off = 0;
+        j.nsplit = h->prec == 2 ? 3 : 1; j.cls = -1;
+        h->fwd_pack.add(j);
+    };
     for (auto &kv : h->convs) {
+        if (!rebuild) break;
         ConvLayer &L = kv.second;
         const bool is_bb = L.conv.compare(0, 9, "backbone.") == 0;
         if ((is_bb && !has_bb) || (!is_bb && !has_neck)) continue;
         NEEDP(w, L.conv + ".weight", (int64_t)L.cout * L.cin * L.ks * L.ks);
-        HIPCHK(h, launch_pack_conv_w(w, L.cout, L.cin, L.ks, L.wpk, L.cin, L.coutp, 0, 0, st));
-        if (h->prec >= 1 && L.cin % 8 == 0)
-            HIPCHK(h, launch_pack_conv_w_bf16(w, L.cout, L.cin, L.ks, L.wpk16, L.cin, L.coutp, 0, 0, h->prec == 2 ? 3 : 1, st));
+        add_fwd(w, L.cout, L.cin, L.ks, L.wpk, L.wpk16, L.cin, L.coutp, 0);
         NEEDP(g, L.bn + ".weight", L.cout);
         NEEDP(b, L.bn + ".bias", L.cout);
         NEEDP(rm, L.bn + ".running_mean", L.cout);
         NEEDP(rv, L.bn + ".running_var", L.cout);
-        HIPCHK(h, launch_fold_bn(g, b, rm, rv, 1e-5f, L.cout, L.scale, L.shift, st));
+        h->folds.add(mc::FoldJobDesc{g, b, rm, rv, 1e-5f, L.cout, L.scale, L.shift});
     }
     for (auto &kv : h->deconvs) {
         if (!has_neck) break;
@@ -577,25 +585,24 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         NEEDP(b, "backbone.base_layer.1.bias", 16);
         NEEDP(rm, "backbone.base_layer.1.running_mean", 16);
         NEEDP(rv, "backbone.base_layer.1.running_var", 16);
-        HIPCHK(h, launch_fold_bn(g, b, rm, rv, 1e-5f, 16, h->stem_scale, h->stem_shift, st));
+        if (rebuild) h->folds.add(mc::FoldJobDesc{g, b, rm, rv, 1e-5f, 16, h->stem_scale, h->stem_shift});
     }
     // heads
     const HeadRow *rows = head_rows();
     const int *rb = head_row_begin();
     (void)rows;
     CopyBatch headcb;      // the 1x1 head weights / biases -> the fused [65][64] / [65] tables, one launch
+    CopyBatch headcb2;     // 3x3 head biases and AttnBN running means -> their concatenated tables
     for (int hd = 0; hd < NUM_HEADS && has_head; ++hd) {
         const std::string pre = std::string("head.") + HEAD_NAMES[hd];
         NEEDP(w3, pre + ".0.weight", 64 * 64 * 9);
         NEEDP(b3, pre + ".0.bias", 64);
-        HIPCHK(h, launch_pack_conv_w(w3, 64, 64, 3, h->head3.wpk, 64, h->head3.coutp, hd * HEAD_CH, 0, st));
-        if (h->prec >= 1)
-            HIPCHK(h, launch_pack_conv_w_bf16(w3, 64, 64, 3, h->head3.wpk16, 64, h->head3.coutp, hd * HEAD_CH, 0, h->prec == 2 ? 3 : 1, st));
-        HIPCHK(h, launch_copy(b3, h->head_bias + hd * HEAD_CH, 64, st));
+        if (rebuild) add_fwd(w3, 64, 64, 3, h->head3.wpk, h->head3.wpk16, 64, h->head3.coutp, hd * HEAD_CH);
+        if (!headcb2.add(b3, h->head_bias + hd * HEAD_CH, 64)) return fail(h, "mc_pack_params: head copy table overflow");
         const std::string an = pre + ".1";
         NEEDP(rm, an + ".running_mean", 64);
         NEEDP(rv, an + ".running_var", 64);
-        HIPCHK(h, launch_copy(rm, h->head_rm + hd * HEAD_CH, 64, st));
+        if (!headcb2.add(rm, h->head_rm + hd * HEAD_CH, 64)) return fail(h, "mc_pack_params: head copy table overflow");
         NEEDP(wg, an + ".weight_", 640);
         NEEDP(wb, an + ".bias_", 640);
         NEEDP(aw, an + ".attn_weights.attention.0.weight", 640);
@@ -603,8 +610,7 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         NEEDP(ab, an + ".attn_weights.attention.1.bias", 10);
         NEEDP(arm, an + ".attn_weights.attention.1.running_mean", 10);
         NEEDP(arv, an + ".attn_weights.attention.1.running_var", 10);
-        HIPCHK(h, launch_fold_bn(ag, ab, arm, arv, 1e-5f, 10, h->att_scale + hd * NUM_AFFINE,
-                                 h->att_shift + hd * NUM_AFFINE, st));
+        if (rebuild) h->folds.add(mc::FoldJobDesc{ag, ab, arm, arv, 1e-5f, 10, h->att_scale + hd * NUM_AFFINE, h->att_shift + hd * NUM_AFFINE});
         h->hap.att_w[hd] = aw;
         h->hap.att_scale[hd] = h->att_scale + hd * NUM_AFFINE;
         h->hap.att_shift[hd] = h->att_shift + hd * NUM_AFFINE;
@@ -629,7 +635,11 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
                 return fail(h, "mc_pack_params: head copy table overflow");
         }
     }
+    if (rebuild) { h->pack_tab_gen = h->bind_gen; h->pack_tab_prec = h->prec; }
+    HIPCHK(h, h->fwd_pack.launch(st));     // every forward panel (fp32 + bf16 pieces) in one grid
+    HIPCHK(h, h->folds.launch(st));        // every eval-mode BatchNorm fold in one grid
     HIPCHK(h, launch_copy_batch(headcb, st));
+    HIPCHK(h, launch_copy_batch(headcb2, st));
     // [65][64] -> [64][65]: the second head pass reads one input channel against all rows of a head
     if (has_head) HIPCHK(h, launch_nchw_to_nhwc(h->head_w1, 1, NUM_OUT_ROWS, 1, HEAD_CH, h->head_w1t, st));
 #undef NEEDP

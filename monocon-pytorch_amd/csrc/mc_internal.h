@@ -114,6 +114,12 @@ struct mc_handle {
     void (*train_free)(TrainState *) = nullptr;
     unsigned long long bind_gen = 0;
     bool pack_clean = false;   // packed panels match the bound parameters (cleared by bind / optimizer step)
+    // job tables of mc_pack_params (forward panels of all layers, BatchNorm folds): rebuilt when the binding or the
+    // precision mode changes, launched as one grid each
+    mc::PackBatch fwd_pack;
+    mc::FoldBatch folds;
+    unsigned long long pack_tab_gen = ~0ull;
+    int pack_tab_prec = -1;
     // train plan: all target tensors / all regression-gradient maps live in one arena each, so the
     // per-step zero fill is one memset instead of 17 + 8 (mc_make_targets / mc_losses_backward)
     void *tgt_arena = nullptr, *dp_arena = nullptr;

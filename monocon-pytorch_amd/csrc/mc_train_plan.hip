@@ -68,6 +68,7 @@ struct TrainState {
     hipEvent_t side_done = nullptr;
     bool dual = true;
     std::vector<PackJob> packs;
+    mc::PackBatch pack_batch;        // the data-gradient panels of `packs`, one grid per forward
     std::vector<Fn> pack_fns;
     // per-call external pointers
     const float *img = nullptr;
@@ -756,12 +757,17 @@ static int forward_train_impl(mc_handle *h, const float *img, const mc_labels *l
     if (!h->pack_clean && mc_pack_params(h, 1, stream)) return -1;   // mc_pack_params / the optimizer step track staleness
     for (auto &f : ts->pack_fns)       // dense head weight copies first: some dgrad panels are cut from them
         if (f(h, st)) return -1;
-    for (const PackJob &j : ts->packs) {
-        HIPCHK(h, launch_pack_conv_w_dgrad(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls, j.dst, st));
-        if (j.dst16)
-            HIPCHK(h, launch_pack_conv_w_dgrad_bf16(j.w, j.Cout, j.CinTotal, j.k, j.c_off, j.Cs, j.CsP, j.CoutPad, j.cls,
-                                                    h->prec == 2 ? 3 : 1, j.dst16, st));
+    if (ts->pack_batch.jobs.size() != ts->packs.size()) {      // first forward of the plan: table of the data-gradient panels
+        ts->pack_batch.clear();
+        for (const PackJob &j : ts->packs) {
+            mc::PackJobDesc d{};
+            d.w = j.w; d.dst32 = j.dst; d.dst16 = j.dst16; d.kind = 1;
+            d.Cout = j.Cout; d.Cin = j.Cs; d.k = j.k; d.CinTotal = j.CinTotal; d.CoutP = j.CoutPad; d.n_off = 0; d.c_off = j.c_off;
+            d.CsP = j.CsP; d.cls = j.cls; d.nsplit = h->prec == 2 ? 3 : 1;
+            ts->pack_batch.add(d);
+        }
     }
+    HIPCHK(h, ts->pack_batch.launch(st));
     ++g_train_generation;
     h->train_generation = g_train_generation;
     for (auto &f : ts->fwd)

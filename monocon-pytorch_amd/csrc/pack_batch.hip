@@ -1,0 +1,147 @@
+// Batched weight packing: every conv weight of the model -> its K-major MFMA panel (fp32 and, in the bf16-pipe modes,
+// the bf16 piece planes), for the forward panels and for the data-gradient panels, in ONE launch each.
+//
+// The panels are re-derived from the master weights before every train step (the optimizer just changed them):
+// per layer that was one launch for the fp32 panel, one for the bf16 planes and one BatchNorm fold -- ~200 launches of
+// ~5 us per step in fp32 mode, ~400 in the bf16x3 mode, i.e. 1-2 ms of a 80-100 ms step spent on launch cadence.
+// A job table (one entry per weight tensor, block ranges by prefix sum) turns each family into a single grid.
+// Layouts are those of pack_conv_w_kernel / pack_conv_w_bf16_kernel / pack_conv_w_dgrad_kernel /
+// pack_conv_w_dgrad_bf16_kernel (kernels_misc.hip, conv_bf16.hip, kernels_head_train.hip), element for element.
+#include "kernels.h"
+#include "train.h"
+
+namespace mc {
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackJobDesc *__restrict__ tab, int njobs) {
+    // job of this block: last entry whose block_begin <= blockIdx.x (wave-uniform binary search)
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJobDesc j = tab[lo];
+    const int lb = blockIdx.x - j.block_begin;
+    const int k = j.k, kk = k * k;
+    __bf16 *d16 = static_cast<__bf16 *>(j.dst16);
+    if (j.kind == 0) {
+        // forward panel: [tap][CinPanel/4][CoutP][4] fp32, [piece][tap][CinPanel/8][CoutP][8] bf16
+        const size_t total = (size_t)j.Cout * j.Cin * kk;
+        const size_t plane = (size_t)kk * j.CinTotal * j.CoutP;
+        for (size_t e = (size_t)lb * 256 + threadIdx.x; e < total; e += (size_t)j.nblocks * 256) {
+            const int tap = e % kk;
+            const int c = (e / kk) % j.Cin;
+            const int n = e / ((size_t)kk * j.Cin);
+            const int cc = c + j.c_off, nn = n + j.n_off;
+            float r = j.w[e];
+            if (j.dst32) j.dst32[(((size_t)tap * (j.CinTotal >> 2) + (cc >> 2)) * j.CoutP + nn) * 4 + (cc & 3)] = r;
+            if (d16)
+                for (int q = 0; q < j.nsplit; ++q) {
+                    const __bf16 piece = (__bf16)r;
+                    d16[q * plane + (((size_t)tap * (j.CinTotal >> 3) + (cc >> 3)) * j.CoutP + nn) * 8 + (cc & 7)] = piece;
+                    r -= (float)piece;
+                }
+        }
+    } else {
+        // data-gradient panel of one source (channels [c_off, c_off + Cs) of the forward weight): transposed + flipped,
+        // or one output-parity class of a stride-2 3x3 data gradient (cls = 2*py + px)
+        const int Cs = j.Cin, cls = j.cls, py = cls >> 1, px = cls & 1;
+        const size_t total = (size_t)j.Cout * Cs * kk;
+        const size_t plane = (size_t)(cls < 0 ? kk : (1 + py) * (1 + px)) * j.CoutP * j.CsP;
+        for (size_t e = (size_t)lb * 256 + threadIdx.x; e < total; e += (size_t)j.nblocks * 256) {
+            const int tap = e % kk;
+            const int cl = (e / kk) % Cs;
+            const int n = e / ((size_t)kk * Cs);
+            const int r = tap / k, s = tap % k;
+            int tapd;
+            if (cls < 0) {
+                tapd = (k - 1 - r) * k + (k - 1 - s);
+            } else {
+                if ((py == 0) != (r == 1) || (px == 0) != (s == 1)) continue;   // tap of the other parity
+                const int dr = py ? (2 - r) / 2 : 0, ds = px ? (2 - s) / 2 : 0;
+                tapd = dr * (1 + px) + ds;
+            }
+            float rem = j.w[(((size_t)n * j.CinTotal + j.c_off + cl) * k + r) * k + s];
+            if (j.dst32) j.dst32[(((size_t)tapd * (j.CoutP >> 2) + (n >> 2)) * j.CsP + cl) * 4 + (n & 3)] = rem;
+            if (d16)
+                for (int q = 0; q < j.nsplit; ++q) {
+                    const __bf16 piece = (__bf16)rem;
+                    d16[q * plane + (((size_t)tapd * (j.CoutP >> 3) + (n >> 3)) * j.CsP + cl) * 8 + (n & 7)] = piece;
+                    rem -= (float)piece;
+                }
+        }
+    }
+}
+
+void PackBatch::clear() {
+    jobs.clear();
+    total_blocks = 0;
+    uploaded = false;
+}
+void PackBatch::add(PackJobDesc j) {
+    const size_t total = (size_t)j.Cout * j.Cin * j.k * j.k;
+    size_t nb = (total + 1023) / 1024;          // ~4 elements per thread
+    if (nb < 1) nb = 1;
+    if (nb > 256) nb = 256;
+    j.nblocks = (int)nb;
+    j.block_begin = total_blocks;
+    total_blocks += (int)nb;
+    jobs.push_back(j);
+    uploaded = false;
+}
+hipError_t PackBatch::launch(hipStream_t st) {
+    if (jobs.empty()) return hipSuccess;
+    if (!uploaded) {
+        if (dev) (void)hipFree(dev);
+        dev = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&dev), jobs.size() * sizeof(PackJobDesc));
+        if (e != hipSuccess) return e;
+        e = hipMemcpy(dev, jobs.data(), jobs.size() * sizeof(PackJobDesc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        uploaded = true;
+    }
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, dev, (int)jobs.size());
+    return hipGetLastError();
+}
+PackBatch::~PackBatch() {
+    if (dev) (void)hipFree(dev);
+}
+
+// ---- BatchNorm folding (eval mode) of many layers in one launch
+__global__ void fold_bn_batch_kernel(const FoldJobDesc *__restrict__ tab) {
+    const FoldJobDesc j = tab[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= j.C) return;
+    const float inv = 1.0f / sqrtf(j.rv[c] + j.eps);
+    const float s = (j.g ? j.g[c] : 1.f) * inv;
+    j.scale[c] = s;
+    j.shift[c] = (j.b ? j.b[c] : 0.f) - j.rm[c] * s;
+}
+void FoldBatch::clear() {
+    jobs.clear();
+    uploaded = false;
+    maxC = 0;
+}
+void FoldBatch::add(const FoldJobDesc &j) {
+    jobs.push_back(j);
+    if (j.C > maxC) maxC = j.C;
+    uploaded = false;
+}
+hipError_t FoldBatch::launch(hipStream_t st) {
+    if (jobs.empty()) return hipSuccess;
+    if (!uploaded) {
+        if (dev) (void)hipFree(dev);
+        dev = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&dev), jobs.size() * sizeof(FoldJobDesc));
+        if (e != hipSuccess) return e;
+        e = hipMemcpy(dev, jobs.data(), jobs.size() * sizeof(FoldJobDesc), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        uploaded = true;
+    }
+    hipLaunchKernelGGL(fold_bn_batch_kernel, dim3((unsigned)((maxC + 63) / 64), (unsigned)jobs.size()), dim3(64), 0, st, dev);
+    return hipGetLastError();
+}
+FoldBatch::~FoldBatch() {
+    if (dev) (void)hipFree(dev);
+}
+
+}  // namespace mc

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #include "conv_mfma.h"
 
@@ -42,6 +43,52 @@ struct GatherLossArgs {
     int wrt_pred;                // mode 1: 0 = gradient wrt the raw 1x1 outputs, 1 = wrt the prediction maps themselves
 };
 hipError_t launch_gathered_losses(const GatherLossArgs &a, int mode, hipStream_t st);
+
+// ---- batched weight packing / BatchNorm folding (pack_batch.hip)
+struct PackJobDesc {
+    const float *w;        // master weight, OIHW fp32
+    float *dst32;          // fp32 panel or null
+    void *dst16;           // bf16 piece planes or null
+    int kind;              // 0: forward panel, 1: data-gradient panel
+    int Cout, Cin, k;      // forward: shape of w.  data gradient: Cin = channels of the source (Cs)
+    int CinTotal;          // forward: channels of the panel (virtual concat).  data gradient: Cin of the forward weight
+    int CoutP;             // forward: padded columns.  data gradient: CoutPad (K of the data gradient)
+    int n_off, c_off;      // forward: column / channel offset in the panel.  data gradient: c_off of the source
+    int CsP, cls, nsplit;  // data gradient: padded source channels, parity class (-1: stride 1); bf16 pieces (1 or 3)
+    int block_begin, nblocks;
+};
+struct PackBatch {
+    std::vector<PackJobDesc> jobs;
+    PackJobDesc *dev = nullptr;
+    int total_blocks = 0;
+    bool uploaded = false;
+    void clear();
+    void add(PackJobDesc j);
+    hipError_t launch(hipStream_t st);
+    PackBatch() = default;
+    PackBatch(const PackBatch &) = delete;
+    PackBatch &operator=(const PackBatch &) = delete;
+    ~PackBatch();
+};
+struct FoldJobDesc {
+    const float *g, *b, *rm, *rv;
+    float eps;
+    int C;
+    float *scale, *shift;
+};
+struct FoldBatch {
+    std::vector<FoldJobDesc> jobs;
+    FoldJobDesc *dev = nullptr;
+    bool uploaded = false;
+    int maxC = 0;
+    void clear();
+    void add(const FoldJobDesc &j);
+    hipError_t launch(hipStream_t st);
+    FoldBatch() = default;
+    FoldBatch(const FoldBatch &) = delete;
+    FoldBatch &operator=(const FoldBatch &) = delete;
+    ~FoldBatch();
+};
 
 // ---- fused clip + AdamW (reference engine/monocon_engine.py:94-102)
 struct OptTensor { float *p, *g, *m, *v; };
