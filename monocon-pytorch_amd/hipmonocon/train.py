@@ -53,6 +53,15 @@ def _binding(detector):
     return tb
 
 
+def _loss_grad_vector(grads, like):
+    """(10,) device vector of the upstream gradients of the ten losses (None: that loss does not reach the objective)"""
+    first = grads[0]
+    if first is not None and all(g is first for g in grads):        # sum(loss_dict.values()).backward(): one shared scalar
+        return first.detach().reshape(1).expand(10).contiguous().float()
+    zero = torch.zeros((), dtype=torch.float32, device=like.device)
+    return torch.stack([zero if g is None else g.detach().reshape(()).float() for g in grads])
+
+
 class _HipTrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, detector, tb, eng, img, label, max_objs, *params):
@@ -79,13 +88,16 @@ class _HipTrainStep(torch.autograd.Function):
         _lib.check(eng.h, eng.lib.mc_train_generation(eng.h, C.byref(gen)), "mc_train_generation")
         ctx.generation = gen.value
         torch.autograd.graph.increment_version(tb.buffers)        # running statistics were updated in place
-        ctx.eng, ctx.tb, ctx.keep = eng, tb, (img, keep, preds)
+        ctx.eng, ctx.tb, ctx.keep = eng, tb, (img, keep, preds, losses)
         ctx.mark_non_differentiable(*preds)
-        return (losses, *preds)
+        # ten separate 0-dim outputs (views of the one device vector the kernel wrote): the backward then receives the ten
+        # upstream gradients directly, instead of ten select-backward nodes each filling a zero vector and adding it
+        return (*losses.unbind(0), *preds)
 
     @staticmethod
-    def backward(ctx, grad_losses, *unused):
+    def backward(ctx, *grads):
         eng, tb = ctx.eng, ctx.tb
+        grad_losses = _loss_grad_vector(grads[:10], ctx.keep[3])
         gen = C.c_ulonglong(0)
         _lib.check(eng.h, eng.lib.mc_train_generation(eng.h, C.byref(gen)), "mc_train_generation")
         if gen.value != ctx.generation:
@@ -157,7 +169,7 @@ def forward_train(detector, data_dict):
     eng = detector._rt.get(tb.state(detector))
     params = [p for _, p in tb.named]
     out = _HipTrainStep.apply(detector, tb, eng, img.contiguous(), label, detector.head.max_objs, *params)
-    losses, preds = out[0], out[1:]
+    losses, preds = out[:10], out[10:]
     pred_dict = dict(zip(PRED_KEYS, preds))
     loss_dict = {k: losses[i] for i, k in enumerate(netspec.LOSS_KEYS)}
     return pred_dict, loss_dict
@@ -206,13 +218,14 @@ class _HipHeadTrainStep(torch.autograd.Function):
         _lib.check(eng.h, eng.lib.mc_train_generation(eng.h, C.byref(gen)), "mc_train_generation")
         ctx.generation = gen.value
         torch.autograd.graph.increment_version(tb.buffers)
-        ctx.eng, ctx.tb, ctx.keep, ctx.feat_shape = eng, tb, (feat, keep, preds), feat.shape
+        ctx.eng, ctx.tb, ctx.keep, ctx.feat_shape = eng, tb, (feat, keep, preds, losses), feat.shape
         ctx.mark_non_differentiable(*preds)
-        return (losses, *preds)
+        return (*losses.unbind(0), *preds)
 
     @staticmethod
-    def backward(ctx, grad_losses, *unused):
+    def backward(ctx, *grads):
         eng, tb = ctx.eng, ctx.tb
+        grad_losses = _loss_grad_vector(grads[:10], ctx.keep[3])
         gen = C.c_ulonglong(0)
         _lib.check(eng.h, eng.lib.mc_train_generation(eng.h, C.byref(gen)), "mc_train_generation")
         if gen.value != ctx.generation:
@@ -253,5 +266,5 @@ def head_forward_train(heads, feat, data_dict):
     eng = heads._rt.get(tb.state(heads))
     params = [p for _, p in tb.named]
     out = _HipHeadTrainStep.apply(tb, eng, feat.contiguous().float(), label, pad_hw, heads.max_objs, *params)
-    losses, preds = out[0], out[1:]
+    losses, preds = out[:10], out[10:]
     return dict(zip(PRED_KEYS, preds)), {k: losses[i] for i, k in enumerate(netspec.LOSS_KEYS)}
