@@ -71,6 +71,19 @@ json.dump({"source": "profiles/%s_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SI
                              "launches_sampled": v[2], "avg_us_under_pmc": v[3] / v[2]}
                         for f_, v in fam.items() if v[2] and f_.startswith("mc::")}},
           open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
+# ---- LDS counters (bank conflicts) of the kernels that use the LDS most
+lp = os.path.join(src, "pmc_lds", "p_counter_collection.csv")
+if os.path.exists(lp):
+    lds, lcnt, _ = pmc(lp)
+    with open(os.path.join(dst, tag + "_lds.txt"), "w") as f:
+        f.write("# per dispatch averages of rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA (own pass).\n")
+        f.write("# conflict_ratio = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: share of the LDS array's cycles spent on bank-conflict replays\n")
+        f.write("%-50s %7s %5s %13s %13s %9s %11s %11s\n" % ("kernel", "blocks", "n", "lds_conflict", "lds_active", "ratio", "insts_lds", "insts_mfma"))
+        for k in sorted(lds, key=lambda k: -lds[k].get("SQ_LDS_IDX_ACTIVE", 0))[:24]:
+            if not k[0].startswith("mc::"): continue
+            v = lds[k]; n = len(lcnt[k])
+            f.write("%-50s %7d %5d %13.4g %13.4g %9.3f %11.4g %11.4g\n" % (k[0][:50], k[1], n, v["SQ_LDS_BANK_CONFLICT"] / n, v["SQ_LDS_IDX_ACTIVE"] / n,
+                    v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_LDS_IDX_ACTIVE"], 1), v["SQ_INSTS_LDS"] / n, v["SQ_INSTS_MFMA"] / n))
 for extra in ("conv_shapes.txt", "mfma_peak.txt"):
     p = os.path.join(src, extra)
     if os.path.exists(p):
