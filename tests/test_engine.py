@@ -73,6 +73,16 @@ def test_engine_trains_checkpoints_and_resumes(tmp_path):
     assert eng2.epochs == 3 and eng2.global_iters == 5
     a, b = eng.model.state_dict(), eng2.model.state_dict()
     assert all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a)
+    # the optimizer comes back with torch.optim.AdamW's per-parameter state (step restored, warm moments) and the
+    # one-cycle schedule at the step it was saved at (reference base_engine.py:155-219)
+    st1, st2 = eng.optimizer.state_dict()['state'], eng2.optimizer.state_dict()['state']
+    assert st1.keys() == st2.keys() and len(st2) == 236
+    for k in st1:
+        assert float(st2[k]['step']) == float(st1[k]['step']) == 4.0
+        assert torch.equal(st1[k]['exp_avg'].cpu(), st2[k]['exp_avg'].cpu())
+        assert torch.equal(st1[k]['exp_avg_sq'].cpu(), st2[k]['exp_avg_sq'].cpu())
+    assert eng2.scheduler._step_count == eng.scheduler._step_count
+    assert eng2.optimizer.param_groups[0]['lr'] == eng.optimizer.param_groups[0]['lr']
     ev = eng2.evaluate()
     assert ev['num_results'] == 2.0
 
