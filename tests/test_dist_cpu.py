@@ -73,3 +73,36 @@ def test_shard_batch_partitions_the_global_batch():
         assert torch.equal(sb["label"]["mask"], b["label"]["mask"][idx[0]:idx[-1] + 1])
         seen += idx
     assert seen == list(range(6))
+
+
+def _sync_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hipmonocon import dist as hdist
+    torch.manual_seed(1000 + rank)                       # every rank draws its own weights ...
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Linear(4, 4))
+    m[1].num_batches_tracked += rank                     # ... and has its own (int64) buffer state
+    before = hdist.state_checksum(m)
+    n = hdist.sync_module_state(m)                       # ... until rank 0's state is broadcast
+    seed = hdist.broadcast_seed(4242 + rank)
+    ok_all = hdist.all_ranks_ok(rank != 1)               # rank 1 reports a bad batch: every rank must see False
+    ok_none = hdist.all_ranks_ok(True)
+    out[rank] = (before, hdist.state_checksum(m), n, seed, ok_all, ok_none, int(m[1].num_batches_tracked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_start_identical_and_fail_together():
+    """ADVICE (round 1, high): with a per-rank random seed every replica used to initialise differently and nothing
+    synchronised them.  ``sync_module_state`` makes every rank adopt rank 0's parameters and buffers, ``broadcast_seed``
+    its seed, and ``all_ranks_ok`` turns one rank's invalid batch into an exception on all ranks."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_sync_worker, args=(world, port, out), nprocs=world, join=True)
+    (b0, a0, n0, s0, f0, t0, nbt0), (b1, a1, n1, s1, f1, t1, nbt1) = out[0], out[1]
+    assert b0 != b1                                      # different before
+    assert a0 == a1 == b0                                # rank 0's state everywhere afterwards
+    assert n0 == n1 == 9 and nbt0 == nbt1 == 0
+    assert s0 == s1 == 4242
+    assert f0 is False and f1 is False and t0 is True and t1 is True
