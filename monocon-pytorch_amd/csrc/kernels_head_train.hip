@@ -65,19 +65,22 @@ hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int 
 // (reference model/dense_heads/monocon_heads.py:119-120 under autograd)
 struct HeadBwdArgs {
     const float *draw; int ld;
-    const float *z, *x, *w1;
+    const float *z, *x, *w1;          // z may be null: recomputed as relu(scale_bc * x + shift_bc), bit-identical to head_apply
+    const float *scale, *shift;       // [B][CP] AttnBN coefficients of the forward (used when z is null)
     float *d, *dw_partial, *red_partial;
     int HW, rows_per_block, blocks_per_img;
 };
 template <int RB, int NR>
-__device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, int h, int lane, size_t p0, int np, int blk) {
+__device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, int h, int lane, size_t p0, int np, int blk, int b) {
     constexpr int CP = NUM_HEADS * HEAD_CH;
     typedef const float __attribute__((address_space(4))) cfloat;
     float w[NR], acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) { w[r] = a.w1[(RB + r) * HEAD_CH + lane]; acc[r] = 0.f; }
     float s1 = 0.f, s2 = 0.f;
-    const float *zp = a.z + p0 * CP + h * HEAD_CH + lane, *xp = a.x + p0 * CP + h * HEAD_CH + lane;
+    const bool rez = a.z == nullptr;
+    const float zsc = rez ? a.scale[(size_t)b * CP + h * HEAD_CH + lane] : 0.f, zsh = rez ? a.shift[(size_t)b * CP + h * HEAD_CH + lane] : 0.f;
+    const float *xp = a.x + p0 * CP + h * HEAD_CH + lane, *zp = rez ? xp : a.z + p0 * CP + h * HEAD_CH + lane;
     float *dp = a.d + p0 * CP + h * HEAD_CH + lane;
     auto one = [&](int i, float zv, float xv) {
         cfloat *g = (cfloat *)(uintptr_t)(a.draw + (p0 + i) * a.ld + RB);
@@ -98,11 +101,17 @@ __device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, int h, int l
     for (; i + U <= np; i += U) {
         float zv[U], xv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { zv[u] = zp[(size_t)(i + u) * CP]; xv[u] = xp[(size_t)(i + u) * CP]; }
+        for (int u = 0; u < U; ++u) {
+            xv[u] = xp[(size_t)(i + u) * CP];
+            if (!rez) zv[u] = zp[(size_t)(i + u) * CP];
+        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) one(i + u, zv[u], xv[u]);
+        for (int u = 0; u < U; ++u) one(i + u, rez ? fmaxf(fmaf(xv[u], zsc, zsh), 0.f) : zv[u], xv[u]);
     }
-    for (; i < np; ++i) one(i, zp[(size_t)i * CP], xp[(size_t)i * CP]);
+    for (; i < np; ++i) {
+        const float xv1 = xp[(size_t)i * CP];
+        one(i, rez ? fmaxf(fmaf(xv1, zsc, zsh), 0.f) : zp[(size_t)i * CP], xv1);
+    }
 #pragma unroll
     for (int r = 0; r < NR; ++r) a.dw_partial[((size_t)blk * NUM_OUT_ROWS + RB + r) * HEAD_CH + lane] = acc[r];
     float *rp = a.red_partial + ((size_t)blk * CP + h * HEAD_CH + lane) * 2;
@@ -118,27 +127,30 @@ __global__ __launch_bounds__(NUM_HEADS * 64) void head_bwd_kernel(const HeadBwdA
     const int np = min(a.HW, r0 + a.rows_per_block) - r0;
     const size_t p0 = (size_t)b * a.HW + r0;
     switch (h) {   // (first row, row count) of each head in HeadRow order
-        case 0: head_bwd_rows<0, 3>(a, h, lane, p0, np, blk); break;
-        case 1: head_bwd_rows<3, 2>(a, h, lane, p0, np, blk); break;
-        case 2: head_bwd_rows<5, 2>(a, h, lane, p0, np, blk); break;
-        case 3: head_bwd_rows<7, 18>(a, h, lane, p0, np, blk); break;
-        case 4: head_bwd_rows<25, 9>(a, h, lane, p0, np, blk); break;
-        case 5: head_bwd_rows<34, 2>(a, h, lane, p0, np, blk); break;
-        case 6: head_bwd_rows<36, 3>(a, h, lane, p0, np, blk); break;
-        case 7: head_bwd_rows<39, 2>(a, h, lane, p0, np, blk); break;
-        default: head_bwd_rows<41, 24>(a, h, lane, p0, np, blk); break;
+        case 0: head_bwd_rows<0, 3>(a, h, lane, p0, np, blk, b); break;
+        case 1: head_bwd_rows<3, 2>(a, h, lane, p0, np, blk, b); break;
+        case 2: head_bwd_rows<5, 2>(a, h, lane, p0, np, blk, b); break;
+        case 3: head_bwd_rows<7, 18>(a, h, lane, p0, np, blk, b); break;
+        case 4: head_bwd_rows<25, 9>(a, h, lane, p0, np, blk, b); break;
+        case 5: head_bwd_rows<34, 2>(a, h, lane, p0, np, blk, b); break;
+        case 6: head_bwd_rows<36, 3>(a, h, lane, p0, np, blk, b); break;
+        case 7: head_bwd_rows<39, 2>(a, h, lane, p0, np, blk, b); break;
+        default: head_bwd_rows<41, 24>(a, h, lane, p0, np, blk, b); break;
     }
 }
 // blocks = chan_reduce_blocks(B, HW); rows_per_block = that partition's row count (kernels_train.hip)
 hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const float *x, const float *w1, int B, int HW,
-                           int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st) {
+                           int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st, const float *scale,
+                           const float *shift) {
     const int *rbeg = head_row_begin();
     static const int RB[NUM_HEADS + 1] = {0, 3, 5, 7, 25, 34, 36, 39, 41, 65};
     for (int i = 0; i <= NUM_HEADS; ++i)
         if (rbeg[i] != RB[i]) return hipErrorInvalidValue;      // the switch above hard-codes the HeadRow table
     if (blocks % B) return hipErrorInvalidValue;
     HeadBwdArgs a;
+    if (!z && (!scale || !shift)) return hipErrorInvalidValue;
     a.draw = draw; a.ld = ld; a.z = z; a.x = x; a.w1 = w1; a.d = d; a.dw_partial = dw_partial; a.red_partial = red_partial;
+    a.scale = scale; a.shift = shift;
     a.HW = HW; a.blocks_per_img = blocks / B; a.rows_per_block = (HW + a.blocks_per_img - 1) / a.blocks_per_img;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(NUM_HEADS * 64), 0, st, a);
     return hipGetLastError();

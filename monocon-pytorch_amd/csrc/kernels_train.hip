@@ -344,6 +344,9 @@ hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, dou
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ partial, int nb, int Cstride,
+                                                           float *__restrict__ out);
+
 // ------------------------------------------------------------------ dy = P*d + Q*y + R,  d = relu ? dz*[z>0] : dz
 // gres_mode: 0 none, 1 gres = d, 2 gres += d (gradient of the residual input)
 __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict__ dz, const f32x4 *__restrict__ z,
@@ -351,7 +354,10 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
                                                          int C4, int RG, int rows_per_img, int blocks_per_img,
                                                          int rows_per_block, int per_sample, int relu,
                                                          f32x4 *__restrict__ dy, f32x4 *__restrict__ gres, int gres_mode,
-                                                         const float *__restrict__ fa, const float *__restrict__ fb) {
+                                                         const float *__restrict__ fa, const float *__restrict__ fb,
+                                                         float *__restrict__ csum /*[blocks][4*C4][2] or null*/) {
+    __shared__ f32x4 cred[256];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};      // column sums of dy over this thread's rows (conv bias gradient), csum != null
     const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
     const int b = blockIdx.x / blocks_per_img, rb = blockIdx.x % blocks_per_img;
     const int r0 = rb * rows_per_block, r1 = min(rows_per_img, r0 + rows_per_block);
@@ -373,6 +379,7 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
             if (relu == 1) d[j] = zv[j] > 0.f ? d[j] : 0.f;
             else if (relu == 2) d[j] = fmaf(yv[j], ma[j], mb[j]) > 0.f ? d[j] : 0.f;
             o[j] = fmaf(cp[j], d[j], fmaf(cq[j], yv[j], cr[j]));
+            cs[j] += o[j];
         }
         dy[e] = o;
         if (gres_mode == 1) gres[e] = d;
@@ -402,10 +409,24 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
         if (relu == 1) zv = z[e];
         one(e, dz[e], zv, y[e]);
     }
+    if (csum) {       // row groups folded in order through LDS: one (sum, -) pair per block and channel (colsum_final_kernel's format)
+        cred[threadIdx.x] = cs;
+        __syncthreads();
+        if (rg == 0) {
+            for (int g = 1; g < RG; ++g) {
+                const f32x4 o = cred[g * C4 + c4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cs[j] += o[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csum[((size_t)blockIdx.x * (4 * C4) + c4 * 4 + j) * 2] = cs[j];
+        }
+    }
 }
+int affine_bwd_blocks(int B, size_t rows_per_img, int C) { return B * row_split(B, rows_per_img, C / 4).blocks_per_img; }
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st,
-                             const float *fa, const float *fb) {
+                             const float *fa, const float *fb, float *csum, float *csum_out) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
     if (relu == 2 && (!fa || !fb || per_sample)) return hipErrorInvalidValue;
     if (dbg_skip("abwd")) return hipSuccess;
@@ -414,7 +435,9 @@ hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, co
                        reinterpret_cast<const f32x4 *>(dz), reinterpret_cast<const f32x4 *>(z),
                        reinterpret_cast<const f32x4 *>(y), coef, C / 4, rs.rg, (int)rows_per_img, rs.blocks_per_img,
                        rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(dy), reinterpret_cast<f32x4 *>(gres),
-                       gres_mode, fa, fb);
+                       gres_mode, fa, fb, csum);
+    if (csum && csum_out)     // column sums of dy: the partial rows of the launch above, finished per column
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, st, csum, B * rs.blocks_per_img, C, csum_out);
     return hipGetLastError();
 }
 

@@ -477,7 +477,9 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     // ---- heads
     const int CP = NUM_HEADS * HEAD_CH, LD = 80;
     Tensor xh; xh.B = B; xh.H = fh; xh.W = fw; xh.C = CP; xh.p = b.alloc(xh.numel());
-    Tensor hn = xh; hn.p = b.alloc(xh.numel());
+    // (round 2: the normalised hidden maps are no longer stored -- head_bwd_kernel recomputes relu(scale*x + shift) from the
+    //  conv output it reads anyway: one 2.3 GB write and one 2.3 GB read per step less)
+
     Tensor raw; raw.B = B; raw.H = fh; raw.W = fw; raw.C = LD; raw.p = b.alloc(raw.numel());
     AttnTrainArgs at{};
     static const char *HN[NUM_HEADS] = {"heatmap_head", "wh_head", "offset_head", "center2kpt_offset_head", "kpt_heatmap_head",
@@ -522,7 +524,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     HeadApplyArgs ha{};
     {
         ha.hidden = xh.p; ha.scale = at.scale; ha.shift = at.shift; ha.w = h->head_w1t; ha.b = h->head_b1;
-        ha.B = B; ha.HW = HW; ha.z_out = hn.p;
+        ha.B = B; ha.HW = HW; ha.z_out = nullptr;
         static const int PCH[10] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
         for (int i = 0; i < 10; ++i) ha.pred_c[i] = PCH[i];     // the prediction pointers are per call (ts->preds)
         // one closure per kernel family so that mc_profile_train attributes the durations correctly
@@ -604,24 +606,24 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
                 ts->ok = false;
         }
         {
-            const float *xp = xh.p, *hp = hn.p, *w1 = h->head_w1;
+            const float *xp = xh.p, *w1 = h->head_w1, *zsc = at.scale, *zsh = at.shift;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_head_bwd(draw, LD, hp, xp, w1, B, HW, nbr, dh, dw1p, partial, st));
+                HIPCHK(hh, launch_head_bwd(draw, LD, nullptr, xp, w1, B, HW, nbr, dh, dw1p, partial, st, zsc, zsh));
                 HIPCHK(hh, launch_splitk_reduce(dw1p, nbr, 1, NUM_OUT_ROWS, HEAD_CH, dw1, st));
                 HIPCHK(hh, launch_copy_batch(segcb, st));
                 return 0;
             });
         }
         float *db3 = b.alloc(CP), *dw3 = b.alloc((size_t)CP * 64 * 9);
-        float *cs3 = b.alloc(colsum_partial_floats((size_t)B * HW, CP));
+        float *cs3 = b.alloc((size_t)affine_bwd_blocks(B, (size_t)HW, CP) * CP * 2);
         Tensor dxT = xh; dxT.p = dx;
         {
-            const float *xp = xh.p, *hp = hn.p;
+            const float *xp = xh.p;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                // d is already masked: the AttnBN backward is the plain per-(image, channel) affine map
+                // d is already masked: the AttnBN backward is the plain per-(image, channel) affine map; the same pass
+                // leaves the column sums of dx (the 3x3 convs' bias gradients) instead of a second read of dx
                 HIPCHK(hh, launch_attn_train_bwd(at, partial, rb_per_img, gp, coef, st));
-                HIPCHK(hh, launch_affine_bwd(dh, hp, xp, coef, B, (size_t)HW, CP, 1, 0, dx, nullptr, 0, st));
-                HIPCHK(hh, launch_colsum(dx, (size_t)B * HW, CP, CP, cs3, db3, st));
+                HIPCHK(hh, launch_affine_bwd(dh, nullptr, xp, coef, B, (size_t)HW, CP, 1, 0, dx, nullptr, 0, st, nullptr, nullptr, cs3, db3));
                 return 0;
             });
         }

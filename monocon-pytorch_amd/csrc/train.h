@@ -115,7 +115,9 @@ hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, dou
                                   hipStream_t st, double *fold = nullptr);
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st,
-                             const float *fa = nullptr, const float *fb = nullptr);
+                             const float *fa = nullptr, const float *fb = nullptr, float *csum = nullptr, float *csum_out = nullptr);
+// csum: scratch of affine_bwd_blocks(B, rows, C) * C * 2 floats -> csum_out[C] = column sums of dy (the conv bias gradient)
+int affine_bwd_blocks(int B, size_t rows_per_img, int C);
 hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st);
 size_t colsum_partial_floats(size_t rows, int ld);
 hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st);
@@ -154,7 +156,8 @@ hipError_t launch_attn_train_fwd(const AttnTrainArgs &a, hipStream_t st);
 hipError_t launch_attn_train_bwd(const AttnTrainArgs &a, const float *partial, int rb_per_img, const AttnGradPtrs &gp,
                                  float *coef, hipStream_t st);
 hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const float *x, const float *w1, int B, int HW,
-                           int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st);
+                           int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st,
+                           const float *scale = nullptr, const float *shift = nullptr);
 hipError_t launch_splitk_reduce(const float *partial, int ksplit, int T, int Cout, int Cin, float *dw, hipStream_t st);
 int stem_wgrad_blocks(int B, int H, int W);
 hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
