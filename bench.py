@@ -130,8 +130,9 @@ def cpu_baseline(sd, height, width, budget_s):
         with torch.no_grad():
             O.clip_and_adamw([p.detach() for p in ps], gs, ms, vs, 1, 2.25e-4, 0.95)
 
-    def timed(fn, budget, min_runs=3, max_runs=30):
-        fn()                                     # warm-up
+    def timed(fn, budget, min_runs=3, max_runs=30, warm=True):
+        if warm:
+            fn()                                 # warm-up
         times = []
         t_end = time.perf_counter() + budget
         while len(times) < min_runs or (time.perf_counter() < t_end and len(times) < max_runs):
@@ -150,8 +151,9 @@ def cpu_baseline(sd, height, width, budget_s):
         m2, n2 = timed(lambda: O.forward(sd, img2), budget_s / 4)
         legs["eval_forward_b2"] = {"images_per_sec": round(2 / m2, 3), "s_per_run": round(m2, 3), "runs": n2}
         img32 = img2.repeat(16, 1, 1, 1)
-        m32, n32 = timed(lambda: O.forward(sd, img32), budget_s / 2, min_runs=2, max_runs=5)
-        legs["eval_forward_b32"] = {"images_per_sec": round(32 / m32, 3), "s_per_run": round(m32, 3), "runs": n32}
+        m32, n32 = timed(lambda: O.forward(sd, img32), 0.0, min_runs=1, max_runs=1, warm=False)   # ~12 s: one run, no warm-up
+        legs["eval_forward_b32"] = {"images_per_sec": round(32 / m32, 3), "s_per_run": round(m32, 3), "runs": n32,
+                                    "note": "single un-warmed run (the B=2 leg just exercised the same kernels)"}
         K, DB = 100, 64
         d = {k: torch.from_numpy(v) for k, v in synth.make_decode_inputs(77, DB, height // 4, width // 4, topk=K).items()}
         P2 = np.stack([synth.KITTI_P2] * DB)
