@@ -128,7 +128,7 @@ typedef struct mc_targets {
  * (utils/tensor_ops.py:62-125): one launch instead of a Python loop over batch x objects x 9. */
 int mc_make_targets(mc_handle *h, const mc_labels *labels, int B, int max_objs, int pad_h,
                     int pad_w, int feat_h, int feat_w, const mc_targets *targets, void *stream);
-/* Replaces MonoConDenseHeads._get_losses + losses/*.py (model/dense_heads/monocon_heads.py:203-310):
+/* Replaces MonoConDenseHeads._get_losses + losses/{l1,dim,depth,focal,cross_entropy}_loss.py (model/dense_heads/monocon_heads.py:203-310):
  * losses[10] (device) in the reference's loss_dict order: center_heatmap, wh, offset, dim,
  * center2kpt_offset, kpt_heatmap, kpt_heatmap_offset, alpha_cls, alpha_reg, depth. */
 int mc_losses(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *targets,
