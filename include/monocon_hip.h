@@ -240,6 +240,13 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
 int mc_preprocess(mc_handle *h, const void *img_hwc, int dtype, int H, int W, const double mean[3],
                   const double std[3], int pad_h, int pad_w, float *out_chw, void *stream);
 
+/* Device memory a plan of the handle needs for one input shape, WITHOUT building it (lets the caller size
+ * the batch against the 288 GB of HBM before the first step; the plan builder runs dry -- nothing is allocated or
+ * launched).  mode 0: inference forward (mc_forward_infer), 1: train step (mc_forward_train + mc_backward), 2: heads-only
+ * train step (mc_head_forward_train).  The parameters the mode needs must be bound and packed.  Replaces nothing in
+ * the reference (torch's caching allocator grows on demand, engine/base_engine.py has no such query). */
+int mc_query_workspace(mc_handle *h, int B, int H, int W, int mode, size_t *bytes);
+
 /* Measurement aid for bench.py: re-runs the launches of the last mc_forward_train + mc_backward
  * `iters` times with a HIP event pair around every launch group on `stream` and returns, per
  * kernel family k (0 = everything else, 1 = conv_mfma_kernel: forward convs + data gradients,

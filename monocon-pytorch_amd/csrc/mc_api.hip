@@ -22,6 +22,7 @@
 #include "conv_mfma.h"
 #include "kernels.h"
 
+#include <cstdint>
 #include "mc_internal.h"
 
 std::string g_create_err;
@@ -35,6 +36,12 @@ static const int PRED_CH[MC_NUM_PREDS] = {3, 9, 2, 2, 2, 18, 3, 2, 12, 12};
 static int dev_alloc(mc_handle *h, float **p, size_t nfloats, std::vector<void *> &track, size_t &acct) {
     void *q = nullptr;
     const size_t bytes = (nfloats == 0 ? 4 : nfloats) * sizeof(float);
+    if (h->dry_alloc) {                       // mc_query_workspace: count only
+        h->dry_next += (bytes + 255) / 256 * 256;
+        acct += bytes;
+        *p = reinterpret_cast<float *>((uintptr_t)0x100000 + h->dry_next);
+        return 0;
+    }
     HIPCHK(h, hipMalloc(&q, bytes));
     HIPCHK(h, hipMemset(q, 0, bytes));
     track.push_back(q);
@@ -269,6 +276,9 @@ struct Builder {
 
 int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     const bool small_ok = conv_small_ok(a_in, ks, stride);
+    if (h->dry_alloc)    // mc_query_workspace: nothing is launched; only row-kernel eligibility matters for buffer sizes
+        return (small_ok && !(a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride))) ? (int)CFG_SMALL
+                                                                               : conv_pick_cfg(a_in.Cout, a_in.CoutP, ks, stride, a_in.B, a_in.Hout, a_in.Wout);
     // the 16x16x4 row kernel sums K in a different order than the 32x32x2 tilings: choosing it by eligibility, not by
     // timing, keeps results independent of the batch size / of autotuning noise (it is also the faster one)
     if (small_ok && !(a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride))) return CFG_SMALL;
@@ -419,6 +429,10 @@ static Plan *get_plan(mc_handle *h, int B, int H, int W) {
     for (auto &op : pl->ops) {
         pl->flops += op.flops;
         pl->hbm_bytes += op.bytes;
+    }
+    if (h->dry_alloc) {                       // counted only: hand the size back through dry_next, keep nothing
+        h->dry_next = pl->bytes;
+        return nullptr;
     }
     if (hipDeviceSynchronize() != hipSuccess) return nullptr;   // buffer zero-fills ran on the null stream
     Plan *ret = pl.get();
@@ -1009,6 +1023,25 @@ int mc_set_precision(mc_handle *h, int mode) {
 }
 
 // ---------------------------------------------------------------------------- introspection
+int mc_train_query_workspace(mc_handle *h, int B, int H, int W, int head_only, size_t *bytes);   // mc_train_plan.hip
+
+int mc_query_workspace(mc_handle *h, int B, int H, int W, int mode, size_t *bytes) {
+    if (!h || !bytes) return -1;
+    if (B < 1 || H < 32 || W < 32 || (H % 32) || (W % 32)) return fail(h, "mc_query_workspace: B >= 1, H and W multiples of 32");
+    if (mode == 0) {
+        if (!h->packed) return fail(h, "mc_query_workspace: bind all parameters and call mc_pack_params first");
+        auto it = h->plans.find(std::make_tuple(B, H, W));
+        if (it != h->plans.end()) { *bytes = it->second->bytes; return 0; }
+        h->dry_alloc = true; h->dry_next = 0;
+        (void)get_plan(h, B, H, W);
+        h->dry_alloc = false;
+        *bytes = h->dry_next;
+        return *bytes ? 0 : -1;
+    }
+    if (mode == 1 || mode == 2) return mc_train_query_workspace(h, B, H, W, mode == 2, bytes);
+    return fail(h, "mc_query_workspace: mode %d (0 inference forward, 1 train step, 2 heads-only train step)", mode);
+}
+
 size_t mc_workspace_bytes(mc_handle *h) {
     if (!h) return 0;
     size_t n = h->param_bytes + (3 * h->decode_filt_n + h->decode_count_n) * sizeof(float) + h->train_bytes;

@@ -110,6 +110,10 @@ struct mc_handle {
     // train-step plan (mc_train_plan.hip)
     TrainState *train = nullptr;
     size_t train_bytes = 0;   // device memory owned by the train plan
+    // mc_query_workspace: plan builders run "dry" -- buffers are counted, not allocated (fake addresses that are never
+    // dereferenced), nothing is launched or cached
+    bool dry_alloc = false;
+    size_t dry_next = 0;
     unsigned long long train_generation = 0;   // id of the forward whose activations the train plan holds (0: none)
     void (*train_free)(TrainState *) = nullptr;
     unsigned long long bind_gen = 0;

@@ -113,6 +113,11 @@ struct TB {   // train plan builder
         float *p = nullptr;
         void *q = nullptr;
         const size_t bytes = (n ? n : 1) * sizeof(float);
+        if (h->dry_alloc) {                   // mc_query_workspace: count only (never dereferenced)
+            h->dry_next += (bytes + 255) / 256 * 256;
+            ts->bytes += bytes;
+            return reinterpret_cast<float *>((uintptr_t)0x100000 + h->dry_next);
+        }
         if (hipMalloc(&q, bytes) != hipSuccess || hipMemset(q, 0, bytes) != hipSuccess) {
             ts->ok = false;
             h->err = "train plan: out of device memory";
@@ -436,7 +441,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     float *ones16 = b.alloc(16), *zeros16 = b.alloc(16);
     {
         std::vector<float> one(16, 1.f);
-        if (hipMemcpy(ones16, one.data(), 64, hipMemcpyHostToDevice) != hipSuccess) ts->ok = false;
+        if (!h->dry_alloc && hipMemcpy(ones16, one.data(), 64, hipMemcpyHostToDevice) != hipSuccess) ts->ok = false;
         const int nb = chan_reduce_blocks(B, H * W);
         float *partial = b.alloc((size_t)nb * 16 * 2), *ca = b.alloc(16), *cb = b.alloc(16);
         stem.mean = b.alloc(16); stem.rstd = b.alloc(16);
@@ -707,6 +712,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         });
     }
     if (!ts->ok) return nullptr;
+    if (h->dry_alloc) return tsp.release();   // mc_query_workspace: sizes only
     ts->bwd_side.resize(ts->bwd.size(), 0);
     if (const char *e = std::getenv("MONOCON_HIP_DUAL_STREAM")) ts->dual = std::atoi(e) != 0;
     if (ts->dual) {
@@ -785,6 +791,30 @@ int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, in
 int mc_head_forward_train(mc_handle *h, const float *feat, const mc_labels *labels, int B, int pad_h, int pad_w, int max_objs,
                           float *const preds[MC_NUM_PREDS], float *losses, void *stream) {
     return forward_train_impl(h, feat, labels, B, pad_h, pad_w, max_objs, preds, losses, stream, true);
+}
+
+// sizes of the train plan (mc_query_workspace modes 1 / 2): the builder runs dry, nothing is allocated or launched
+int mc_train_query_workspace(mc_handle *h, int B, int H, int W, int head_only, size_t *bytes) {
+    if (!h || !bytes) return -1;
+    if (B < 2 || B > 64) return fail(h, "mc_query_workspace: train batch %d (2..64 per GPU)", B);
+    if (head_only ? !(h->packed_groups & 4) : h->packed_groups != 7)
+        return fail(h, "mc_query_workspace: bind the parameters (and their \"#grad\" buffers) and call mc_pack_params first");
+    TrainState *cur = h->train;
+    if (cur && cur->B == B && cur->H == H && cur->W == W && cur->head_only == (head_only != 0) && cur->bind_gen == h->bind_gen) {
+        *bytes = cur->bytes;
+        return 0;
+    }
+    void *ta = h->tgt_arena, *da = h->dp_arena;
+    const size_t tb = h->tgt_arena_bytes, db = h->dp_arena_bytes;
+    h->dry_alloc = true; h->dry_next = 0;
+    TrainState *ts = build_train(h, B, H, W, head_only != 0);
+    h->dry_alloc = false;
+    h->tgt_arena = ta; h->dp_arena = da; h->tgt_arena_bytes = tb; h->dp_arena_bytes = db;   // (the builder points these at its arenas)
+    if (!ts) return -1;
+    *bytes = ts->bytes;
+    ts->bufs.clear();
+    train_free(ts);
+    return 0;
 }
 
 int mc_train_generation(mc_handle *h, unsigned long long *out) {

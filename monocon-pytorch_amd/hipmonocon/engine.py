@@ -174,6 +174,14 @@ class Engine:
         names = ("other", "conv", "wgrad")
         return {k: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": n[i]} for i, k in enumerate(names)}
 
+    def query_workspace(self, B, H, W, mode="train"):
+        """device bytes the plan for this shape needs, without building it (mode: 'infer', 'train', 'head_train')"""
+        out = C.c_size_t(0)
+        m = {"infer": 0, "train": 1, "head_train": 2}[mode]
+        with torch.cuda.device(self.device):
+            _lib.check(self.h, self.lib.mc_query_workspace(self.h, int(B), int(H), int(W), m, C.byref(out)), "mc_query_workspace")
+        return int(out.value)
+
     def workspace_bytes(self):
         return int(self.lib.mc_workspace_bytes(self.h))
 

@@ -15,7 +15,7 @@ NUM_PREDS = 10
 EXPORTS = (
     "mc_create", "mc_destroy", "mc_last_error", "mc_version", "mc_bind_params", "mc_pack_params",
     "mc_forward_infer", "mc_backbone_forward", "mc_neck_forward", "mc_head_forward", "mc_decode", "mc_make_targets", "mc_losses", "mc_losses_backward", "mc_losses_backward_pred", "mc_forward_train", "mc_backward", "mc_train_generation", "mc_head_forward_train", "mc_head_backward", "mc_train_debug_node", "mc_optim_bind", "mc_clip_adamw_step", "mc_op_conv", "mc_op_conv_wgrad", "mc_op_conv_dgrad", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
-    "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_forward_cost",
+    "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_query_workspace", "mc_forward_cost",
     "mc_preprocess", "mc_profile_forward", "mc_profile_train", "mc_set_precision", "mc_set_conv_cfg", "mc_bench_conv", "mc_bench_mfma_peak",
 )
 
@@ -91,6 +91,7 @@ def load():
     lib.mc_op_nchw_to_nhwc.argtypes = [vp, vp, i, i, i, i, vp, vp]
     lib.mc_op_nhwc_to_nchw.argtypes = [vp, vp, i, i, i, i, vp, vp]
     lib.mc_workspace_bytes.argtypes = [vp]
+    lib.mc_query_workspace.argtypes = [vp, i, i, i, i, C.POINTER(C.c_size_t)]
     lib.mc_workspace_bytes.restype = C.c_size_t
     lib.mc_forward_cost.argtypes = [vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.mc_profile_forward.argtypes = [vp, i, fp, C.POINTER(i), vp]

@@ -236,6 +236,33 @@ def test_heads_forward_train_standalone(cond_sd):
         heads.forward_train(fc[:, :32], data)
 
 
+def test_query_workspace_predicts_what_the_plans_allocate(golden_sd):
+    """mc_query_workspace: the dry run of the plan builders reports exactly the bytes the real build
+    allocates afterwards -- inference plan and train plan -- and allocates nothing itself."""
+    from hipmonocon.train import _binding
+    m = build(golden_sd, train=False)
+    eng = m._engine()
+    base = eng.workspace_bytes()
+    q_inf = eng.query_workspace(2, 64, 128, "infer")
+    assert q_inf > 0 and eng.workspace_bytes() == base
+    m({"img": torch.zeros(2, 3, 64, 128, device="cuda")})
+    assert eng.workspace_bytes() - base == q_inf
+    assert eng.query_workspace(2, 64, 128, "infer") == q_inf            # built plan: same answer
+    m.train()
+    tb = _binding(m)
+    eng = m._rt.get(tb.state(m))                                         # binds the "#grad" buffers too
+    base = eng.workspace_bytes()
+    q_tr = eng.query_workspace(3, 64, 128, "train")
+    assert q_tr > q_inf and eng.workspace_bytes() == base
+    _, loss = m(to_cuda(synth.make_batch(9, 3, 64, 128)))
+    assert eng.workspace_bytes() - base == q_tr
+    sum(loss.values()).backward()
+    assert eng.workspace_bytes() - base == q_tr
+    # full size, without building anything: the number DESIGN.md quotes for B=32
+    q32 = eng.query_workspace(32, 384, 1280, "train")
+    assert 40e9 < q32 < 50e9, q32
+
+
 # ------------------------------------------------------------------------------------- guards
 def test_backward_of_a_stale_forward_raises(golden_sd):
     from hipmonocon.lib import MonoconHipError
