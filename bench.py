@@ -189,9 +189,10 @@ def _traffic(family):
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "latest_traffic.json")))
         fam = tj["families"][family]
-        return round((fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]) / 1e6, 1), tj["source"]
+        pmc = {k: round(fam[k], 3) for k in ("mfma_busy", "clock_ghz") if fam.get(k) is not None}
+        return round((fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]) / 1e6, 1), tj["source"], pmc
     except Exception:
-        return None, None
+        return None, None, {}
 
 
 def main():
@@ -316,7 +317,7 @@ def main():
         mi = MODES[mode]
         alg_tf = conv["flops"] / (conv["ms"] * 1e-3) / 1e12            # algorithmic fp32 FLOPs of the family / its time
         exe_tf = alg_tf * mi["mfma_per_mac"]                            # MFMA FLOPs the kernel executes for them
-        traffic, src = _traffic(mi["family"])
+        traffic, src, pmc = _traffic(mi["family"])
         r = {"bound": "mfma", "kernel": "%s: %s" % (mi["family"], n_launch_label),
              "achieved": round(exe_tf, 2), "peak": mi["peak"], "unit": mi["unit"], "frac": round(exe_tf / mi["peak"], 4),
              "traffic": traffic, "traffic_unit": "MB of HBM traffic per launch (PMC)", "traffic_source": src,
@@ -324,6 +325,10 @@ def main():
              "frac_of_fp32_mfma_peak": round(alg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
              "algorithmic_mb_per_launch": round(conv.get("bytes", 0.0) / max(conv["launches"], 1) / 1e6, 1),
              "avg_launch_ms": round(conv["ms"] / max(conv["launches"], 1), 4)}
+        if pmc:   # committed PMC pass of the same command: how busy the matrix pipe is and at which clock the chip sustains it
+            r["pmc"] = dict(pmc, note="SQ_VALU_MFMA_BUSY_CYCLES / SIMD cycles and GRBM_GUI_ACTIVE / time, time-weighted over the "
+                                      "family's launches; frac ~= mfma_busy * clock_ghz / 2.4 -- the matrix kernels of this mode "
+                                      "are power-limited (MI355X_MICROARCH.md, DVFS give-back)")
         return r
 
     def train_report(mode, leg):

@@ -57,8 +57,14 @@ with open(os.path.join(dst, tag + "_pmc.txt"), "w") as f:
 # ---- per-launch HBM traffic of the kernel families (bench.py reports it as roofline.traffic)
 import json
 fam = collections.defaultdict(lambda: [0.0, 0.0, 0, 0.0])
+busy = collections.defaultdict(lambda: [0.0, 0.0, 0.0])     # family -> [sum MFMA-busy cycles, sum SIMD cycles available, sum clock*us]
 for k in sq:
     f_ = re.sub(r"<.*", "", k[0])
+    v = sq[k]
+    gui = v["GRBM_GUI_ACTIVE"] / 8.0
+    busy[f_][0] += v["SQ_VALU_MFMA_BUSY_CYCLES"]
+    busy[f_][1] += 1024.0 * gui
+    busy[f_][2] += dur[k]
     if k in fe and k in wr:
         n = min(len(cf[k]), len(cw[k]))
         fam[f_][0] += 2.0 * fe[k]["FETCH_SIZE"] * 1024.0 / max(len(cf[k]), 1) * n
@@ -68,7 +74,10 @@ for k in sq:
 json.dump({"source": "profiles/%s_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
                      "MI355X_MICROARCH.md gfx950 note, WRITE_SIZE as reported)" % tag,
            "families": {f_: {"hbm_read_bytes_per_launch": v[0] / v[2], "hbm_write_bytes_per_launch": v[1] / v[2],
-                             "launches_sampled": v[2], "avg_us_under_pmc": v[3] / v[2]}
+                             "launches_sampled": v[2], "avg_us_under_pmc": v[3] / v[2],
+                             # time-weighted over all launches of the family in the SQ pass
+                             "mfma_busy": busy[f_][0] / busy[f_][1] if busy[f_][1] else None,
+                             "clock_ghz": busy[f_][1] / 1024.0 / busy[f_][2] / 1e3 if busy[f_][2] else None}
                         for f_, v in fam.items() if v[2] and f_.startswith("mc::")}},
           open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
 # ---- LDS counters (bank conflicts) of the kernels that use the LDS most
