@@ -322,3 +322,38 @@ def test_a_few_optimizer_steps_reduce_the_loss(golden_sd):
         totals.append(float(t))
     assert all(np.isfinite(totals))
     assert totals[-1] < 0.9 * totals[0], totals
+
+
+def test_bf16x3_and_fp32_training_trajectories_agree(cond_sd):
+    """the two fp32 modes as TRAINING paths: five optimizer steps (forward, backward, fused clip + AdamW, schedule) from
+    the same state on the same batches.  The first step's ten losses agree to 1e-5 (round-off only; measured 1.7e-6) and the parameters
+    after it to 1e-3 of their norm (see the comment at the assertion).  From then on the runs separate the way any two fp32 implementations do -- AdamW's
+    first updates are sign-like (m / sqrt(v) ~ +-1), so a gradient that is ~0 in one mode and ~-0 in the other moves
+    that weight by 2*lr -- measured: losses within 2e-2 after five steps; bound asserted: 1e-1, both runs finite."""
+    from solver import AdamW, CyclicScheduler
+    batches = [to_cuda(synth.make_conditioned_batch(900 + i, 4, 64, 128)) for i in range(5)]
+    runs = {}
+    for prec in PRECISIONS:
+        m = build(cond_sd, prec)
+        opt = AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=35.0)
+        sch = CyclicScheduler(opt, total_steps=100)
+        hist, p1 = [], None
+        for i, b in enumerate(batches):
+            opt.zero_grad()
+            _, loss = m(b)
+            sum(loss.values()).backward()
+            opt.step()
+            sch.step()
+            hist.append([float(v.detach()) for v in loss.values()])
+            if i == 0:
+                p1 = torch.cat([p.detach().flatten() for p in m.parameters()]).double().cpu()
+        runs[prec] = (np.array(hist), p1)
+    ha, pa = runs["fp32"]
+    hb, pb = runs["bf16x3"]
+    assert np.all(np.isfinite(ha)) and np.all(np.isfinite(hb))
+    rel = np.abs(ha - hb) / np.maximum(np.abs(ha), 1e-12)
+    assert rel[0].max() < 1e-5, rel[0].max()
+    # AdamW's first step moves every weight by ~lr * sign(g): the ~0.03 % of weights whose gradient is zero up to round-off
+    # take opposite signs in the two modes (measured 2e-4 of the parameter norm = 4 % of the update norm)
+    assert float((pa - pb).norm() / pa.norm()) < 1e-3
+    assert rel.max() < 1e-1, rel.max()
