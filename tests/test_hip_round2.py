@@ -376,3 +376,24 @@ def test_data_parallel_ranks_on_one_device_over_gloo(tmp_path, world):
     errs = "".join(open(os.path.join(tmp_path, f)).read() for f in sorted(os.listdir(tmp_path)) if f.endswith(".err"))
     assert r.returncode == 0, "worker failure:\n" + errs[-4000:] + "\n---- launcher stderr tail ----\n" + r.stderr[-1500:]
     assert r.stdout.count("DP_OK") == world, r.stdout[-2000:]
+
+
+def test_bench_multi_rank_path_end_to_end(tmp_path):
+    """the command the driver's scaling run uses, `python bench.py --gpus N ...`, on a 1-GPU box: two ranks on device 0
+    over gloo (MONOCON_BENCH_BACKEND, a control-flow hook -- not a measurement).  Exercises the self-launch under
+    torch.distributed.run, the rank-0 state broadcast, the in-backward gradient all-reduce, the barrier-bracketed
+    timing with the max over ranks, and the single JSON line of rank 0."""
+    import json
+    env = dict(os.environ, MONOCON_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--height", "64", "--width", "128", "--forward-steps", "2", "--no-cpu-baseline", "--no-extra-modes"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["collective_backend"] == "gloo"
+    assert d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == 2
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 0.02 * d["value"]      # whole-job images / second
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0
