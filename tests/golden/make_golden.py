@@ -234,6 +234,7 @@ def main():
     cond_train(sd_stats=stats)
     dp_shards(sd_stats=stats)
     init_pins()
+    train_full(sd_stats=stats)
 
 
 # ==================================================================== round-2 additions
@@ -319,6 +320,52 @@ def cond_train(sd_stats):
     return picked
 
 
+def train_full(sd_stats, tries=3):
+    """(4c) the headline workload itself: B=2, 384x1280, train mode (batch-statistics BatchNorm), conditioned
+    parameters / images, reference in fp64 -- 10 losses, updated BN buffers, per-tensor gradient norms + strided
+    samples, strided samples of the 10 prediction maps.  A map of 2x16x384x1280 activations cannot be selected
+    flip-free (expected flips ~ N*e/sigma >> 1), but one flip moves a gradient tensor by ~1/sqrt(N) here, so the
+    screening keeps, of ``tries`` seeds, the one whose fp64 gradients move least under a 3e-7 image perturbation,
+    and the fixture RECORDS per tensor (a) that margin and (b) the reference's own fp32-vs-fp64 error -- the
+    yard-sticks the GPU test bounds against."""
+    sd = synth.make_conditioned_state_dict(SEED, bn_stats={k: v.numpy() for k, v in sd_stats.items()})
+    B, H, W = 2, 384, 1280
+    best = None
+    for t in range(tries):
+        seed = 700 + t
+        b = synth.make_conditioned_batch(seed, B, H, W)
+        g64, l64, m64, p64 = _grads(sd, b, True)
+        noise = torch.from_numpy(synth.uniform(seed, "cond.noise", tuple(b["img"].shape), -1.0, 1.0))
+        bp = dict(b)
+        bp["img"] = (b["img"].double() * (1.0 + 3e-7 * noise))
+        g64p = _grads(sd, bp, True)[0]
+        margin = _tensor_errs(g64p, g64)
+        print("train_full seed %d: perturbed-fp64 max %.2e median %.2e" % (seed, max(margin.values()), float(np.median(list(margin.values())))), flush=True)
+        if best is None or max(margin.values()) < max(best[1].values()):
+            new64 = {k: v.clone() for k, v in m64.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+            best = (seed, margin, g64, l64, new64, {k: v.detach().clone() for k, v in p64.items()})
+        del g64p, m64, p64
+    seed, margin, g64, l64, new64, p64 = best
+    b = synth.make_conditioned_batch(seed, B, H, W)
+    g32, l32, _, _ = _grads(sd, b, False)
+    e32 = _tensor_errs(g32, g64)
+    print("train_full: kept seed %d; ref fp32-vs-fp64 max %.2e median %.2e" % (seed, max(e32.values()), float(np.median(list(e32.values())))))
+    out = {"seed": seed, "shape": np.array([B, H, W])}
+    for k in l64:
+        out["f64." + k] = l64[k]
+        out[k] = l32[k]
+    for n in g64:
+        out["gnorm64." + n] = g64[n].norm()
+        out["g64." + n] = gsample(g64[n])
+        out["gerr32." + n] = e32[n]
+        out["gmargin." + n] = margin[n]
+    for k, v in new64.items():
+        out["buf64." + k] = v
+    for k, v in p64.items():
+        out["pred64." + k] = v.reshape(-1)[::sample_step(v.numel(), 4096)].float().clone()
+    save("train_full.npz", **out)
+
+
 def dp_shards(sd_stats):
     """(8) data parallelism: N-rank gradients == mean over ranks of the per-shard gradients (each loss is
     normalised by its *local* object count).  Global batch of 8 at 64x64 split into 2 shards of 4
@@ -369,7 +416,10 @@ def init_pins():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+    if len(sys.argv) > 1 and sys.argv[1] == "train_full":
+        _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
+        train_full(sd_stats=_stats)
+    elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
         cond_train(sd_stats=_stats)
         dp_shards(sd_stats=_stats)

@@ -204,3 +204,22 @@ def test_dp_shard_goldens_world2(cond_sd):
         e = grad_rel_l2(mean[k] / 2, g["w2.g64." + k], g["w2.gnorm64." + k], mean[k].numel())
         # shards are not selected flip-free: bound = the reference's own fp32 deviation on this tensor, x4
         assert e <= 4.0 * float(g["w2.gerr32." + k]) + 2e-3, (k, e, float(g["w2.gerr32." + k]))
+
+
+def test_full_size_train_forward_vs_reference_fp64(cond_sd):
+    """the oracle's train-mode forward at the headline shape (B=2, 384x1280, tests/golden/train_full.npz): ten losses,
+    prediction samples and updated BatchNorm buffers within 1e-4 of the reference's float64 run (forward only -- the
+    full-size backward is checked on the GPU, tests/test_hip_train_full.py)."""
+    g = load_golden("train_full.npz")
+    B, H, W = (int(x) for x in g["shape"])
+    batch = synth.make_conditioned_batch(int(g["seed"]), B, H, W)
+    with torch.no_grad():
+        preds, _, L, newbuf = O.train_forward({k: v.clone() for k, v in cond_sd.items()}, batch)
+    for k, v in L.items():
+        assert abs(float(v) - float(g["f64." + k])) <= 1e-4 * abs(float(g["f64." + k])) + 1e-7, k
+    for k, v in preds.items():
+        step = max(1, v.numel() // 4096)
+        assert rel_err(v.reshape(-1)[::step], g["pred64." + k]) < TOL, k
+    for k, v in newbuf.items():
+        if not k.endswith("num_batches_tracked"):
+            assert rel_err(v, g["buf64." + k]) < 1e-4, k
