@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--forward-steps", type=int, default=10,
                     help="also time this many eval forwards (BASELINE configs[1]); 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
-    ap.add_argument("--precision", default=os.environ.get("MONOCON_BENCH_PRECISION", "bf16x3"), choices=("bf16x3", "fp32"),
+    ap.add_argument("--precision", default=os.environ.get("MONOCON_BENCH_PRECISION", "bf16x3"), choices=("f16x2", "bf16x3", "fp32"),
                     help="precision mode of the headline value: both keep fp32 values and meet the fp32 parity tolerances")
     ap.add_argument("--no-extra-modes", action="store_true",
                     help="skip the fp32_emulated / mixed_precision legs (profiles/collect.sh: keeps the kernel trace on the headline path)")
@@ -177,6 +177,10 @@ MODES = {
                         "fp32 accumulation)",
                "family": "mc::conv_bf16_kernel", "peak": PEAK_BF16_MFMA_TFLOPS, "mfma_per_mac": 6.0,
                "unit": "TFLOP/s (bf16 MFMA executed: 6 partial products per fp32 multiply-add)"},
+    "f16x2": {"dtype": "f32 (f16x2-emulated: fp32 values, conv arithmetic on the fp16 matrix pipe by a 2-way split of the "
+                       "power-of-two-scaled operands, fp32 accumulation)",
+              "family": "mc::conv_bf16_kernel", "peak": PEAK_BF16_MFMA_TFLOPS, "mfma_per_mac": 3.0,
+              "unit": "TFLOP/s (fp16 MFMA executed: 3 partial products per fp32 multiply-add; dense fp16 peak = dense bf16 peak)"},
     "fp32": {"dtype": "f32 (native v_mfma_f32_32x32x2_f32)", "family": "mc::conv_mfma_kernel", "peak": PEAK_FP32_MFMA_TFLOPS,
              "mfma_per_mac": 1.0, "unit": "TFLOP/s"},
     "bf16": {"dtype": "bf16 operands / f32 accumulate", "family": "mc::conv_bf16_kernel", "peak": PEAK_BF16_MFMA_TFLOPS,

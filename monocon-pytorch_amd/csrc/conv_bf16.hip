@@ -27,6 +27,16 @@
 // to large).  Six bf16 MFMAs cost 192 cycles per K=16 against 512 for eight fp32 MFMAs, and the result is as close
 // to the fp64 reference as the fp32 FMA chain (measured: worst prediction map 5.0e-5 vs 5.3e-5, scratch/emu_split.py).
 //
+// SPL = 2 (mc_set_precision(h, 3)): fp32 emulation with HALF the matrix work of SPL = 3.  fp16 carries 11 significant bits
+// against bf16's 8, so TWO pieces already hold 22 bits: x*s = h + l, h = fp16(x*s), l = fp16(x*s - h), and a product
+// needs three partial products (l*h, h*l, h*h -- each exact in the fp32 accumulator) instead of six, two LDS planes
+// instead of three.  fp16's narrow exponent is what the power-of-two scale s is for: every operand TENSOR is scaled so
+// that its max |x| sits in [2^14, 2^15) (ConvArgs::amax_in / amax_w hold the maxima, written by the producers of the
+// tensors; weights are scaled when their panels are packed) and the accumulator is multiplied by the exact inverse
+// 2^-(e_a + e_w) in the epilogue.  Elements below 2^-18 of their tensor's maximum lose relative (not absolute)
+// precision: their absolute error is 2^-40 of the maximum.  Measured through the oracle (scratch/emu_f16x2.py): worst
+// prediction map 5.5e-5 from the fp64 reference (native fp32 5.3e-5, bf16x3 5.0e-5).
+//
 // SPL = 1 is not the parity path: results differ from the fp32 reference by bf16 operand rounding (~1e-3
 // norm-wise per layer); tests/test_hip_bf16.py states the tolerance.  Selected per handle with
 // mc_set_precision(h, 1); layers whose sources are not multiples of 32 channels stay on the fp32 kernels.
@@ -36,6 +46,14 @@ namespace mc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// element type / vectors / MFMA of a split mode: SPL 1, 3 = bf16 pieces, SPL 2 = fp16 pieces
+template <int SPL> struct Piece { typedef __bf16 T; typedef bf16x8 V8; typedef bf16x4 V4; };
+template <> struct Piece<2> { typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4; };
+__device__ __forceinline__ f32x16 mfma_k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma_k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL>
 struct ConvCfgB16 {
@@ -58,6 +76,9 @@ struct ConvCfgB16 {
 template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
 __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kernel(const ConvArgs a) {
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
+    typedef typename Piece<SPL>::T pc_t;
+    typedef typename Piece<SPL>::V8 pc8;
+    typedef typename Piece<SPL>::V4 pc4;
     constexpr int PLANE = Cfg::PLANE_BYTES;
     constexpr int CK = Cfg::CK, PB = Cfg::PB, BNT = Cfg::BNT, NT = Cfg::NT, PAD = Cfg::PAD;
     constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, ROWB = Cfg::ROWB;
@@ -96,7 +117,17 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     // SPL == 3: the five minor partial products (weight <= 2^-8) accumulate apart from the h*h products, so that the
     // main accumulator takes exactly as many additions as the fp32 MFMA path (its round-off, not the exactness of the
     // products, is what limits the emulation) and the minor sum's round-off is 2^-8 smaller; folded in once at the end.
-    constexpr int NACC = SPL == 3 ? 2 : 1;
+    // SPL == 2: operand scale 2^e_a (activations; one scale for all sources of a virtual concat: the largest maximum
+    // decides) and the exact inverse of both scales for the epilogue
+    float a_scale = 1.f, omul = 1.f;
+    if constexpr (SPL == 2) {
+        unsigned am = 0u;
+        for (int i = 0; i < a.nsrc; ++i) { const unsigned v = amax_read(a.amax_in[i]); am = v > am ? v : am; }
+        const int ea = f16_scale_exp(am), ew = f16_scale_exp(*a.amax_w);
+        a_scale = exp2i(ea);
+        omul = exp2i(-ea) * exp2i(-ew);
+    }
+    constexpr int NACC = SPL >= 2 ? 2 : 1;
     f32x16 acc[WTM][WTN], accm[NACC == 2 ? WTM : 1][NACC == 2 ? WTN : 1];
 #pragma unroll
     for (int tm = 0; tm < WTM; ++tm)
@@ -127,7 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     const int w_lane = (g * a.CoutP + n0 + wn * WTN * 32 + li) * 16;   // bytes
 
     constexpr int KSTEPS = CK / 16, NS = Cfg::KH * Cfg::KW * KSTEPS;
-    auto load_b = [&](bf16x8(&dst)[SPL][WTN], int kc, int s) {
+    auto load_b = [&](pc8(&dst)[SPL][WTN], int kc, int s) {
         const int tap = s / KSTEPS, m = s % KSTEPS;
         const int soff = (tap * Cin8 + ((kc + m * 16) >> 3)) * a.CoutP * 16;
 #pragma unroll
@@ -135,20 +166,20 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
             for (int tn = 0; tn < WTN; ++tn)
                 dst[q][tn] = __builtin_bit_cast(
-                    bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, w_lane + tn * 32 * 16, soff + q * w_plane, 0));
+                    pc8, __builtin_amdgcn_raw_buffer_load_b128(r_w, w_lane + tn * 32 * 16, soff + q * w_plane, 0));
     };
-    auto load_a = [&](bf16x8(&dst)[SPL][WTM], int s) {
+    auto load_a = [&](pc8(&dst)[SPL][WTM], int s) {
         const int tap = s / KSTEPS, m = s % KSTEPS;
 #pragma unroll
         for (int q = 0; q < SPL; ++q)
 #pragma unroll
             for (int tm = 0; tm < WTM; ++tm)
-                dst[q][tm] = *reinterpret_cast<const bf16x8 *>(
+                dst[q][tm] = *reinterpret_cast<const pc8 *>(
                     lds_raw + q * PLANE + a_off[tm] +
                     (PLANAR ? 2 * m * CPL + ((tap / Cfg::KW) * RS + (tap % Cfg::KW)) * 16
                             : ((tap / Cfg::KW) * IW + (tap % Cfg::KW)) * ROWB + m * 32));
     };
-    bf16x8 bcur[SPL][WTN];
+    pc8 bcur[SPL][WTN];
     load_b(bcur, 0, 0);
 
     int kbase = 0;
@@ -184,30 +215,30 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                 for (int u = 0; u < UB; ++u) {
                     const int i = i0 + u;
                     if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL)) {
-                        bf16x4 q[SPL];
+                        pc4 q[SPL];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            float r = v[u][j];
+                            float r = SPL == 2 ? v[u][j] * a_scale : v[u][j];
 #pragma unroll
-                            for (int pz = 0; pz < SPL; ++pz) {   // h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
-                                q[pz][j] = (__bf16)r;
+                            for (int pz = 0; pz < SPL; ++pz) {   // h = rnd(x), m = rnd(x - h), l = rnd(x - h - m)
+                                q[pz][j] = (pc_t)r;
                                 r -= (float)q[pz][j];
                             }
                         }
 #pragma unroll
                         for (int pz = 0; pz < SPL; ++pz)
-                            *reinterpret_cast<bf16x4 *>(lds_raw + sdst[i] + pz * PLANE) = q[pz];
+                            *reinterpret_cast<pc4 *>(lds_raw + sdst[i] + pz * PLANE) = q[pz];
                     }
                 }
             }
             __syncthreads();
             const int kc = kbase + c0;
             const int kc_next = (kc + CK < a.Cin) ? kc + CK : kc;
-            bf16x8 acur[SPL][WTM];
+            pc8 acur[SPL][WTM];
             load_a(acur, 0);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                bf16x8 anext[SPL][WTM], bnext[SPL][WTN];
+                pc8 anext[SPL][WTM], bnext[SPL][WTN];
                 if (s + 1 < NS) {
                     load_a(anext, s + 1);
                     load_b(bnext, kc, s + 1);
@@ -216,8 +247,10 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // partial products, smallest first: (piece of A, piece of B) with weight 2^-8*(i+j) >= 2^-16 relative
-                constexpr int NP = SPL == 1 ? 1 : 6;
-                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PBv[6] = {2, 0, 1, 1, 0, 0};
+                // (SPL == 2: l*h, h*l, h*h)
+                constexpr int NP = SPL == 1 ? 1 : (SPL == 2 ? 3 : 6);
+                constexpr int PA[6] = {SPL == 2 ? 1 : 0, SPL == 2 ? 0 : 2, SPL == 2 ? 0 : 1, 0, 1, 0};
+                constexpr int PBv[6] = {SPL == 2 ? 0 : 2, SPL == 2 ? 1 : 0, SPL == 2 ? 0 : 1, 1, 0, 0};
 #pragma unroll
                 for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
@@ -225,11 +258,9 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
                         for (int tn = 0; tn < WTN; ++tn) {
                             if (NACC == 2 && pp < NP - 1)
-                                accm[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[PA[pp]][tm], bcur[PBv[pp]][tn],
-                                                                                       accm[tm][tn], 0, 0, 0);
+                                accm[tm][tn] = mfma_k16(acur[PA[pp]][tm], bcur[PBv[pp]][tn], accm[tm][tn]);
                             else
-                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                    acur[SPL == 1 ? 0 : PA[pp]][tm], bcur[SPL == 1 ? 0 : PBv[pp]][tn], acc[tm][tn], 0, 0, 0);
+                                acc[tm][tn] = mfma_k16(acur[SPL == 1 ? 0 : PA[pp]][tm], bcur[SPL == 1 ? 0 : PBv[pp]][tn], acc[tm][tn]);
                         }
                 if (s + 1 < NS) {
 #pragma unroll
@@ -254,15 +285,31 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accm[tm][tn][r];
     }
-    conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
+    conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li, omul);
 }
 
 // ---- weight packing: OIHW fp32 -> [tap][Cin/8][CoutP][8] bf16 (forward) and the dgrad variants
 // (transposed + flipped per source, or one output-parity class of a stride-2 data gradient; same tap
 // conventions as pack_conv_w_kernel / pack_conv_w_dgrad_kernel)
-__global__ void pack_conv_w_bf16_kernel(const float *__restrict__ w, int Cout, int Cin, int k, __bf16 *__restrict__ dst,
-                                        int CinPanel, int CoutP, int n_off, int c_off, int nsplit) {
+// nsplit == 2: fp16 pieces of w * 2^e_w (e_w from the weight tensor's max |w|, `amax`), else bf16 pieces of w
+__device__ __forceinline__ void store_pieces(float r, unsigned short *dst, size_t plane, int nsplit) {
+    if (nsplit == 2) {
+        const _Float16 hi = (_Float16)r;
+        const _Float16 lo = (_Float16)(r - (float)hi);
+        dst[0] = __builtin_bit_cast(unsigned short, hi);
+        dst[plane] = __builtin_bit_cast(unsigned short, lo);
+    } else {
+        for (int q = 0; q < nsplit; ++q) {
+            const __bf16 piece = (__bf16)r;
+            dst[q * plane] = __builtin_bit_cast(unsigned short, piece);
+            r -= (float)piece;
+        }
+    }
+}
+__global__ void pack_conv_w_bf16_kernel(const float *__restrict__ w, int Cout, int Cin, int k, unsigned short *__restrict__ dst,
+                                        int CinPanel, int CoutP, int n_off, int c_off, int nsplit, const unsigned *amax) {
     const size_t plane = (size_t)k * k * CinPanel * CoutP;
+    const float wscale = nsplit == 2 ? exp2i(f16_scale_exp(*amax)) : 1.f;
     const int kk = k * k;
     const size_t total = (size_t)Cout * Cin * kk;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -270,25 +317,23 @@ __global__ void pack_conv_w_bf16_kernel(const float *__restrict__ w, int Cout, i
         const int c = (e / kk) % Cin;
         const int n = e / ((size_t)kk * Cin);
         const int cc = c + c_off, nn = n + n_off;
-        float r = w[e];
-        for (int q = 0; q < nsplit; ++q) {
-            const __bf16 piece = (__bf16)r;
-            dst[q * plane + (((size_t)tap * (CinPanel >> 3) + (cc >> 3)) * CoutP + nn) * 8 + (cc & 7)] = piece;
-            r -= (float)piece;
-        }
+        store_pieces(w[e] * wscale, dst + (((size_t)tap * (CinPanel >> 3) + (cc >> 3)) * CoutP + nn) * 8 + (cc & 7), plane, nsplit);
     }
 }
 hipError_t launch_pack_conv_w_bf16(const float *w, int Cout, int Cin, int k, void *dst, int CinPanel, int CoutP, int n_off,
-                                   int c_off, int nsplit, hipStream_t st) {
+                                   int c_off, int nsplit, hipStream_t st, const unsigned *amax) {
+    if (nsplit == 2 && !amax) return hipErrorInvalidValue;
     const size_t total = (size_t)Cout * Cin * k * k;
     size_t gsz = (total + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(pack_conv_w_bf16_kernel, dim3((unsigned)gsz), dim3(256), 0, st, w, Cout, Cin, k,
-                       static_cast<__bf16 *>(dst), CinPanel, CoutP, n_off, c_off, nsplit);
+                       static_cast<unsigned short *>(dst), CinPanel, CoutP, n_off, c_off, nsplit, amax);
     return hipGetLastError();
 }
 __global__ void pack_conv_w_dgrad_bf16_kernel(const float *__restrict__ w, int Cout, int CinTotal, int k, int c_off, int Cs,
-                                              int CsP, int CoutPad, int cls, int nsplit, __bf16 *__restrict__ dst) {
+                                              int CsP, int CoutPad, int cls, int nsplit, unsigned short *__restrict__ dst,
+                                              const unsigned *amax) {
+    const float wscale = nsplit == 2 ? exp2i(f16_scale_exp(*amax)) : 1.f;
     const size_t plane = (size_t)(cls < 0 ? k * k : (1 + (cls >> 1)) * (1 + (cls & 1))) * CoutPad * CsP;
     const int kk = k * k;
     const size_t total = (size_t)Cout * Cs * kk;
@@ -306,21 +351,18 @@ __global__ void pack_conv_w_dgrad_bf16_kernel(const float *__restrict__ w, int C
             const int dr = py ? (2 - r) / 2 : 0, ds = px ? (2 - s) / 2 : 0;
             tapd = dr * (1 + px) + ds;
         }
-        float rem = w[(((size_t)n * CinTotal + c_off + cl) * k + r) * k + s];
-        for (int q = 0; q < nsplit; ++q) {
-            const __bf16 piece = (__bf16)rem;
-            dst[q * plane + (((size_t)tapd * (CoutPad >> 3) + (n >> 3)) * CsP + cl) * 8 + (n & 7)] = piece;
-            rem -= (float)piece;
-        }
+        const float rem = w[(((size_t)n * CinTotal + c_off + cl) * k + r) * k + s] * wscale;
+        store_pieces(rem, dst + (((size_t)tapd * (CoutPad >> 3) + (n >> 3)) * CsP + cl) * 8 + (n & 7), plane, nsplit);
     }
 }
 hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
-                                         int cls, int nsplit, void *dst, hipStream_t st) {
+                                         int cls, int nsplit, void *dst, hipStream_t st, const unsigned *amax) {
+    if (nsplit == 2 && !amax) return hipErrorInvalidValue;
     const size_t total = (size_t)Cout * Cs * k * k;
     size_t gsz = (total + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(pack_conv_w_dgrad_bf16_kernel, dim3((unsigned)gsz), dim3(256), 0, st, w, Cout, CinTotal, k, c_off, Cs,
-                       CsP, CoutPad, cls, nsplit, static_cast<__bf16 *>(dst));
+                       CsP, CoutPad, cls, nsplit, static_cast<unsigned short *>(dst), amax);
     return hipGetLastError();
 }
 
@@ -366,6 +408,11 @@ static hipError_t launch_b16_shape(const ConvArgs &a, hipStream_t st, ConvArgs *
 
 bool conv_bf16_ok(const ConvArgs &a, int ks, int stride) {
     if (!a.wpk16) return false;
+    if (a.prec == 3) {       // the fp16 split needs the maxima of every operand tensor
+        if (!a.amax_w) return false;
+        for (int i = 0; i < a.nsrc; ++i)
+            if (!a.amax_in[i]) return false;
+    }
     for (int i = 0; i < a.nsrc; ++i)
         if (a.src[i].C % 32) return false;
     if (ks == 3) return stride == 1 || stride == 2;
@@ -384,6 +431,7 @@ static hipError_t launch_conv_b16_spl(const ConvArgs &a, int ks, int stride, hip
 
 hipError_t launch_conv_bf16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
     if (!conv_bf16_ok(a, ks, stride)) return hipErrorInvalidValue;
+    if (a.prec == 3) return launch_conv_b16_spl<2>(a, ks, stride, st, resolved);
     return a.prec == 2 ? launch_conv_b16_spl<3>(a, ks, stride, st, resolved) : launch_conv_b16_spl<1>(a, ks, stride, st, resolved);
 }
 

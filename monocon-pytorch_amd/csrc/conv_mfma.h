@@ -76,7 +76,66 @@ struct ConvArgs {
     const float *bm_z;       // post-BN map z (mask z > 0), bm_relu == 1
     const float *bm_a, *bm_b;// forward BN coefficients (mask fma(y, a, b) > 0, bit-identical to z > 0), bm_relu == 2
     int bm_relu;             // 0: no ReLU (no mask), 1, 2
+    // prec 3 (conv_bf16.hip, fp32 emulated by a 2-way fp16 split): both operands are scaled by a power of two derived
+    // from their tensor's max |x| so that they sit in fp16's range; the slots hold the BIT PATTERN of that maximum
+    // (a non-negative float orders like its bits), written by whoever produced the tensor (amax_update_* below; a
+    // tensor's slot is AMAX_SUB sub-slots, a weight's slot one word)
+    const unsigned *amax_in[4];   // per source of the virtual concat
+    const unsigned *amax_w;       // of the master weight(s) the panel was cut from
+    unsigned *amax_out;           // optional: max |out| of this launch is folded in (eval plans: the consumer's amax_in)
 };
+
+// ---- power-of-two operand scaling of the fp16-split mode ---------------------------------------------------------
+// scale exponent of a tensor whose max |x| has the bit pattern `amax_bits`: max |x| * 2^e lands in [2^14, 2^15) (fp16
+// overflows at 65504).  An all-zero (or denormal-max) tensor keeps e = 0; e stays within what exp2i() can represent.
+// The output rescale is formed as the PRODUCT 2^-e_a * 2^-e_w, which leaves the float range only where the true
+// result does.
+__host__ __device__ __forceinline__ int f16_scale_exp(unsigned amax_bits) {
+    const int E = (int)((amax_bits >> 23) & 0xffu);
+    if (E == 0) return 0;
+    const int e = 141 - E;
+    return e > 126 ? 126 : e;
+}
+__host__ __device__ __forceinline__ float exp2i(int e) {     // 2^e, -126 <= e <= 127
+    const unsigned u = (unsigned)(127 + e) << 23;
+    return __builtin_bit_cast(float, u);
+}
+// ---- the max-|x| slots ------------------------------------------------------------------------------------------
+// A tensor's slot is AMAX_SUB words, AMAX_STRIDE words (256 bytes) apart; its maximum is the largest of them.  Every
+// workgroup of a producing launch folds its own maximum into sub-slot (blockIdx.x % AMAX_SUB), and only when that can
+// still raise it (a relaxed read first; a stale value merely costs a redundant atomic).  Why not one word and one
+// atomic per lane: measured (round 3, rocprofv3) -- ~32 k same-address requests per launch serialise in one L2 channel
+// at ~1.5 ns each: +55 us on a 55 us element-wise pass.  One request per workgroup, spread over 16 channels, is noise.
+// Inf / NaN never enter a slot (they propagate through the data instead).  Weight slots are single words (amax_w).
+constexpr int AMAX_SUB = 16, AMAX_STRIDE = 64, AMAX_WORDS = AMAX_SUB * AMAX_STRIDE;
+__device__ __forceinline__ void amax_commit(unsigned *slot, unsigned bits) {       // call from ONE lane per workgroup / wave
+    unsigned *p = slot + (blockIdx.x % AMAX_SUB) * AMAX_STRIDE;
+    if (bits < 0x7f800000u && bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);
+}
+// every thread of the workgroup calls this (partially filled waves are fine: the reduction goes through LDS atomics)
+__device__ __forceinline__ void amax_update_block(unsigned *slot, float v) {
+    __shared__ unsigned s_amax;
+    if (threadIdx.x == 0) s_amax = 0u;
+    __syncthreads();
+    const unsigned bits = __builtin_bit_cast(unsigned, v);
+    if (bits < 0x7f800000u && bits != 0u) atomicMax(&s_amax, bits);
+    __syncthreads();
+    if (threadIdx.x == 0) amax_commit(slot, s_amax);
+}
+// full 64-lane waves only (the MFMA kernels' epilogues): one commit per wave
+__device__ __forceinline__ void amax_update_wave(unsigned *slot, float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) amax_commit(slot, __builtin_bit_cast(unsigned, v));
+}
+// the tensor's maximum (bit pattern), wave-uniform; full 64-lane waves only
+__device__ __forceinline__ unsigned amax_read(const unsigned *slot) {
+    const int lane = threadIdx.x & 63;
+    unsigned v = lane < AMAX_SUB ? slot[lane * AMAX_STRIDE] : 0u;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
 
 // Filter window code KS: 3 = 3x3 (pad 1), 1 = 1x1; 12 / 21 / 22 = 1x2, 2x1, 2x2 windows without padding --
 // the four output-parity classes of a stride-2 3x3 data gradient (dX[2i+py][2j+px] only sees the taps
@@ -144,8 +203,11 @@ __device__ __forceinline__ int xcd_order(int b, int n) {
 // = (oy0 + (r>>2), ox0 + (r&3) + 4*(lane>>5)).
 template <int WM, int WN, int WTM, int WTN, int BNT, bool BM = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[WTM][WTN], const int *pinfo,
-                                              int patch0, int img, int n0, int wm, int wn, int g, int li) {
+                                              int patch0, int img, int n0, int wm, int wn, int g, int li,
+                                              float omul = 1.f) {
+    // omul: power-of-two rescale of the accumulator (fp16-split mode: undoes the operand scaling, exact); 1 otherwise
     const bool do_stats = a.stats != nullptr;
+    float vmax = 0.f;                            // max |stored value| of this lane (ConvArgs::amax_out)
     const bool has_res = a.res != nullptr;
     constexpr bool bm = BM;                      // backward-statistics mode (see ConvArgs): its own instantiation
     const int bm_relu = a.bm_relu;
@@ -163,7 +225,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
     for (int tn = 0; tn < WTN; ++tn) {
         const int n = n0 + (wn * WTN + tn) * 32 + li;
         const bool nok = n < a.Cout;
-        const float sc = (a.scale && nok) ? a.scale[n] : 1.f;
+        const float sc = ((a.scale && nok) ? a.scale[n] : 1.f) * omul;
         const float bi = (a.bias && nok) ? a.bias[n] : 0.f;
         const float sh = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
         const float ma = (bm && bm_relu == 2 && nok) ? a.bm_a[n] : 0.f;
@@ -214,6 +276,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         ssq += d * d;
                     }
                     v = fmaxf(v, floor_v);
+                    vmax = fmaxf(vmax, fabsf(v));
                     buf_store1(v, r_out, v_out, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
                 }
             } else {
@@ -237,6 +300,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                             ssq += d * d;
                         }
                         v = fmaxf(v, floor_v);
+                        vmax = fmaxf(vmax, fabsf(v));
                         buf_store1(v, r_out, (y * a.o_row + x * a.o_px + a.out_coff + n) * 4, 0);
                     }
                 }
@@ -252,6 +316,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
             }
         }
     }
+    if (a.amax_out) amax_update_wave(a.amax_out, vmax);
 }
 
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN, bool BM = false>
@@ -639,10 +704,15 @@ inline int conv_chunks_per_image(int cfg, int Hout, int Wout) {
 bool conv_small_ok(const ConvArgs &a, int ks, int stride);
 bool conv_bf16_ok(const ConvArgs &a, int ks, int stride);
 hipError_t launch_conv_bf16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved);
+// nsplit: 1 = bf16, 3 = three bf16 pieces, 2 = two fp16 pieces of w * 2^e_w (amax: the weight tensor's max |w|, see ConvArgs)
 hipError_t launch_pack_conv_w_bf16(const float *w, int Cout, int Cin, int k, void *dst, int CinPanel, int CoutP, int n_off,
-                                   int c_off, int nsplit, hipStream_t st);
+                                   int c_off, int nsplit, hipStream_t st, const unsigned *amax = nullptr);
 hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
-                                         int cls, int nsplit, void *dst, hipStream_t st);
+                                         int cls, int nsplit, void *dst, hipStream_t st, const unsigned *amax = nullptr);
+// max |x| of a dense fp32 tensor folded into *slot (bit pattern; the caller zeroes the slot): for tensors that enter the
+// fp16-split mode from outside the plans' own producers (op-level entry points, stage-level forwards)
+// (single_word: a weight slot -- one word; otherwise a tensor slot of AMAX_WORDS words)
+hipError_t launch_absmax(const float *x, size_t n, unsigned *slot, hipStream_t st, bool single_word = false);
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st);
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);

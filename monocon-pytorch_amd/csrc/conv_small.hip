@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     }
     const bool do_stats = a.stats != nullptr, has_res = a.res != nullptr;
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
+    float vmax = 0.f;                 // max |out| of this lane (ConvArgs::amax_out)
 
     const int vx = (li * S * CIN + kq * 4) * 4;                     // input lane offset inside a group
     constexpr int NR = (S == 1 && CIN == 16) ? 2 : 1;               // output rows per pass: a pair shares 2 of its 4 input rows
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
                             ssq[q][nt] += d * d;
                         }
                         v = fmaxf(v, floor_v);
+                        vmax = fmaxf(vmax, nok[nt] ? fabsf(v) : 0.f);
                         buf_store1(v, r_out[q], v_out, (x0 + e) * a.out_ld * 4);
                     }
                 }
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
             }
         }
     }
+    if (a.amax_out) amax_update_wave(a.amax_out, vmax);
 }
 
 bool conv_small_ok(const ConvArgs &a, int ks, int stride) {

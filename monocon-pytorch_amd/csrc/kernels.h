@@ -39,7 +39,7 @@ hipError_t launch_stem(const float *img_nchw, int B, int H, int W, const float *
                        const float *shift, float *out_nhwc, hipStream_t st, int relu = 1);
 hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out,
-                          hipStream_t st);
+                          hipStream_t st, unsigned *amax = nullptr);   // amax: max |out| folded into the slot (conv_mfma.h)
 hipError_t launch_nchw_to_nhwc(const float *in, int B, int C, int H, int W, float *out, hipStream_t st);
 hipError_t launch_nhwc_to_nchw(const float *in, int B, int C, int H, int W, float *out, hipStream_t st);
 

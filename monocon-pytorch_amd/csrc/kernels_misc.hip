@@ -2,6 +2,7 @@
 // 4x4 transposed convolution, layout transposes and the attentive-norm dense-head passes.
 // All activations are NHWC fp32; every kernel is bandwidth-bound and written for 16-byte
 // per-lane accesses.
+#include <algorithm>
 #include "kernels.h"
 #include "conv_mfma.h"
 
@@ -197,9 +198,10 @@ hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *o
 // depthwise ConvTranspose2d(k=4, s=2, p=1): out[oy,ox] = sum over the <=2x2 inputs with
 // oy = 2*iy - 1 + ky (reference model/backbone/dla_neck.py:58-65)
 __global__ void deconv4_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4,
-                               const f32x4 *__restrict__ wpk, f32x4 *__restrict__ out) {
+                               const f32x4 *__restrict__ wpk, f32x4 *__restrict__ out, unsigned *__restrict__ amax) {
     const int Ho = 2 * H, Wo = 2 * W;
     const size_t total = (size_t)B * Ho * Wo * C4;
+    float vmax = 0.f;          // max |out| of this thread (amax != null, see ConvArgs::amax_in)
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int c = e % C4;
         const size_t p = e / C4;
@@ -222,13 +224,46 @@ __global__ void deconv4_kernel(const f32x4 *__restrict__ in, int B, int H, int W
             }
         }
         out[e] = acc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(acc[j]));
     }
+    if (amax) amax_update_block(amax, vmax);
 }
-hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out, hipStream_t st) {
+hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out, hipStream_t st,
+                          unsigned *amax) {
     const size_t total = (size_t)B * 4 * H * W * (C / 4);
     hipLaunchKernelGGL(deconv4_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st,
                        reinterpret_cast<const f32x4 *>(in), B, H, W, C / 4, reinterpret_cast<const f32x4 *>(wpk),
-                       reinterpret_cast<f32x4 *>(out));
+                       reinterpret_cast<f32x4 *>(out), amax);
+    return hipGetLastError();
+}
+
+// max |x| of a dense tensor -> *slot (bit pattern of a non-negative float; see amax_update): the operand-scale input of
+// the fp16-split mode for tensors that come from outside the plans' own producers
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, unsigned *__restrict__ slot, int single) {
+    float vmax = 0.f;
+    const size_t n4 = n / 4;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x);
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = x4[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(v[j]));
+    }
+    for (size_t e = n4 * 4 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        vmax = fmaxf(vmax, fabsf(x[e]));
+    if (!single) { amax_update_block(slot, vmax); return; }
+    __shared__ unsigned s_max;                   // single-word slot (a weight's maximum)
+    if (threadIdx.x == 0) s_max = 0u;
+    __syncthreads();
+    const unsigned bits = __builtin_bit_cast(unsigned, vmax);
+    if (bits < 0x7f800000u && bits != 0u) atomicMax(&s_max, bits);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max != 0u) atomicMax(slot, s_max);
+}
+hipError_t launch_absmax(const float *x, size_t n, unsigned *slot, hipStream_t st, bool single_word) {
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(absmax_kernel, dim3(std::min(grid_for(n / 4 + 1, 256), single_word ? 64 : 2048)), dim3(256), 0, st, x, n, slot,
+                       single_word ? 1 : 0);
     return hipGetLastError();
 }
 

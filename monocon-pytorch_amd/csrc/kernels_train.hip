@@ -243,11 +243,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
                                                          const float *__restrict__ bb, const f32x4 *__restrict__ res,
                                                          int C4, int RG, int rows_per_img, int blocks_per_img,
                                                          int rows_per_block, int per_sample, int relu,
-                                                         f32x4 *__restrict__ z) {
+                                                         f32x4 *__restrict__ z, unsigned *__restrict__ amax) {
     const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
     const int b = blockIdx.x / blocks_per_img, rb = blockIdx.x % blocks_per_img;
     const int r0 = rb * rows_per_block, r1 = min(rows_per_img, r0 + rows_per_block);
     const int ci = (per_sample ? b * C4 : 0) + c4;
+    float vmax = 0.f;            // max |z| of this thread (amax != null: the consumers' fp16-split operand scale)
     const f32x4 av = reinterpret_cast<const f32x4 *>(a)[ci], bv = reinterpret_cast<const f32x4 *>(bb)[ci];
     const float fl = relu ? 0.f : -__builtin_inff();
     const unsigned base = ((unsigned)b * rows_per_img) * C4 + c4;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
                 float t = fmaf(v[u][j], av[j], bv[j]);
                 if (res) t += q[u][j];
                 v[u][j] = fmaxf(t, fl);
+                vmax = fmaxf(vmax, fabsf(v[u][j]));
             }
             z[e + u * step] = v[u];
         }
@@ -281,18 +283,20 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
             float t = fmaf(v[j], av[j], bv[j]);
             if (res) t += res[e][j];
             v[j] = fmaxf(t, fl);
+            vmax = fmaxf(vmax, fabsf(v[j]));
         }
         z[e] = v;
     }
+    if (amax) amax_update_block(amax, vmax);
 }
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
-                             int C, int per_sample, int relu, float *z, hipStream_t st) {
+                             int C, int per_sample, int relu, float *z, hipStream_t st, unsigned *amax) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
     if (dbg_skip("aact")) return hipSuccess;
     const RowSplit rs = row_split(B, rows_per_img, C / 4);
     hipLaunchKernelGGL(affine_act_kernel, dim3(B * rs.blocks_per_img), dim3(rs.threads), 0, st,
                        reinterpret_cast<const f32x4 *>(y), a, b, reinterpret_cast<const f32x4 *>(res), C / 4, rs.rg,
-                       (int)rows_per_img, rs.blocks_per_img, rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(z));
+                       (int)rows_per_img, rs.blocks_per_img, rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(z), amax);
     return hipGetLastError();
 }
 
@@ -355,8 +359,10 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
                                                          int rows_per_block, int per_sample, int relu,
                                                          f32x4 *__restrict__ dy, f32x4 *__restrict__ gres, int gres_mode,
                                                          const float *__restrict__ fa, const float *__restrict__ fb,
-                                                         float *__restrict__ csum /*[blocks][4*C4][2] or null*/) {
+                                                         float *__restrict__ csum /*[blocks][4*C4][2] or null*/,
+                                                         unsigned *__restrict__ amax /*max |dy| or null*/) {
     __shared__ f32x4 cred[256];
+    float vmax = 0.f;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};      // column sums of dy over this thread's rows (conv bias gradient), csum != null
     const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
     const int b = blockIdx.x / blocks_per_img, rb = blockIdx.x % blocks_per_img;
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
             else if (relu == 2) d[j] = fmaf(yv[j], ma[j], mb[j]) > 0.f ? d[j] : 0.f;
             o[j] = fmaf(cp[j], d[j], fmaf(cq[j], yv[j], cr[j]));
             cs[j] += o[j];
+            vmax = fmaxf(vmax, fabsf(o[j]));
         }
         dy[e] = o;
         if (gres_mode == 1) gres[e] = d;
@@ -422,11 +429,12 @@ __global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict
             for (int j = 0; j < 4; ++j) csum[((size_t)blockIdx.x * (4 * C4) + c4 * 4 + j) * 2] = cs[j];
         }
     }
+    if (amax) amax_update_block(amax, vmax);
 }
 int affine_bwd_blocks(int B, size_t rows_per_img, int C) { return B * row_split(B, rows_per_img, C / 4).blocks_per_img; }
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st,
-                             const float *fa, const float *fb, float *csum, float *csum_out) {
+                             const float *fa, const float *fb, float *csum, float *csum_out, unsigned *amax) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
     if (relu == 2 && (!fa || !fb || per_sample)) return hipErrorInvalidValue;
     if (dbg_skip("abwd")) return hipSuccess;
@@ -435,7 +443,7 @@ hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, co
                        reinterpret_cast<const f32x4 *>(dz), reinterpret_cast<const f32x4 *>(z),
                        reinterpret_cast<const f32x4 *>(y), coef, C / 4, rs.rg, (int)rows_per_img, rs.blocks_per_img,
                        rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(dy), reinterpret_cast<f32x4 *>(gres),
-                       gres_mode, fa, fb, csum);
+                       gres_mode, fa, fb, csum, amax);
     if (csum && csum_out)     // column sums of dy: the partial rows of the launch above, finished per column
         hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, st, csum, B * rs.blocks_per_img, C, csum_out);
     return hipGetLastError();

@@ -127,6 +127,15 @@ static int build_layers(mc_handle *h) {
     if (dev_alloc(h, &h->head_w1, NUM_OUT_ROWS * HEAD_CH, h->param_bufs, h->param_bytes)) return -1;
     if (dev_alloc(h, &h->head_w1t, NUM_OUT_ROWS * HEAD_CH, h->param_bufs, h->param_bytes)) return -1;
     if (dev_alloc(h, &h->head_b1, NUM_OUT_ROWS, h->param_bufs, h->param_bytes)) return -1;
+    {   // precision mode 3: one max-|w| slot per conv layer + one for the fused head panel
+        float *q = nullptr;
+        h->w_amax_n = (int)h->convs.size() + 1;
+        if (dev_alloc(h, &q, (size_t)h->w_amax_n, h->param_bufs, h->param_bytes)) return -1;
+        h->w_amax_arena = reinterpret_cast<unsigned *>(q);
+        int i = 0;
+        for (auto &kv : h->convs) kv.second.w_amax = h->w_amax_arena + i++;
+        H3.w_amax = h->w_amax_arena + i;
+    }
     HIPCHK(h, hipDeviceSynchronize());   // zero-fills above ran on the null stream
     h->layers_built = true;
     return 0;
@@ -157,10 +166,20 @@ struct Builder {
     bool ok = true;
     std::map<const float *, Tensor> pooled;   // max-pool de-duplication (nested trees re-pool the same input)
 
+    static constexpr int AMAX_SLOTS = 256;
     Tensor alloc(int B, int H, int W, int C) {
         Tensor t;
         t.B = B; t.H = H; t.W = W; t.C = C;
         if (dev_alloc(h, &t.p, t.numel(), pl->bufs, pl->bytes)) ok = false;
+        if (h->prec == 3) {        // max-|x| slot of the tensor (operand scale of the convs that read it)
+            if (!pl->amax_arena) {
+                float *q = nullptr;
+                if (dev_alloc(h, &q, (size_t)AMAX_SLOTS * AMAX_WORDS, pl->bufs, pl->bytes)) ok = false;
+                pl->amax_arena = reinterpret_cast<unsigned *>(q);
+            }
+            if (pl->amax_used >= AMAX_SLOTS) { ok = false; h->err = "plan: amax slot table overflow"; }
+            else if (pl->amax_arena) t.amax = pl->amax_arena + (size_t)(pl->amax_used++) * AMAX_WORDS;
+        }
         return t;
     }
     float *alloc_raw(size_t n) {
@@ -195,6 +214,11 @@ struct Builder {
         a.Cin = cin; a.Cout = L.cout; a.CoutP = L.coutp;
         a.wpk = L.wpk;
         a.wpk16 = L.wpk16; a.prec = h->prec;
+        if (h->prec == 3) {
+            for (int i = 0; i < a.nsrc; ++i) a.amax_in[i] = srcs[i].amax;
+            a.amax_w = L.w_amax;
+            a.amax_out = out.amax;
+        }
         a.scale = use_layer_affine ? L.scale : scale;
         a.bias = use_layer_affine ? L.shift : shift;
         a.res = res ? res->p : nullptr;
@@ -219,6 +243,7 @@ struct Builder {
         auto it = pooled.find(x.p);
         if (it != pooled.end()) return it->second;
         Tensor o = alloc(x.B, x.H / 2, x.W / 2, x.C);
+        o.amax = x.amax;           // max |pool(x)| <= max |x|: the input's slot serves
         Op op{};
         op.kind = OP_POOL;
         op.in = x.p; op.out = o.p; op.B = x.B; op.H = x.H; op.W = x.W; op.C = x.C;
@@ -233,6 +258,7 @@ struct Builder {
         Op op{};
         op.kind = OP_DECONV;
         op.in = x.p; op.out = o.p; op.w = D.wpk; op.B = x.B; op.H = x.H; op.W = x.W; op.C = x.C;
+        op.amax = o.amax;
         op.flops = 2.0 * 4.0 * (double)o.numel();
         op.bytes = 4.0 * ((double)x.numel() + (double)o.numel());
         pl->ops.push_back(op);
@@ -440,6 +466,18 @@ static Plan *get_plan(mc_handle *h, int B, int H, int W) {
     return ret;
 }
 
+// precision mode 3: the max-|x| slots of a plan's tensors start every forward at zero (producers only raise them)
+static int plan_reset_amax(mc_handle *h, Plan *pl, hipStream_t st) {
+    if (pl->amax_arena && pl->amax_used)
+        HIPCHK(h, hipMemsetAsync(pl->amax_arena, 0, (size_t)pl->amax_used * AMAX_WORDS * sizeof(unsigned), st));
+    return 0;
+}
+// ... and a tensor that enters a plan from outside (stage-level forwards) gets its maximum from a pass of its own
+static int plan_absmax(mc_handle *h, const Tensor &t, hipStream_t st) {
+    if (t.amax) HIPCHK(h, launch_absmax(t.p, t.numel(), t.amax, st));
+    return 0;
+}
+
 static int run_op(mc_handle *h, const Op &op, hipStream_t st) {
     switch (op.kind) {
         case OP_STEM:
@@ -452,7 +490,7 @@ static int run_op(mc_handle *h, const Op &op, hipStream_t st) {
             HIPCHK(h, launch_maxpool2(op.in, op.B, op.H, op.W, op.C, op.out, st));
             break;
         case OP_DECONV:
-            HIPCHK(h, launch_deconv4(op.in, op.B, op.H, op.W, op.C, op.w, op.out, st));
+            HIPCHK(h, launch_deconv4(op.in, op.B, op.H, op.W, op.C, op.w, op.out, st, op.amax));
             break;
         case OP_HEAD_ATTN:
             HIPCHK(h, launch_head_attn(op.in, op.B, op.chunks, op.H * op.W, h->hap, op.out,
@@ -516,7 +554,12 @@ int mc_create(int device, mc_handle **out) {
     mc_handle *h = new mc_handle();
     h->device = device;
     if (const char *e = std::getenv("MONOCON_HIP_AUTOTUNE")) h->autotune = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MONOCON_HIP_PRECISION")) h->prec = (std::strcmp(e, "bf16") == 0 || std::strcmp(e, "1") == 0) ? 1 : ((std::strcmp(e, "bf16x3") == 0 || std::strcmp(e, "2") == 0) ? 2 : 0);
+    if (const char *e = std::getenv("MONOCON_HIP_PRECISION")) {
+        if (std::strcmp(e, "bf16") == 0 || std::strcmp(e, "1") == 0) h->prec = 1;
+        else if (std::strcmp(e, "bf16x3") == 0 || std::strcmp(e, "2") == 0) h->prec = 2;
+        else if (std::strcmp(e, "f16x2") == 0 || std::strcmp(e, "3") == 0) h->prec = 3;
+        else h->prec = 0;
+    }
     load_tune_cache(h);
     *out = h;
     return 0;
@@ -567,11 +610,15 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
     if (!has_bb && !has_neck && !has_head) return fail(h, "mc_pack_params: no backbone./neck./head. parameters bound");
     const bool rebuild = h->pack_tab_gen != h->bind_gen || h->pack_tab_prec != h->prec;
     if (rebuild) { h->fwd_pack.clear(); h->folds.clear(); }
-    auto add_fwd = [&](const float *w, int Cout, int Cin, int ks, float *dst32, void *dst16, int CinPanel, int CoutP, int n_off) {
+    if (rebuild) h->w_amax_of.clear();
+    auto add_fwd = [&](const float *w, int Cout, int Cin, int ks, float *dst32, void *dst16, int CinPanel, int CoutP, int n_off,
+                       unsigned *amax) {
         mc::PackJobDesc j{};
         j.w = w; j.dst32 = dst32; j.dst16 = (h->prec >= 1 && CinPanel % 8 == 0) ? dst16 : nullptr;
         j.kind = 0; j.Cout = Cout; j.Cin = Cin; j.k = ks; j.CinTotal = CinPanel; j.CoutP = CoutP; j.n_off = n_off; j.c_off = 0;
-        j.nsplit = h->prec == 2 ? 3 : 1; j.cls = -1;
+        j.nsplit = h->prec == 2 ? 3 : (h->prec == 3 ? 2 : 1); j.cls = -1;
+        j.amax = amax;
+        h->w_amax_of[w] = amax;
         h->fwd_pack.add(j);
     };
     for (auto &kv : h->convs) {
@@ -580,7 +627,7 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         const bool is_bb = L.conv.compare(0, 9, "backbone.") == 0;
         if ((is_bb && !has_bb) || (!is_bb && !has_neck)) continue;
         NEEDP(w, L.conv + ".weight", (int64_t)L.cout * L.cin * L.ks * L.ks);
-        add_fwd(w, L.cout, L.cin, L.ks, L.wpk, L.wpk16, L.cin, L.coutp, 0);
+        add_fwd(w, L.cout, L.cin, L.ks, L.wpk, L.wpk16, L.cin, L.coutp, 0, L.w_amax);
         NEEDP(g, L.bn + ".weight", L.cout);
         NEEDP(b, L.bn + ".bias", L.cout);
         NEEDP(rm, L.bn + ".running_mean", L.cout);
@@ -611,7 +658,7 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         const std::string pre = std::string("head.") + HEAD_NAMES[hd];
         NEEDP(w3, pre + ".0.weight", 64 * 64 * 9);
         NEEDP(b3, pre + ".0.bias", 64);
-        if (rebuild) add_fwd(w3, 64, 64, 3, h->head3.wpk, h->head3.wpk16, 64, h->head3.coutp, hd * HEAD_CH);
+        if (rebuild) add_fwd(w3, 64, 64, 3, h->head3.wpk, h->head3.wpk16, 64, h->head3.coutp, hd * HEAD_CH, h->head3.w_amax);
         if (!headcb2.add(b3, h->head_bias + hd * HEAD_CH, 64)) return fail(h, "mc_pack_params: head copy table overflow");
         const std::string an = pre + ".1";
         NEEDP(rm, an + ".running_mean", 64);
@@ -650,7 +697,8 @@ int mc_pack_params(mc_handle *h, int train_mode, void *stream) {
         }
     }
     if (rebuild) { h->pack_tab_gen = h->bind_gen; h->pack_tab_prec = h->prec; }
-    HIPCHK(h, h->fwd_pack.launch(st));     // every forward panel (fp32 + bf16 pieces) in one grid
+    if (h->prec == 3) HIPCHK(h, hipMemsetAsync(h->w_amax_arena, 0, (size_t)h->w_amax_n * sizeof(unsigned), st));
+    HIPCHK(h, h->fwd_pack.launch(st, h->prec == 3));     // every forward panel (fp32 + bf16 / fp16 pieces) in one grid
     HIPCHK(h, h->folds.launch(st));        // every eval-mode BatchNorm fold in one grid
     HIPCHK(h, launch_copy_batch(headcb, st));
     HIPCHK(h, launch_copy_batch(headcb2, st));
@@ -680,6 +728,7 @@ int mc_forward_infer(mc_handle *h, const float *img, int B, int H, int W, float 
         if (!preds[i]) return fail(h, "mc_forward_infer: preds[%d] is NULL", i);
         pl->ops[pl->head_apply_op].ha.pred[i] = preds[i];
     }
+    if (plan_reset_amax(h, pl, st)) return -1;
     for (const Op &op : pl->ops)
         if (run_op(h, op, st)) return -1;
     if (feat_nchw) HIPCHK(h, launch_nhwc_to_nchw(pl->feat.p, B, pl->feat.C, pl->feat.H, pl->feat.W, feat_nchw, st));
@@ -709,6 +758,7 @@ int mc_backbone_forward(mc_handle *h, const float *img, int B, int H, int W, flo
     if (!pl) return -1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     pl->ops[pl->stem_op].in = img;
+    if (plan_reset_amax(h, pl, st)) return -1;
     for (int i = 0; i < pl->n_backbone_ops; ++i)
         if (run_op(h, pl->ops[i], st)) return -1;
     for (int i = 0; i < 6; ++i)
@@ -725,10 +775,12 @@ int mc_neck_forward(mc_handle *h, const float *const levels[6], int B, int H, in
     Plan *pl = stage_plan(h, 2, B, H, W, "mc_neck_forward");
     if (!pl) return -1;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (plan_reset_amax(h, pl, st)) return -1;
     for (int i = 2; i < 6; ++i) {
         if (!levels[i]) return fail(h, "mc_neck_forward: levels[%d] is NULL", i);
         const Tensor &t = pl->lv[i];
         HIPCHK(h, launch_nchw_to_nhwc(levels[i], t.B, t.C, t.H, t.W, t.p, st));
+        if (plan_absmax(h, t, st)) return -1;
     }
     for (int i = pl->n_backbone_ops; i < pl->n_neck_ops; ++i)
         if (run_op(h, pl->ops[i], st)) return -1;
@@ -743,7 +795,9 @@ int mc_head_forward(mc_handle *h, const float *feat, int B, int H, int W, float 
     Plan *pl = stage_plan(h, 4, B, H, W, "mc_head_forward");
     if (!pl) return -1;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (plan_reset_amax(h, pl, st)) return -1;
     HIPCHK(h, launch_nchw_to_nhwc(feat, B, pl->feat.C, pl->feat.H, pl->feat.W, pl->feat.p, st));
+    if (plan_absmax(h, pl->feat, st)) return -1;
     for (int i = 0; i < MC_NUM_PREDS; ++i) {
         if (!preds[i]) return fail(h, "mc_head_forward: preds[%d] is NULL", i);
         pl->ops[pl->head_apply_op].ha.pred[i] = preds[i];
@@ -825,11 +879,25 @@ int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[],
     HIPCHK(h, hipMemsetAsync(wpk.p, 0, wn * sizeof(float), st));
     HIPCHK(h, launch_pack_conv_w(weight_oihw, Cout, cin, ksize, wpk.as<float>(), cin, a.CoutP, 0, 0, st));
     a.wpk = wpk.as<float>();
+    ScratchBuf slots;       // mode 3: max |x| of every source and of the weight, each from a pass of its own
     if (h->prec >= 1 && cin % 8 == 0) {
-        const int pieces = h->prec == 2 ? 3 : 1;
+        const int pieces = h->prec == 2 ? 3 : (h->prec == 3 ? 2 : 1);
+        unsigned *sl = nullptr;
+        if (h->prec == 3) {
+            HIPCHK(h, slots.alloc(5 * AMAX_WORDS * sizeof(unsigned)));
+            sl = slots.as<unsigned>();
+            HIPCHK(h, hipMemsetAsync(sl, 0, 5 * AMAX_WORDS * sizeof(unsigned), st));
+            for (int i = 0; i < nsrc; ++i) {
+                HIPCHK(h, launch_absmax(src[i], (size_t)B * Hin * Win * src_channels[i], sl + i * AMAX_WORDS, st));
+                a.amax_in[i] = sl + i * AMAX_WORDS;
+            }
+            sl += 4 * AMAX_WORDS;                                       // the weight's single-word slot
+            HIPCHK(h, launch_absmax(weight_oihw, (size_t)Cout * cin * ksize * ksize, sl, st, true));
+            a.amax_w = sl;
+        }
         HIPCHK(h, wpk16.alloc(wn * 2 * pieces));
         HIPCHK(h, hipMemsetAsync(wpk16.p, 0, wn * 2 * pieces, st));
-        HIPCHK(h, launch_pack_conv_w_bf16(weight_oihw, Cout, cin, ksize, wpk16.p, cin, a.CoutP, 0, 0, pieces, st));
+        HIPCHK(h, launch_pack_conv_w_bf16(weight_oihw, Cout, cin, ksize, wpk16.p, cin, a.CoutP, 0, 0, pieces, st, sl));
         a.wpk16 = wpk16.p; a.prec = h->prec;
     }
     a.scale = scale; a.bias = bias; a.res = residual; a.res_ld = Cout;
@@ -1007,8 +1075,9 @@ int mc_set_conv_cfg(mc_handle *h, int cfg) {
 
 int mc_set_precision(mc_handle *h, int mode) {
     if (!h) return -1;
-    if (mode < 0 || mode > 2)
-        return fail(h, "mc_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 MFMA operands) or 2 (fp32 emulated by a 3-way bf16 split)");
+    if (mode < 0 || mode > 3)
+        return fail(h, "mc_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 MFMA operands), 2 (fp32 emulated by a 3-way bf16 "
+                       "split) or 3 (fp32 emulated by a 2-way fp16 split)");
     if (mode == h->prec) return 0;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());

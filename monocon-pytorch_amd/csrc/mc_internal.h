@@ -29,6 +29,7 @@ struct Bound {
 struct Tensor {   // NHWC activation
     float *p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;
+    unsigned *amax = nullptr;   // slot receiving max |x| of the tensor (precision mode 3: operand scale of its consumers)
     size_t numel() const { return (size_t)B * H * W * C; }
 };
 
@@ -37,7 +38,8 @@ struct ConvLayer {
     int ks = 1, stride = 1, cin = 0, cout = 0, coutp = 0, cfg = 0;
     float bn_eps = 1e-5f;
     float *wpk = nullptr, *scale = nullptr, *shift = nullptr;
-    void *wpk16 = nullptr;   // bf16 panel (mixed-precision mode)
+    void *wpk16 = nullptr;   // bf16 / fp16 piece panels (precision modes 1..3)
+    unsigned *w_amax = nullptr;   // max |w| of the master weight(s) (mode 3: the panel's power-of-two scale)
 };
 
 struct DeconvLayer {
@@ -61,6 +63,7 @@ struct Op {
     int chunks = 0;
     HeadApplyArgs ha{};
     double flops = 0, bytes = 0;
+    unsigned *amax = nullptr;   // OP_DECONV in mode 3: slot of the output tensor
 };
 
 struct Plan {
@@ -69,6 +72,8 @@ struct Plan {
     std::vector<void *> bufs;
     size_t bytes = 0;
     Tensor feat, lv[6];
+    unsigned *amax_arena = nullptr;   // mode 3: one slot per activation tensor, zeroed at the start of every forward
+    int amax_used = 0;
     int stem_op = -1, head_apply_op = -1;
     int n_backbone_ops = 0, n_neck_ops = 0;
     double flops = 0, hbm_bytes = 0;
@@ -98,7 +103,10 @@ struct mc_handle {
     size_t decode_filt_n = 0;
     size_t decode_count_n = 0;
     int force_cfg = 0;   // tuning aid (mc_bench_conv)
-    int prec = 0;        // 0 fp32 (parity path), 1 bf16 MFMA operands (mc_set_precision)
+    int prec = 0;        // mc_set_precision: 0 fp32 MFMA, 1 bf16 operands, 2 three-way bf16 split, 3 two-way fp16 split
+    unsigned *w_amax_arena = nullptr;                    // mode 3: max |w| per conv layer (+ the fused head panel)
+    int w_amax_n = 0;
+    std::map<const float *, unsigned *> w_amax_of;       // master weight -> its slot (train plan: data-gradient panels)
     int autotune = 1;    // time the workgroup shapes of every distinct conv once (MONOCON_HIP_AUTOTUNE=0: heuristic)
     std::map<std::vector<int>, int> tuned;   // conv signature -> shape id
     float *loss_ws = nullptr;   // focal partials + small reduction scratch

@@ -173,6 +173,18 @@ int mc_op_conv_wgrad(mc_handle *h, const float *const src[], const int src_chann
     a.Wout = (Win + 2 * (ksize / 2) - ksize) / stride + 1;
     a.Cin = cin; a.Cout = Cout; a.dy = dy; a.dy_ld = Cout;
     a.prec = h->prec;
+    ScratchBuf slots;       // mode 3: max |x| of every source and of dY
+    if (h->prec == 3) {
+        HIPCHK(h, slots.alloc(5 * mc::AMAX_WORDS * sizeof(unsigned)));
+        unsigned *sl = slots.as<unsigned>();
+        HIPCHK(h, hipMemsetAsync(sl, 0, 5 * mc::AMAX_WORDS * sizeof(unsigned), st));
+        for (int i = 0; i < nsrc; ++i) {
+            HIPCHK(h, mc::launch_absmax(src[i], (size_t)B * Hin * Win * src_channels[i], sl + i * mc::AMAX_WORDS, st));
+            a.amax_x[i] = sl + i * mc::AMAX_WORDS;
+        }
+        HIPCHK(h, mc::launch_absmax(dy, (size_t)B * a.Hout * a.Wout * Cout, sl + 4 * mc::AMAX_WORDS, st));
+        a.amax_dy = sl + 4 * mc::AMAX_WORDS;
+    }
     mc::wgrad_plan(a, ksize, stride);
     void *part = nullptr;
     HIPCHK(h, hipMalloc(&part, mc::wgrad_partial_floats(a, ksize) * sizeof(float)));
@@ -196,10 +208,19 @@ int mc_op_conv_dgrad(mc_handle *h, const float *dy, const float *weight_oihw, in
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Ho = (Hin + 2 * (ksize / 2) - ksize) / stride + 1, Wo = (Win + 2 * (ksize / 2) - ksize) / stride + 1;
-    const int CsP = mc::conv_coutp(Cs), pieces = h->prec == 2 ? 3 : 1;
+    const int CsP = mc::conv_coutp(Cs), pieces = h->prec == 2 ? 3 : (h->prec == 3 ? 2 : 1);
     const int nclass = stride == 2 ? 4 : 1;
     std::vector<void *> tmp;
     hipError_t e = hipSuccess;
+    ScratchBuf slots;       // mode 3: max |dy| and max |w|
+    unsigned *sl = nullptr;
+    if (h->prec == 3) {
+        HIPCHK(h, slots.alloc((mc::AMAX_WORDS + 1) * sizeof(unsigned)));
+        sl = slots.as<unsigned>();
+        HIPCHK(h, hipMemsetAsync(sl, 0, (mc::AMAX_WORDS + 1) * sizeof(unsigned), st));
+        HIPCHK(h, mc::launch_absmax(dy, (size_t)B * Ho * Wo * Cout, sl, st));
+        HIPCHK(h, mc::launch_absmax(weight_oihw, (size_t)Cout * CinTotal * ksize * ksize, sl + mc::AMAX_WORDS, st, true));
+    }
     for (int cls = 0; cls < nclass && e == hipSuccess; ++cls) {
         const int cid = stride == 2 ? cls : -1;
         const int py = cls >> 1, px = cls & 1;
@@ -215,7 +236,8 @@ int mc_op_conv_dgrad(mc_handle *h, const float *dy, const float *weight_oihw, in
             if (hipMalloc(&panel16, pn * 2 * pieces) != hipSuccess) { e = hipErrorOutOfMemory; break; }
             tmp.push_back(panel16);
             (void)hipMemsetAsync(panel16, 0, pn * 2 * pieces, st);
-            e = mc::launch_pack_conv_w_dgrad_bf16(weight_oihw, Cout, CinTotal, ksize, c_off, Cs, CsP, Cout, cid, pieces, panel16, st);
+            e = mc::launch_pack_conv_w_dgrad_bf16(weight_oihw, Cout, CinTotal, ksize, c_off, Cs, CsP, Cout, cid, pieces, panel16, st,
+                                                  sl ? sl + mc::AMAX_WORDS : nullptr);
             if (e != hipSuccess) break;
         }
         mc::ConvArgs d{};
@@ -223,6 +245,7 @@ int mc_op_conv_dgrad(mc_handle *h, const float *dy, const float *weight_oihw, in
         d.B = B; d.Hin = Ho; d.Win = Wo; d.Hout = Ho; d.Wout = Wo;
         d.Cin = Cout; d.Cout = Cs; d.CoutP = CsP; d.wpk = static_cast<float *>(panel);
         d.wpk16 = panel16; d.prec = panel16 ? h->prec : 0;
+        if (sl) { d.amax_in[0] = sl; d.amax_w = sl + mc::AMAX_WORDS; }
         d.out = dx; d.out_ld = Cs;
         int kk = ksize;
         if (stride == 2) {

@@ -32,7 +32,8 @@ struct PackJob {           // dgrad panel refreshed from the master weights befo
     int Cout, CinTotal, k, c_off, Cs, CsP, CoutPad;
     int cls;           // -1: stride-1 panel; 0..3: output-parity class of a stride-2 data gradient
     float *dst;
-    void *dst16;       // bf16 twin of the panel (mixed-precision mode) or null
+    void *dst16;       // bf16 / fp16 piece planes of the panel (precision modes 1..3) or null
+    unsigned *amax;    // mode 3: max-|w| slot of the master weight
 };
 
 enum RecKind { REC_STEM, REC_CONV, REC_POOL, REC_DECONV, REC_HEAD };
@@ -82,6 +83,9 @@ struct TrainState {
     bool head_only = false;
     const float *feat_ext = nullptr;
     float *gfeat_ext = nullptr;
+    // precision mode 3: one max-|x| slot per activation / gradient tensor, zeroed at the start of every forward
+    unsigned *amax_arena = nullptr;
+    int amax_used = 0;
     // plan-owned
     mc_targets targets{};
     float *dpred[10] = {nullptr};
@@ -109,6 +113,19 @@ struct TB {   // train plan builder
     std::map<const float *, int> pooled;
     void *last_panel16 = nullptr;   // bf16 twin of the panel the last pack_job() made
 
+    static constexpr int AMAX_SLOTS = 512;
+    unsigned *slot() {        // mode 3: a fresh max-|x| slot (null in the other modes)
+        if (h->prec != 3) return nullptr;
+        if (!ts->amax_arena) ts->amax_arena = reinterpret_cast<unsigned *>(alloc((size_t)AMAX_SLOTS * AMAX_WORDS));
+        if (ts->amax_used >= AMAX_SLOTS) { ts->ok = false; h->err = "train plan: amax slot table overflow"; return nullptr; }
+        return ts->amax_arena ? ts->amax_arena + (size_t)(ts->amax_used++) * AMAX_WORDS : nullptr;
+    }
+    unsigned *w_slot(const float *w_master) {
+        if (h->prec != 3) return nullptr;
+        auto it = h->w_amax_of.find(w_master);
+        if (it == h->w_amax_of.end()) { ts->ok = false; h->err = "train plan: no max-|w| slot for a master weight"; return nullptr; }
+        return it->second;
+    }
     float *alloc(size_t n) {
         float *p = nullptr;
         void *q = nullptr;
@@ -132,6 +149,7 @@ struct TB {   // train plan builder
         TNode n;
         n.t.B = B; n.t.H = H; n.t.W = W; n.t.C = C;
         n.t.p = alloc(n.t.numel());
+        n.t.amax = slot();
         n.needs_grad = needs_grad;
         if (needs_grad) n.g = alloc(n.t.numel());
         ts->nodes.push_back(n);
@@ -190,6 +208,10 @@ struct TB {   // train plan builder
         a.B = B; a.Hin = s0.H; a.Win = s0.W; a.Hout = Ho; a.Wout = Wo; a.Cin = cin; a.Cout = Lr.cout; a.CoutP = Lr.coutp;
         a.wpk = Lr.wpk; a.out = r.y.p; a.out_ld = Lr.cout;
         a.wpk16 = Lr.wpk16; a.prec = h->prec;
+        if (h->prec == 3) {
+            for (int i = 0; i < a.nsrc; ++i) a.amax_in[i] = ts->nodes[srcs[i]].t.amax;
+            a.amax_w = Lr.w_amax;
+        }
         a.cfg = ts->ok ? mc_choose_conv_cfg(h, a, Lr.ks, Lr.stride) : CFG_128x32;
         const int chunks = conv_chunks_per_image(a.cfg, Ho, Wo);
         float *stats = alloc((size_t)B * chunks * Lr.coutp * 2);
@@ -204,10 +226,11 @@ struct TB {   // train plan builder
         if (!dead) {
             const float *yp = r.y.p, *rp = res >= 0 ? ts->nodes[res].t.p : nullptr;
             float *zp = ts->nodes[r.z].t.p;
+            unsigned *zmax = ts->nodes[r.z].t.amax;
             const size_t rows = (size_t)Ho * Wo;
             const int C = Lr.cout, rl = relu;
             ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_affine_act(yp, ca, cb, rp, B, rows, C, 0, rl, zp, st));
+                HIPCHK(hh, launch_affine_act(yp, ca, cb, rp, B, rows, C, 0, rl, zp, st, zmax));
                 return 0;
             });
         }
@@ -220,6 +243,7 @@ struct TB {   // train plan builder
         auto it = pooled.find(t.p);
         if (it != pooled.end()) return it->second;
         const int o = node(t.B, t.H / 2, t.W / 2, t.C);
+        ts->nodes[o].t.amax = t.amax;          // max |pool(x)| <= max |x|: the input's slot serves
         const float *ip = t.p;
         float *op = ts->nodes[o].t.p;
         const int B = t.B, H = t.H, W = t.W, C = t.C;
@@ -236,8 +260,9 @@ struct TB {   // train plan builder
         const int o = node(t.B, t.H * 2, t.W * 2, t.C);
         const float *ip = t.p, *w = D.wpk;
         float *op = ts->nodes[o].t.p;
+        unsigned *omax = ts->nodes[o].t.amax;
         const int B = t.B, H = t.H, W = t.W, C = t.C;
-        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_deconv4(ip, B, H, W, C, w, op, st)); return 0; });
+        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_deconv4(ip, B, H, W, C, w, op, st, omax)); return 0; });
         Rec r;
         r.kind = REC_DECONV; r.in = x; r.z = o; r.D = &D;
         ts->recs.push_back(r);
@@ -280,6 +305,7 @@ struct TB {   // train plan builder
         const int taps = cls < 0 ? k * k : (1 + (cls >> 1)) * (1 + (cls & 1));
         j.dst = alloc((size_t)taps * CoutPad * j.CsP);
         j.dst16 = (h->prec >= 1 && CoutPad % 8 == 0) ? alloc((3 * (size_t)taps * CoutPad * j.CsP + 1) / 2) : nullptr;
+        j.amax = w_slot(w);
         last_panel16 = j.dst16;
         ts->packs.push_back(j);
         *dst_out = j.dst;
@@ -306,6 +332,7 @@ struct TB {   // train plan builder
                 d.B = dy.B; d.Hin = dy.H; d.Win = dy.W; d.Hout = dy.H; d.Wout = dy.W;
                 d.Cin = dy.C; d.Cout = sn.t.C; d.CoutP = csp; d.wpk = panel;
                 d.wpk16 = last_panel16; d.prec = last_panel16 ? h->prec : 0;
+                d.amax_in[0] = dy.amax; d.amax_w = w_slot(w_master);
                 const int ld = sn.t.C;
                 d.out = sn.g + ((size_t)py * sn.t.W + px) * ld; d.out_ld = ld;
                 d.o_px = 2 * ld; d.o_row = 2 * sn.t.W * ld; d.o_img = sn.t.H * sn.t.W * ld;
@@ -330,6 +357,7 @@ struct TB {   // train plan builder
         d.B = dy.B; d.Hin = Hd; d.Win = Wd; d.Hout = Hd; d.Wout = Wd;
         d.Cin = dy.C; d.Cout = sn.t.C; d.CoutP = csp; d.wpk = panel;
         d.wpk16 = last_panel16; d.prec = last_panel16 ? h->prec : 0;
+        d.amax_in[0] = dy.amax; d.amax_w = w_slot(w_master);
         d.out = sn.g; d.out_ld = sn.t.C;
         if (sn.ginit) { d.res = sn.g; d.res_ld = sn.t.C; }
         if (Hd != sn.t.H || Wd != sn.t.W) { ts->ok = false; h->err = "train plan: dgrad shape mismatch"; }
@@ -348,8 +376,10 @@ struct TB {   // train plan builder
         for (int i = 0; i < a.nsrc; ++i) {
             a.src[i].p = ts->nodes[srcs[i]].t.p;
             a.src[i].C = ts->nodes[srcs[i]].t.C;
+            a.amax_x[i] = ts->nodes[srcs[i]].t.amax;
             cin += a.src[i].C;
         }
+        a.amax_dy = dy.amax;
         const Tensor &s0 = ts->nodes[srcs[0]].t;
         a.B = s0.B; a.Hin = s0.H; a.Win = s0.W; a.Hout = dy.H; a.Wout = dy.W; a.Cin = cin; a.Cout = Cout;
         a.dy = dy.p; a.dy_ld = dy_ld;
@@ -364,6 +394,8 @@ struct TB {   // train plan builder
         TNode &zn = ts->nodes[r.z];
         Tensor dy = r.y;
         dy.p = alloc(r.y.numel());
+        dy.amax = slot();
+        unsigned *dymax = dy.amax;
         const int B = r.y.B, C = r.y.C, rows = r.y.H * r.y.W;
         const float *yp = r.y.p, *gz = zn.g, *zp = zn.t.p, *gamma = P(bn + ".weight"), *mean = r.mean, *rstd = r.rstd;
         float *dg = G(bn + ".weight"), *db = G(bn + ".bias"), *dyp = dy.p;
@@ -394,7 +426,8 @@ struct TB {   // train plan builder
             double *fold = fold_scratch(nbp, C);
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, cstride, n, C, gamma, mean, rstd, dg, db, coef, st, fold));
-                HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, 0, dyp, gres, gmode, st));
+                HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, 0, dyp, gres, gmode, st, nullptr, nullptr, nullptr,
+                                             nullptr, dymax));
                 return 0;
             });
             return dy;
@@ -404,7 +437,8 @@ struct TB {   // train plan builder
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
             HIPCHK(hh, launch_chan_reduce(yp, gz, zp, nullptr, B, rows, C, 1, relu, partial, C, st, fa, fb));
             HIPCHK(hh, launch_bn_bwd_finalize(partial, nb, C, n, C, gamma, mean, rstd, dg, db, coef, st));
-            HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, relu, dyp, gres, gmode, st, fa, fb));
+            HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, relu, dyp, gres, gmode, st, fa, fb, nullptr, nullptr,
+                                         dymax));
             return 0;
         });
         return dy;
@@ -421,13 +455,23 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     TB b{h, ts};
     const int fh = H / 4, fw = W / 4, HW = fh * fw;
     int feat = -1;
+    if (h->prec == 3) {      // the max-|x| slots start every forward at zero: their producers only raise them
+        (void)b.slot();
+        --ts->amax_used;
+        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
+            HIPCHK(hh, hipMemsetAsync(ts->amax_arena, 0, (size_t)ts->amax_used * AMAX_WORDS * sizeof(unsigned), st));
+            return 0;
+        });
+    }
     if (head_only) {
         // the heads on their own (MonoConDenseHeads.forward_train, monocon_heads.py:150-157): the neck output is an
         // external NCHW tensor, copied into the plan's NHWC node; its gradient is copied out after the backward
         feat = b.node(B, fh, fw, 64);
         float *fp = ts->nodes[feat].t.p;
+        unsigned *fmax = ts->nodes[feat].t.amax;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
             HIPCHK(hh, launch_nchw_to_nhwc(ts->feat_ext, B, 64, fh, fw, fp, st));
+            if (fmax) HIPCHK(hh, launch_absmax(fp, (size_t)B * fh * fw * 64, fmax, st));
             return 0;
         });
     } else {
@@ -513,6 +557,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         c3.B = B; c3.Hin = fh; c3.Win = fw; c3.Hout = fh; c3.Wout = fw; c3.Cin = 64; c3.Cout = CP; c3.CoutP = h->head3.coutp;
         c3.wpk = h->head3.wpk; c3.bias = h->head_bias; c3.out = xh.p; c3.out_ld = CP; c3.cfg = h->head3.cfg;
         c3.wpk16 = h->head3.wpk16; c3.prec = h->prec;
+        if (h->prec == 3) { c3.amax_in[0] = fn.t.amax; c3.amax_w = h->head3.w_amax; }
         at.chunks = conv_chunks_per_image(c3.cfg, fh, fw);
         at.stat_ld = h->head3.coutp;
         float *stats = b.alloc((size_t)B * at.chunks * at.stat_ld * 2);
@@ -621,14 +666,16 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         }
         float *db3 = b.alloc(CP), *dw3 = b.alloc((size_t)CP * 64 * 9);
         float *cs3 = b.alloc((size_t)affine_bwd_blocks(B, (size_t)HW, CP) * CP * 2);
-        Tensor dxT = xh; dxT.p = dx;
+        Tensor dxT = xh; dxT.p = dx; dxT.amax = b.slot();
+        unsigned *dxmax = dxT.amax;
         {
             const float *xp = xh.p;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 // d is already masked: the AttnBN backward is the plain per-(image, channel) affine map; the same pass
                 // leaves the column sums of dx (the 3x3 convs' bias gradients) instead of a second read of dx
                 HIPCHK(hh, launch_attn_train_bwd(at, partial, rb_per_img, gp, coef, st));
-                HIPCHK(hh, launch_affine_bwd(dh, nullptr, xp, coef, B, (size_t)HW, CP, 1, 0, dx, nullptr, 0, st, nullptr, nullptr, cs3, db3));
+                HIPCHK(hh, launch_affine_bwd(dh, nullptr, xp, coef, B, (size_t)HW, CP, 1, 0, dx, nullptr, 0, st, nullptr, nullptr, cs3, db3,
+                                             dxmax));
                 return 0;
             });
         }
@@ -651,6 +698,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         for (int hd = 0; hd < NUM_HEADS; ++hd)
             if (!w3cb.add(w3[hd], w3dense + (size_t)hd * 64 * 64 * 9, (size_t)64 * 64 * 9)) ts->ok = false;
         ts->pack_fns.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_copy_batch(w3cb, st)); return 0; });
+        if (h->prec == 3) h->w_amax_of[w3dense] = h->head3.w_amax;     // the dense copy shares the fused head panel's maximum
         b.emit_dgrad(w3dense, dxT, CP, 64, 3, 1, 0, feat, CP);
     }
     // ---- neck + backbone in reverse forward order
@@ -771,7 +819,8 @@ static int forward_train_impl(mc_handle *h, const float *img, const mc_labels *l
             mc::PackJobDesc d{};
             d.w = j.w; d.dst32 = j.dst; d.dst16 = j.dst16; d.kind = 1;
             d.Cout = j.Cout; d.Cin = j.Cs; d.k = j.k; d.CinTotal = j.CinTotal; d.CoutP = j.CoutPad; d.n_off = 0; d.c_off = j.c_off;
-            d.CsP = j.CsP; d.cls = j.cls; d.nsplit = h->prec == 2 ? 3 : 1;
+            d.CsP = j.CsP; d.cls = j.cls; d.nsplit = h->prec == 2 ? 3 : (h->prec == 3 ? 2 : 1);
+            d.amax = j.amax;
             ts->pack_batch.add(d);
         }
     }

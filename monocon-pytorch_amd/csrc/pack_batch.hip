@@ -9,8 +9,51 @@
 // pack_conv_w_dgrad_bf16_kernel (kernels_misc.hip, conv_bf16.hip, kernels_head_train.hip), element for element.
 #include "kernels.h"
 #include "train.h"
+#include "conv_mfma.h"
 
 namespace mc {
+
+// nsplit == 2: two fp16 pieces of r (already multiplied by the tensor's power-of-two scale), else nsplit bf16 pieces
+__device__ __forceinline__ void store_pieces_b(float r, unsigned short *dst, size_t plane, int nsplit) {
+    if (nsplit == 2) {
+        const _Float16 hi = (_Float16)r;
+        const _Float16 lo = (_Float16)(r - (float)hi);
+        dst[0] = __builtin_bit_cast(unsigned short, hi);
+        dst[plane] = __builtin_bit_cast(unsigned short, lo);
+    } else {
+        for (int q = 0; q < nsplit; ++q) {
+            const __bf16 piece = (__bf16)r;
+            dst[q * plane] = __builtin_bit_cast(unsigned short, piece);
+            r -= (float)piece;
+        }
+    }
+}
+
+// max |w| of every forward job's master weight folded into its slot (fp16-split mode; slots zeroed by the caller).
+// Jobs that share a slot (the nine head convs of the fused 64 -> 576 panel) end up with their common maximum.
+__global__ __launch_bounds__(256) void weight_amax_batch_kernel(const PackJobDesc *__restrict__ tab, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJobDesc j = tab[lo];
+    if (!j.amax || j.kind != 0) return;
+    // at most WA_BLOCKS workgroups per job take part (the grid is the pack kernel's): one atomic each on the job's word
+    constexpr int WA_BLOCKS = 8;
+    const int lb = blockIdx.x - j.block_begin, nb = j.nblocks < WA_BLOCKS ? j.nblocks : WA_BLOCKS;
+    if (lb >= nb) return;
+    const size_t total = (size_t)j.Cout * j.Cin * j.k * j.k;
+    float vmax = 0.f;
+    for (size_t e = (size_t)lb * 256 + threadIdx.x; e < total; e += (size_t)nb * 256) vmax = fmaxf(vmax, fabsf(j.w[e]));
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0) s_max = 0u;
+    __syncthreads();
+    const unsigned bits = __builtin_bit_cast(unsigned, vmax);
+    if (bits < 0x7f800000u && bits != 0u) atomicMax(&s_max, bits);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max != 0u) atomicMax(j.amax, s_max);
+}
 
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJobDesc *__restrict__ tab, int njobs) {
     // job of this block: last entry whose block_begin <= blockIdx.x (wave-uniform binary search)
@@ -22,7 +65,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJobDesc *__re
     const PackJobDesc j = tab[lo];
     const int lb = blockIdx.x - j.block_begin;
     const int k = j.k, kk = k * k;
-    __bf16 *d16 = static_cast<__bf16 *>(j.dst16);
+    unsigned short *d16 = static_cast<unsigned short *>(j.dst16);
+    const float wscale = (j.nsplit == 2 && d16) ? exp2i(f16_scale_exp(*j.amax)) : 1.f;
     if (j.kind == 0) {
         // forward panel: [tap][CinPanel/4][CoutP][4] fp32, [piece][tap][CinPanel/8][CoutP][8] bf16
         const size_t total = (size_t)j.Cout * j.Cin * kk;
@@ -35,11 +79,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJobDesc *__re
             float r = j.w[e];
             if (j.dst32) j.dst32[(((size_t)tap * (j.CinTotal >> 2) + (cc >> 2)) * j.CoutP + nn) * 4 + (cc & 3)] = r;
             if (d16)
-                for (int q = 0; q < j.nsplit; ++q) {
-                    const __bf16 piece = (__bf16)r;
-                    d16[q * plane + (((size_t)tap * (j.CinTotal >> 3) + (cc >> 3)) * j.CoutP + nn) * 8 + (cc & 7)] = piece;
-                    r -= (float)piece;
-                }
+                store_pieces_b(r * wscale, d16 + (((size_t)tap * (j.CinTotal >> 3) + (cc >> 3)) * j.CoutP + nn) * 8 + (cc & 7), plane,
+                               j.nsplit);
         }
     } else {
         // data-gradient panel of one source (channels [c_off, c_off + Cs) of the forward weight): transposed + flipped,
@@ -63,11 +104,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJobDesc *__re
             float rem = j.w[(((size_t)n * j.CinTotal + j.c_off + cl) * k + r) * k + s];
             if (j.dst32) j.dst32[(((size_t)tapd * (j.CoutP >> 2) + (n >> 2)) * j.CsP + cl) * 4 + (n & 3)] = rem;
             if (d16)
-                for (int q = 0; q < j.nsplit; ++q) {
-                    const __bf16 piece = (__bf16)rem;
-                    d16[q * plane + (((size_t)tapd * (j.CoutP >> 3) + (n >> 3)) * j.CsP + cl) * 8 + (n & 7)] = piece;
-                    rem -= (float)piece;
-                }
+                store_pieces_b(rem * wscale, d16 + (((size_t)tapd * (j.CoutP >> 3) + (n >> 3)) * j.CsP + cl) * 8 + (n & 7), plane,
+                               j.nsplit);
         }
     }
 }
@@ -88,8 +126,10 @@ void PackBatch::add(PackJobDesc j) {
     jobs.push_back(j);
     uploaded = false;
 }
-hipError_t PackBatch::launch(hipStream_t st) {
+hipError_t PackBatch::launch(hipStream_t st, bool with_amax) {
     if (jobs.empty()) return hipSuccess;
+    for (const PackJobDesc &j : jobs)
+        if (j.nsplit == 2 && j.dst16 && !j.amax) return hipErrorInvalidValue;
     if (!uploaded) {
         if (dev) (void)hipFree(dev);
         dev = nullptr;
@@ -99,6 +139,8 @@ hipError_t PackBatch::launch(hipStream_t st) {
         if (e != hipSuccess) return e;
         uploaded = true;
     }
+    if (with_amax)      // the maxima first: the pack kernel scales by them
+        hipLaunchKernelGGL(weight_amax_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, dev, (int)jobs.size());
     hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, dev, (int)jobs.size());
     return hipGetLastError();
 }

@@ -54,8 +54,9 @@ struct PackJobDesc {
     int CinTotal;          // forward: channels of the panel (virtual concat).  data gradient: Cin of the forward weight
     int CoutP;             // forward: padded columns.  data gradient: CoutPad (K of the data gradient)
     int n_off, c_off;      // forward: column / channel offset in the panel.  data gradient: c_off of the source
-    int CsP, cls, nsplit;  // data gradient: padded source channels, parity class (-1: stride 1); bf16 pieces (1 or 3)
+    int CsP, cls, nsplit;  // data gradient: padded source channels, parity class (-1: stride 1); pieces: 1 / 3 bf16, 2 fp16
     int block_begin, nblocks;
+    unsigned *amax;        // nsplit == 2: slot holding max |w| of the master weight(s) behind the panel (conv_mfma.h)
 };
 struct PackBatch {
     std::vector<PackJobDesc> jobs;
@@ -64,7 +65,8 @@ struct PackBatch {
     bool uploaded = false;
     void clear();
     void add(PackJobDesc j);
-    hipError_t launch(hipStream_t st);
+    // with_amax: first fold max |w| of every forward job into its slot (slots zeroed by the caller)
+    hipError_t launch(hipStream_t st, bool with_amax = false);
     PackBatch() = default;
     PackBatch(const PackBatch &) = delete;
     PackBatch &operator=(const PackBatch &) = delete;
@@ -109,13 +111,14 @@ hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double 
                               double *fold = nullptr);
 size_t partial_fold_doubles(int nb, int C);   // scratch for `fold` (0: the partial list is short, no pre-pass)
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
-                             int C, int per_sample, int relu, float *z, hipStream_t st);
+                             int C, int per_sample, int relu, float *z, hipStream_t st, unsigned *amax = nullptr);
 hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
                                   const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
                                   hipStream_t st, double *fold = nullptr);
 hipError_t launch_affine_bwd(const float *dz, const float *z, const float *y, const float *coef, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *dy, float *gres, int gres_mode, hipStream_t st,
-                             const float *fa = nullptr, const float *fb = nullptr, float *csum = nullptr, float *csum_out = nullptr);
+                             const float *fa = nullptr, const float *fb = nullptr, float *csum = nullptr, float *csum_out = nullptr,
+                             unsigned *amax = nullptr);   // amax: max |z| / max |dy| folded into the slot (see ConvArgs::amax_in)
 // csum: scratch of affine_bwd_blocks(B, rows, C) * C * 2 floats -> csum_out[C] = column sums of dy (the conv bias gradient)
 int affine_bwd_blocks(int B, size_t rows_per_img, int C);
 hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st);
@@ -173,8 +176,9 @@ struct WgradArgs {
     float *partial;           // [ksplit][k*k][Cout][Cin]
     int ksplit, n_tiles, c_tiles, ppr, ppi, groups_per_img;
     int small;                // 1: 16-input-channel layer on the LDS-free 16x16x4 kernel (ksplit = workgroups)
-    int prec;                 // 1: bf16 MFMA operands, 2: 3-way split fp32 emulation, where wgrad_bf16_ok() (wgrad_bf16.hip)
-    int pb;                   // 32-pixel patches per staged group (2, or 1 for the split kernel)
+    int prec;                 // 1: bf16 MFMA operands, 2: 3-way bf16 split, 3: 2-way fp16 split -- where wgrad_bf16_ok() (wgrad_bf16.hip)
+    int pb;                   // 32-pixel patches per staged group (2, or 1 for the split kernels)
+    const unsigned *amax_x[4], *amax_dy;   // prec 3: max |x| (bit patterns) of every source and of dY (see ConvArgs::amax_in)
 };
 void wgrad_plan(WgradArgs &a, int ks, int stride);            // fills the tiling fields
 size_t wgrad_partial_floats(const WgradArgs &a, int ks);

@@ -15,6 +15,9 @@
 //     Offsets, zero fill and the register prefetch across the MFMA phase are as in wgrad_mfma_kernel.
 //   * SPL = 3 (mode 2, fp32 emulation, see conv_bf16.hip): dY and X are each staged as three bf16 pieces and every tap
 //     accumulates the six partial products of weight >= 2^-16; one patch per staged group so two workgroups fit a CU.
+//   * SPL = 2 (mode 3, fp32 emulation by a 2-way fp16 split, see conv_bf16.hip): dY and X are scaled by the power of two
+//     their tensor's max |x| dictates (WgradArgs::amax_dy / amax_x), staged as two fp16 pieces each, three partial
+//     products per tap; the partial sums leave the kernel multiplied by the exact inverse of both scales.
 // Accumulation, split-K partials and the deterministic reduce stay fp32 (wgrad_reduce_kernel).
 // Stride-2 layers (five in DLA-34) and the 16-channel layers keep their fp32 kernels.
 #include <algorithm>
@@ -26,7 +29,14 @@ namespace mc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int SPL> struct WPiece { typedef __bf16 T; typedef bf16x8 V8; typedef bf16x2 V2; };
+template <> struct WPiece<2> { typedef _Float16 T; typedef f16x8 V8; typedef f16x2 V2; };
+__device__ __forceinline__ f32x16 wmfma_k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 wmfma_k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 template <int KS, int WN, int WC, int SPL>
 struct WgB16Cfg {
@@ -60,6 +70,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 template <int KS, int WN, int WC, int SPL>
 __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const WgradArgs a) {
     using Cfg = WgB16Cfg<KS, WN, WC, SPL>;
+    typedef typename WPiece<SPL>::T pc_t;
+    typedef typename WPiece<SPL>::V8 pc8;
+    typedef typename WPiece<SPL>::V2 pc2;
     constexpr int XPL = Cfg::X_PLANE, DPL = Cfg::D_PLANE;
     constexpr int PB = Cfg::PB, NB = Cfg::NB, CB = Cfg::CB, NT = Cfg::NT, PAD = Cfg::PAD;
     constexpr int IH = Cfg::IH, IW = Cfg::IW, XROW = Cfg::XROW, XCH = Cfg::XCH, DCH = Cfg::DCH;
@@ -91,6 +104,13 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
     const int Cs = a.src[si].C;
     const float *xsrc = a.src[si].p;
     const int cs0 = c0 - cbase;
+    float x_scale = 1.f, d_scale = 1.f, omul = 1.f;      // SPL == 2: operand scales and the exact inverse of their product
+    if constexpr (SPL == 2) {
+        const int ex = f16_scale_exp(amax_read(a.amax_x[si])), ed = f16_scale_exp(amax_read(a.amax_dy));
+        x_scale = exp2i(ex);
+        d_scale = exp2i(ed);
+        omul = exp2i(-ex) * exp2i(-ed);
+    }
 
     // ---- staging plan.  X item = (halo row, pixel pair, channel group) of a patch, channel group fastest;
     //      dY item = (patch row, pixel pair, channel group).
@@ -146,15 +166,15 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
         }
     };
     // piece q of (a, b): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (mode 2), packed pixel pair per channel
-    auto put = [&](unsigned char *dst, int plane, f32x4 v0, f32x4 v1, int chan_stride) {
+    auto put = [&](unsigned char *dst, int plane, f32x4 v0, f32x4 v1, int chan_stride, float scale) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float r0 = v0[j], r1 = v1[j];
+            float r0 = SPL == 2 ? v0[j] * scale : v0[j], r1 = SPL == 2 ? v1[j] * scale : v1[j];
 #pragma unroll
             for (int q = 0; q < SPL; ++q) {
-                bf16x2 pr;
-                pr[0] = (__bf16)r0;
-                pr[1] = (__bf16)r1;
+                pc2 pr;
+                pr[0] = (pc_t)r0;
+                pr[1] = (pc_t)r1;
                 *reinterpret_cast<unsigned *>(dst + q * plane + j * chan_stride) = __builtin_bit_cast(unsigned, pr);
                 r0 -= (float)pr[0];
                 r1 -= (float)pr[1];
@@ -164,10 +184,10 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
     auto store = [&](int p) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i)
-            if (NT * (i + 1) <= XP || tid + NT * i < XP) put(xt + p * CB * XCH + x_dst[i], XPL, xv[p][i][0], xv[p][i][1], XCH);
+            if (NT * (i + 1) <= XP || tid + NT * i < XP) put(xt + p * CB * XCH + x_dst[i], XPL, xv[p][i][0], xv[p][i][1], XCH, x_scale);
 #pragma unroll
         for (int i = 0; i < NID; ++i)
-            if (NT * (i + 1) <= DP || tid + NT * i < DP) put(dyt + p * NB * DCH + d_dst[i], DPL, dv[p][i][0], dv[p][i][1], DCH);
+            if (NT * (i + 1) <= DP || tid + NT * i < DP) put(dyt + p * NB * DCH + d_dst[i], DPL, dv[p][i][0], dv[p][i][1], DCH, d_scale);
     };
 
     const unsigned char *a_base = dyt + (wn * 32 + li) * DCH + lds_skew(wn * 32 + li) + g * 16;
@@ -187,16 +207,17 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
             for (int p = 0; p < PB; ++p) fetch(gi + 1, p);
         }
         // partial products (piece of dY, piece of X), smallest first; mode 1: the single (0, 0)
-        constexpr int NP = SPL == 1 ? 1 : 6;
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int NP = SPL == 1 ? 1 : (SPL == 2 ? 3 : 6);
+        constexpr int PA[6] = {SPL == 2 ? 1 : 0, SPL == 2 ? 0 : 2, SPL == 2 ? 0 : 1, 0, 1, 0};
+        constexpr int PX[6] = {SPL == 2 ? 0 : 2, SPL == 2 ? 1 : 0, SPL == 2 ? 0 : 1, 1, 0, 0};
 #pragma unroll
         for (int p = 0; p < PB; ++p)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {   // 16 pixels per MFMA: patch rows 2q (g = 0) and 2q + 1 (g = 1)
-                bf16x8 av[SPL];
+                pc8 av[SPL];
 #pragma unroll
                 for (int z = 0; z < SPL; ++z)
-                    av[z] = *reinterpret_cast<const bf16x8 *>(a_base + z * DPL + p * NB * DCH + (2 * q) * 16);
+                    av[z] = *reinterpret_cast<const pc8 *>(a_base + z * DPL + p * NB * DCH + (2 * q) * 16);
 #pragma unroll
                 for (int r = 0; r < KS; ++r) {
                     const unsigned char *row = b_base + p * CB * XCH + (2 * q + r) * XROW;
@@ -218,11 +239,11 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
                     for (int pp = 0; pp < NP; ++pp) {
                         const int za = SPL == 1 ? 0 : PA[pp], zx = SPL == 1 ? 0 : PX[pp];
                         if (KS == 1) {
-                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[za], __builtin_bit_cast(bf16x8, b0[zx]), acc[0], 0, 0, 0);
+                            acc[0] = wmfma_k16(av[za], __builtin_bit_cast(pc8, b0[zx]), acc[0]);
                         } else {
-                            acc[r * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[za], __builtin_bit_cast(bf16x8, b0[zx]), acc[r * 3 + 0], 0, 0, 0);
-                            acc[r * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[za], __builtin_bit_cast(bf16x8, b1[zx]), acc[r * 3 + 1], 0, 0, 0);
-                            acc[r * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[za], __builtin_bit_cast(bf16x8, b2[zx]), acc[r * 3 + 2], 0, 0, 0);
+                            acc[r * 3 + 0] = wmfma_k16(av[za], __builtin_bit_cast(pc8, b0[zx]), acc[r * 3 + 0]);
+                            acc[r * 3 + 1] = wmfma_k16(av[za], __builtin_bit_cast(pc8, b1[zx]), acc[r * 3 + 1]);
+                            acc[r * 3 + 2] = wmfma_k16(av[za], __builtin_bit_cast(pc8, b2[zx]), acc[r * 3 + 2]);
                         }
                     }
                 }
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (n < a.Cout) a.partial[(((size_t)ks * T + t) * a.Cout + n) * a.Cin + c] = acc[t][r];
+                if (n < a.Cout) a.partial[(((size_t)ks * T + t) * a.Cout + n) * a.Cin + c] = SPL == 2 ? acc[t][r] * omul : acc[t][r];
             }
     }
 }
@@ -268,11 +289,16 @@ bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride) {
     if (a.Wout != a.Win || a.Hout != a.Hin) return false;
     for (int i = 0; i < a.nsrc; ++i)
         if (a.src[i].C % 4) return false;
+    if (a.prec == 3) {        // the fp16 split needs the maxima of both operand tensors
+        if (!a.amax_dy) return false;
+        for (int i = 0; i < a.nsrc; ++i)
+            if (!a.amax_x[i]) return false;
+    }
     return a.dy_ld % 4 == 0;
 }
 
 // patches per staged pixel group of the kernel launch_wgrad_bf16 will run (wgrad_plan sizes the groups with it)
-int wgrad_bf16_patches(int prec) { return prec == 2 ? 1 : 2; }
+int wgrad_bf16_patches(int prec) { return prec >= 2 ? 1 : 2; }
 
 // the main kernel of launch_wgrad in the bf16-pipe modes (the split-K reduce is shared); WN / WC as planned
 template <int SPL>
@@ -287,6 +313,7 @@ static hipError_t launch_wgrad_b16_spl(const WgradArgs &a, int ks, int WN, int W
 #undef WG16
 }
 hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st) {
+    if (a.prec == 3) return launch_wgrad_b16_spl<2>(a, ks, WN, WC, st);
     return a.prec == 2 ? launch_wgrad_b16_spl<3>(a, ks, WN, WC, st) : launch_wgrad_b16_spl<1>(a, ks, WN, WC, st);
 }
 

@@ -314,7 +314,7 @@ class Engine:
         return out, [(Hp, Wp)] * len(images)
 
     def set_precision(self, mode):
-        """0 = fp32 (parity path), 1 = bf16 MFMA operands with fp32 accumulation (config 3)."""
+        """0 = fp32 MFMA, 1 = bf16 MFMA operands (config 3), 2 = fp32 emulated by a 3-way bf16 split, 3 = by a 2-way fp16 split"""
         _lib.check(self.h, self.lib.mc_set_precision(self.h, int(mode)), "mc_set_precision")
         self._sig = None          # panels must be re-packed
         self.precision = int(mode)

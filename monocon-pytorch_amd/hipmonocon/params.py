@@ -107,10 +107,14 @@ class HipRuntime:
 
     def __init__(self):
         self.engine = None
-        self.precision = 0     # 0 fp32 (parity path), 1 bf16 MFMA operands (BASELINE config 3)
+        self.precision = 0     # 0 fp32 MFMA, 1 bf16 operands, 2 fp32 as a 3-way bf16 split, 3 fp32 as a 2-way fp16 split
+
+    PRECISION_MODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp32_split": 2, "f16x2": 3, "fp16x2": 3}
 
     def set_precision(self, mode):
-        self.precision = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp32_split": 2}.get(mode, mode)
+        if isinstance(mode, str) and mode not in self.PRECISION_MODES:
+            raise ValueError("unknown precision mode %r (one of %s)" % (mode, sorted(self.PRECISION_MODES)))
+        self.precision = self.PRECISION_MODES.get(mode, mode)
         if self.engine is not None:
             self.engine.set_precision(self.precision)
 

@@ -32,8 +32,10 @@ class MonoConDetector(nn.Module):
         self._rt = HipRuntime()
 
     def set_precision(self, mode: str = "fp32"):
-        """'fp32' (default, the parity path) or 'bf16': bf16 MFMA operands with fp32 accumulation,
-        activations, master weights, BN statistics and losses (no reference counterpart)."""
+        """Arithmetic of the convolutions.  'fp32' (default): the fp32 matrix pipe.  'bf16x3' / 'f16x2': fp32 values
+        emulated on the bf16 / fp16 matrix pipe by a 3-way / 2-way operand split (same parity tolerances as 'fp32').
+        'bf16': bf16 MFMA operands with fp32 accumulation, activations, master weights, BN statistics and losses
+        (no reference counterpart, not within the parity tolerance)."""
         self._rt.set_precision(mode)
         return self
 

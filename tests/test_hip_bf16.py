@@ -178,11 +178,14 @@ def test_wgrad_bf16_operands(eng16, case):
 
 
 # ----------------------------------------------------------------------------------------------- mode 2: fp32 emulation
-@pytest.fixture()
-def eng_split():
+@pytest.fixture(params=[2, 3], ids=["bf16x3", "f16x2"])
+def eng_split(request):
+    """the two fp32-emulation modes: 2 = 3-way bf16 split (six partial products), 3 = 2-way fp16 split of the
+    power-of-two-scaled operands (three partial products)"""
     from hipmonocon.engine import Engine
     e = Engine()
-    e.set_precision(2)
+    e.set_precision(request.param)
+    e.split_mode = request.param
     yield e
     e.set_precision(0)
 
@@ -207,17 +210,18 @@ def test_conv_split_emulation_is_fp32_accurate(eng_split, case):
     got = eng_split.op_conv(*args).cpu()
     eng_split.set_precision(0)
     base = eng_split.op_conv(*args).cpu()
-    eng_split.set_precision(2)
+    eng_split.set_precision(eng_split.split_mode)
     assert rel_err(got.permute(0, 3, 1, 2), ref) < 5e-6
     assert rel_err(got, base) < 2e-6
 
 
-def test_forward_split_emulation_meets_the_fp32_parity_gate(golden_sd):
-    """eval forward at 64x128 in mode 2 against the REFERENCE's fp64 golden: the same 1e-4 gate as the fp32 path."""
+@pytest.mark.parametrize("mode", [2, 3], ids=["bf16x3", "f16x2"])
+def test_forward_split_emulation_meets_the_fp32_parity_gate(golden_sd, mode):
+    """eval forward at 64x128 in modes 2 / 3 against the REFERENCE's fp64 golden: the same 1e-4 gate as the fp32 path."""
     from conftest import load_golden
     from hipmonocon.engine import Engine
     eng = Engine()
-    eng.set_precision(2)
+    eng.set_precision(mode)
     eng.bind_state({k: v.cuda() for k, v in golden_sd.items()})
     img = synth.make_batch(GOLDEN_SEED + 1, 2, 64, 128, with_labels=False)["img"].cuda()
     g = load_golden("fwd_small_eval.npz")
@@ -241,7 +245,7 @@ def test_wgrad_split_emulation_is_fp32_accurate(eng_split, case):
     assert rel_err(got, w.grad) < 5e-6
 
 
-@pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 5e-6)], ids=["bf16", "split"])
+@pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 5e-6), (3, 5e-6)], ids=["bf16", "split", "f16x2"])
 @pytest.mark.parametrize("case", [(2, 16, 24, 64, 0, 64, 64, 3, 1), (1, 8, 16, 192, 64, 64, 64, 3, 1),
                                   (2, 16, 32, 32, 0, 32, 64, 3, 2), (1, 24, 48, 64, 0, 64, 128, 3, 2),
                                   (1, 12, 16, 448, 256, 64, 128, 1, 1)],
@@ -267,3 +271,33 @@ def test_dgrad_on_the_bf16_pipe(mode, tol, case):
     if mode == 1:
         assert e > 1e-5       # the bf16 kernel really ran
 
+
+
+# ----------------------------------------------------------------------------------------------- mode 3: operand scaling
+@pytest.mark.parametrize("xscale,wscale", [(1e-7, 1.0), (3e5, 1.0), (1.0, 1e-6), (2e4, 5e3), (1e-20, 1e12)],
+                         ids=["tiny_x", "huge_x", "tiny_w", "huge_both", "extreme"])
+def test_f16x2_operand_scaling_covers_the_fp32_range(xscale, wscale):
+    """the fp16 split scales every operand tensor by the power of two its max |x| dictates: tensors far outside fp16's
+    own range (65504 / 6e-8) -- gradients of 1e-7, activations of 1e5 -- go through conv, weight gradient and data
+    gradient at the tolerance of the fp32 kernels (5e-6 norm-wise vs fp64)."""
+    from hipmonocon.engine import Engine
+    B, H, W, cin, cout, k = 2, 16, 24, 64, 64, 3
+    x = rnd(77, "x", (B, cin, H, W), xscale)
+    w = rnd(77, "w", (cout, cin, k, k), wscale * (2.0 / (k * k * cin)) ** 0.5)
+    dy = rnd(77, "dy", (B, cout, H, W), xscale)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y = F.conv2d(xd, wd, None, 1, 1)
+    y.backward(dy.double())
+    eng = Engine()
+    eng.set_precision(3)
+    try:
+        dev = eng.device
+        got = eng.op_conv([nhwc(x).to(dev)], w.to(dev), 1, None, None, None, False).cpu()
+        gw = eng.op_conv_wgrad([nhwc(x).to(dev)], nhwc(dy).to(dev), k, 1).cpu()
+        gx = eng.op_conv_dgrad(nhwc(dy).to(dev), w.to(dev), (H, W), 0, cin, 1).cpu()
+    finally:
+        eng.set_precision(0)
+    assert rel_err(got.permute(0, 3, 1, 2), y.detach()) < 5e-6
+    assert rel_err(gw, wd.grad) < 5e-6
+    assert rel_err(gx.permute(0, 3, 1, 2), xd.grad) < 5e-6

@@ -14,13 +14,14 @@ TOL = 1e-4      # north_star: fp32 heat-maps within 1e-4 relative (norm-wise, pe
 TOL_F32 = 2e-4  # vs the reference's fp32 output: two independent fp32 round-off budgets stack
 
 
-# every test of this module runs in both fp32 modes of the library and must meet the same tolerances: "fp32" = native
-# fp32 MFMA, "bf16x3" = fp32 emulated on the bf16 matrix pipe by a 3-way operand split
-@pytest.fixture(scope="module", params=["fp32", "bf16x3"])
+# every test of this module runs in all three fp32 modes of the library and must meet the same tolerances: "fp32" = native
+# fp32 MFMA, "bf16x3" / "f16x2" = fp32 emulated on the bf16 / fp16 matrix pipe by a 3-way / 2-way operand split
+# 
+@pytest.fixture(scope="module", params=["fp32", "bf16x3", "f16x2"])
 def eng(golden_sd, request):
     from hipmonocon.engine import Engine
     e = Engine()
-    e.set_precision({"fp32": 0, "bf16x3": 2}[request.param])
+    e.set_precision({"fp32": 0, "bf16x3": 2, "f16x2": 3}[request.param])
     e.state = {k: v.to(e.device) for k, v in golden_sd.items()}
     e.bind_state(e.state)
     return e

@@ -11,10 +11,11 @@ from hipmonocon import netspec, synth
 
 pytestmark = pytest.mark.gpu
 
-# The parity tests below run in both fp32 modes of the library: "fp32" = v_mfma_f32_32x32x2_f32 (native fp32 matrix
+# The parity tests below run in all three fp32 modes of the library: "fp32" = v_mfma_f32_32x32x2_f32 (native fp32 matrix
 # pipe), "bf16x3" = fp32 emulated on the bf16 matrix pipe (each fp32 operand split into three bf16 pieces, six partial
-# products, fp32 accumulation).  Both must meet the SAME fp32 tolerances.
-PRECISIONS = ("fp32", "bf16x3")
+# products, fp32 accumulation), "f16x2" = emulated on the fp16 matrix pipe (two fp16 pieces of the power-of-two-scaled
+# operand, three partial products).  All must meet the SAME fp32 tolerances.
+PRECISIONS = ("fp32", "bf16x3", "f16x2")
 LOSS_TOL = 1e-4          # BASELINE.json north_star: fp32 losses within 1e-4 relative (judged against the fp64 reference)
 
 
@@ -333,7 +334,7 @@ def test_bf16x3_and_fp32_training_trajectories_agree(cond_sd):
     from solver import AdamW, CyclicScheduler
     batches = [to_cuda(synth.make_conditioned_batch(900 + i, 4, 64, 128)) for i in range(5)]
     runs = {}
-    for prec in PRECISIONS:
+    for prec in ("fp32", "bf16x3"):
         m = build(cond_sd, prec)
         opt = AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=35.0)
         sch = CyclicScheduler(opt, total_steps=100)
