@@ -156,7 +156,8 @@ int mc_losses_backward_pred(mc_handle *h, const float *const preds[MC_NUM_PREDS]
  * every live parameter are WRITTEN to the tensors bound as "<key>#grad" (the six parameters the
  * reference never back-propagates into -- SURVEY 8a quirk (i) -- are not touched).
  * Data parallelism: every rank runs this on its own shard; averaging the "#grad" tensors across
- * ranks (RCCL all-reduce, done by the host with torch.distributed) precedes the optimizer. * The packed weight panels are refreshed first when mc_bind_params or mc_clip_adamw_step made them
+ * ranks precedes the optimizer -- mc_backward does it itself once mc_comm_init gave the handle a communicator (see
+ * "data parallelism" below), otherwise the host does (torch.distributed, or mc_allreduce_grads).  The packed weight panels are refreshed first when mc_bind_params or mc_clip_adamw_step made them
  * stale; after any other in-place parameter update call mc_pack_params yourself. */
 int mc_forward_train(mc_handle *h, const float *img, const mc_labels *labels, int B, int H, int W,
                      int max_objs, float *const preds[MC_NUM_PREDS], float *losses, void *stream);
@@ -179,6 +180,30 @@ int mc_head_forward_train(mc_handle *h, const float *feat, const mc_labels *labe
 int mc_head_backward(mc_handle *h, const float *grad_losses, float *grad_feat, void *stream);
 /* Debugging aid: activation (which=0) or gradient (which=1) of node `node` of the train plan as NCHW. */
 int mc_train_debug_node(mc_handle *h, int node, int which, float *out_nchw, int dims[4], void *stream);
+
+/* ---- data parallelism -----------------------------------------------------------
+ * The reference is single-GPU (README.MD:11,15: "multi-GPU training is not supported"); these entry points are the
+ * MI355X-side addition BASELINE.json's north_star asks for: one process per GPU, every rank a full replica, the
+ * gradients averaged over the ranks once per step on RCCL over xGMI, then identical clip + AdamW on every rank.  They
+ * stand where torch's DistributedDataParallel would wrap `self.model` in engine/monocon_engine.py:28-32.
+ * mc_comm_unique_id: rank 0 creates the 128-byte RCCL id and hands it to the other ranks by any host-side channel.
+ * mc_comm_init: collective over all ranks (ncclCommInitRank); the handle owns the communicator and its stream.
+ * mc_allreduce_grads: every tensor bound as "<key>#grad" <- its average over the ranks, in place, on `stream` (one
+ *   ncclAllReduce per gradient bucket when the tensors form dense ranges, see csrc/mc_comm.hip).
+ * With a communicator in place (and overlap on, the default) mc_backward performs this exchange itself, bucket by
+ * bucket on the communicator's stream while the rest of the backward runs, and returns with `stream` waiting for it:
+ * do NOT call mc_allreduce_grads again after such a backward.  mc_comm_set_overlap(h, 0) turns that off.
+ * mc_comm_info: rank / world / overlap flag, the number of collectives one exchange issues for the current binding,
+ * the all-reduce calls issued so far, and the RCCL library in use.  mc_comm_exposed_ms: how long the last overlapped
+ * exchange kept `stream` waiting at the end of mc_backward (synchronises). */
+int mc_comm_unique_id(mc_handle *h, void *id128);
+int mc_comm_init(mc_handle *h, int rank, int world, const void *id128);
+int mc_comm_destroy(mc_handle *h);
+int mc_comm_set_overlap(mc_handle *h, int on);
+int mc_comm_info(mc_handle *h, int *rank, int *world, int *overlap, int *n_collectives, unsigned long long *launches,
+                 char *lib_path, int lib_path_len);
+int mc_comm_exposed_ms(mc_handle *h, float *ms);
+int mc_allreduce_grads(mc_handle *h, void *stream);
 
 /* ---- optimizer ---------------------------------------------------------------------------
  * Replaces clip_grad_norm_(max_norm, L2) + torch.optim.AdamW.step (engine/monocon_engine.py:94-102;
@@ -260,7 +285,9 @@ int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], dou
  * fp32 activations / master weights / BN statistics / losses (BASELINE config 3; not within the 1e-4
  * parity tolerance).  2: fp32 EMULATED on the bf16 pipe -- both operands split into three bf16 pieces, six
  * partial products per multiply accumulated in fp32; as close to the fp64 reference as the fp32 MFMA path (same
- * parity tolerances), ~2.7x its matrix rate.  Re-pack (mc_pack_params) before the next forward. */
+ * parity tolerances), ~2.7x its matrix rate.  3: fp32 EMULATED on the fp16 pipe -- every operand tensor scaled by the
+ * power of two its max |x| dictates, split into two fp16 pieces, three partial products per multiply; same parity
+ * tolerances, half the matrix work of mode 2.  Re-pack (mc_pack_params) before the next forward. */
 int mc_set_precision(mc_handle *h, int mode);
 /* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
  * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel, 32 = the LDS-free

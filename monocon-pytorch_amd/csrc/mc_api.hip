@@ -574,6 +574,7 @@ int mc_destroy(mc_handle *h) {
     if (h->decode_filt) (void)hipFree(h->decode_filt);
     if (h->loss_ws) (void)hipFree(h->loss_ws);
     if (h->train && h->train_free) h->train_free(h->train);
+    if (h->comm && h->comm_free) h->comm_free(h->comm);
     if (h->opt_tab) (void)hipFree(h->opt_tab);
     if (h->opt_chunks) (void)hipFree(h->opt_chunks);
     if (h->opt_ws) (void)hipFree(h->opt_ws);

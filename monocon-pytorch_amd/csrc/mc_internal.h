@@ -19,6 +19,22 @@
 using namespace mc;
 
 struct TrainState;   // mc_train_plan.hip
+struct CommState;    // mc_comm.hip
+
+// data parallelism: the bound "<key>#grad" tensors in groups, in the order the backward pass completes them
+// (0: heads + neck, 1: backbone.level5, 2: backbone.level4, 3: the rest of the backbone)
+constexpr int MC_NUM_GRAD_BUCKETS = 4;
+struct GradBucket {
+    float *p = nullptr;                                  // dense address range [p, p + n) ...
+    size_t n = 0;
+    std::vector<std::pair<float *, size_t>> parts;       // ... or, when the tensors are scattered, one entry per tensor
+    int tensors = 0;
+};
+int mc_grad_bucket_of(const std::string &param_name);
+bool mc_comm_overlap_active(mc_handle *h);               // a communicator exists and mc_backward overlaps the exchange
+int mc_comm_prepare(mc_handle *h);
+int mc_comm_fire_bucket(mc_handle *h, int bucket, hipStream_t main, hipStream_t side);
+int mc_comm_join(mc_handle *h, hipStream_t main);
 
 struct Bound {
     void *ptr;
@@ -132,6 +148,9 @@ struct mc_handle {
     mc::FoldBatch folds;
     unsigned long long pack_tab_gen = ~0ull;
     int pack_tab_prec = -1;
+    // RCCL communicator owned by the handle (mc_comm_init)
+    CommState *comm = nullptr;
+    void (*comm_free)(CommState *) = nullptr;
     // train plan: all target tensors / all regression-gradient maps live in one arena each, so the
     // per-step zero fill is one memset instead of 17 + 8 (mc_make_targets / mc_losses_backward)
     void *tgt_arena = nullptr, *dp_arena = nullptr;

@@ -64,6 +64,9 @@ struct TrainState {
     // backward closures that only produce weight gradients (nothing downstream in the step reads them) run
     // on a second stream: MFMA-bound wgrad overlaps the HBM-bound BN passes and the tails of the dgrad chain
     std::vector<char> bwd_side;
+    // data parallelism: gradient bucket b (mc_internal.h) is complete once backward closure bucket_after[b] has been
+    // enqueued (-1: no closure writes into it)
+    int bucket_after[MC_NUM_GRAD_BUCKETS] = {-1, -1, -1, -1};
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> side_ev;
     hipEvent_t side_done = nullptr;
@@ -701,9 +704,16 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         if (h->prec == 3) h->w_amax_of[w3dense] = h->head3.w_amax;     // the dense copy shares the fused head panel's maximum
         b.emit_dgrad(w3dense, dxT, CP, 64, 3, 1, 0, feat, CP);
     }
+    // everything enqueued so far writes head gradients (bucket 0)
+    ts->bucket_after[0] = (int)ts->bwd.size() - 1;
     // ---- neck + backbone in reverse forward order
     for (int ri = (int)ts->recs.size() - 1; ri >= 0; --ri) {
         const Rec r = ts->recs[ri];
+        struct Mark {      // closures pushed while this record is processed complete gradients of its layer group
+            TrainState *t; int b; size_t n0;
+            ~Mark() { if (t->bwd.size() > n0) t->bucket_after[b] = std::max(t->bucket_after[b], (int)t->bwd.size() - 1); }
+        } mark{ts, mc_grad_bucket_of(r.kind == REC_DECONV ? r.D->name : (r.kind == REC_POOL ? std::string("backbone.") : r.bn)),
+               ts->bwd.size()};
         if (r.kind == REC_POOL) {
             TNode &in = ts->nodes[r.in];
             const TNode &o = ts->nodes[r.z];
@@ -897,6 +907,10 @@ int mc_backward(mc_handle *h, const float *grad_losses, void *stream) {
     ts->grad_losses = grad_losses;
     size_t k = 0;
     bool used_side = false;
+    // data parallelism with a communicator owned by the handle: every gradient bucket is exchanged (averaged over the
+    // ranks) on the communicator's stream as soon as its last writer has been enqueued
+    const bool dp = !ts->head_only && mc_comm_overlap_active(h);
+    if (dp && mc_comm_prepare(h)) return -1;
     for (size_t i = 0; i < ts->bwd.size(); ++i) {
         if (ts->dual && ts->bwd_side[i] && k < ts->side_ev.size()) {
             // everything this closure reads (dY of its layer, forward activations) is ready at this point of
@@ -909,10 +923,18 @@ int mc_backward(mc_handle *h, const float *grad_losses, void *stream) {
         } else if (ts->bwd[i](h, st)) {
             return -1;
         }
+        if (dp)
+            for (int b = 0; b < MC_NUM_GRAD_BUCKETS; ++b)
+                if (ts->bucket_after[b] == (int)i && mc_comm_fire_bucket(h, b, st, used_side ? ts->side : nullptr)) return -1;
     }
     if (used_side) {
         HIPCHK(h, hipEventRecord(ts->side_done, ts->side));
         HIPCHK(h, hipStreamWaitEvent(st, ts->side_done, 0));
+    }
+    if (dp) {
+        for (int b = 0; b < MC_NUM_GRAD_BUCKETS; ++b)       // a bucket no closure of this plan writes into still has to be exchanged
+            if (ts->bucket_after[b] < 0 && mc_comm_fire_bucket(h, b, st, nullptr)) return -1;
+        if (mc_comm_join(h, st)) return -1;
     }
     return 0;
 }

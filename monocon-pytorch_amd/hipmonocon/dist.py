@@ -96,6 +96,68 @@ def all_ranks_ok(ok, device=None):
     return bool(t.item())
 
 
+def dp_backend():
+    """who averages the gradients across ranks.  'rccl': the communicator owned by the C handle (csrc/mc_comm.hip) --
+    bucketed, overlapped with the backward, no PyTorch in the data path; the default whenever torch.distributed runs
+    on the 'nccl' (= RCCL) backend.  'torch': one torch.distributed all_reduce of the flat buffer after the backward --
+    the default on 'gloo' (CPU / several ranks on one device, which RCCL refuses) and the yard-stick the tests hold the
+    former to.
+    MONOCON_HIP_DP=rccl|torch overrides."""
+    forced = os.environ.get("MONOCON_HIP_DP", "").strip().lower()
+    if forced in ("rccl", "torch"):
+        return forced
+    if not is_distributed():
+        return "torch"
+    import torch.distributed as dist
+    return "rccl" if dist.get_backend() == "nccl" else "torch"
+
+
+def ensure_engine_comm(engine, force=False):
+    """Give the engine's handle its RCCL communicator (once): rank 0 creates the id, torch.distributed (any backend)
+    is only the host-side channel that carries its 128 bytes.  With ``force`` a world-1 communicator is created even
+    without torch.distributed (self-test on a one-GPU box).  Returns True when the handle exchanges the gradients
+    itself.  A communicator that cannot be built is a hard error on the 'rccl' backend unless MONOCON_HIP_DP_FALLBACK=1."""
+    if engine.comm_world:
+        return True
+    world, rank = 1, 0
+    if is_distributed():
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+    elif not force:
+        return False
+    if not force and dp_backend() != "rccl":
+        return False
+    try:
+        if world > 1:
+            import torch.distributed as dist
+            dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                t.copy_(torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            uid = bytes(t.cpu().numpy().tobytes())
+        else:
+            uid = engine.comm_unique_id()
+        engine.comm_init(rank, world, uid)
+    except Exception as e:      # noqa: BLE001
+        ok = False
+        err = e
+    else:
+        ok, err = True, None
+    if world > 1 and not all_ranks_ok(ok, engine.device):
+        ok = False
+    if not ok:
+        if engine.comm_world:
+            engine.comm_destroy()
+        if os.environ.get("MONOCON_HIP_DP_FALLBACK", "0") == "1" and not force:
+            if rank == 0:
+                print("[hipmonocon] RCCL communicator unavailable (%s): falling back to torch.distributed all_reduce" % (err,), flush=True)
+            os.environ["MONOCON_HIP_DP"] = "torch"
+            return False
+        raise RuntimeError("could not build the handle's RCCL communicator: %s" % (err,))
+    return True
+
+
 class FlatGrads:
     """One contiguous buffer holding the gradients of ``named`` (name, tensor-like with .shape/.numel)
     in order; ``views[name]`` aliases the slice of each tensor.  Slices start at multiples of 4
@@ -115,8 +177,11 @@ class FlatGrads:
         if not is_distributed():
             return self.flat
         import torch.distributed as dist
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.div_(dist.get_world_size(group))
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)        # sum / world inside the collective
+        else:                                                                    # gloo has no AVG
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.mul_(1.0 / dist.get_world_size(group))
         return self.flat
 
 

@@ -47,6 +47,7 @@ class Engine:
         self.h = h
         self._sig = None
         self._keep = None
+        self.comm_world = 0        # > 0: the handle owns an RCCL communicator (comm_init)
 
     def close(self):
         if getattr(self, "h", None):
@@ -318,6 +319,48 @@ class Engine:
         _lib.check(self.h, self.lib.mc_set_precision(self.h, int(mode)), "mc_set_precision")
         self._sig = None          # panels must be re-packed
         self.precision = int(mode)
+
+    # ---- data parallelism through the C-ABI (csrc/mc_comm.hip)
+    def comm_unique_id(self):
+        """rank 0: the 128-byte RCCL id the other ranks need for comm_init (ship it by any host-side channel)"""
+        buf = C.create_string_buffer(128)
+        _lib.check(self.h, self.lib.mc_comm_unique_id(self.h, buf), "mc_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        """collective over all ranks: the handle gets its own RCCL communicator; from then on mc_backward exchanges
+        (averages) the gradients itself, overlapped with the backbone's backward"""
+        assert len(unique_id) == 128
+        with torch.cuda.device(self.device):
+            _lib.check(self.h, self.lib.mc_comm_init(self.h, int(rank), int(world), C.c_char_p(unique_id)), "mc_comm_init")
+        self.comm_world = int(world)
+
+    def comm_destroy(self):
+        _lib.check(self.h, self.lib.mc_comm_destroy(self.h), "mc_comm_destroy")
+        self.comm_world = 0
+
+    def comm_set_overlap(self, on):
+        _lib.check(self.h, self.lib.mc_comm_set_overlap(self.h, int(bool(on))), "mc_comm_set_overlap")
+
+    def comm_info(self):
+        r, w, o, n = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        la = C.c_ulonglong(0)
+        path = C.create_string_buffer(256)
+        _lib.check(self.h, self.lib.mc_comm_info(self.h, C.byref(r), C.byref(w), C.byref(o), C.byref(n), C.byref(la), path, 256),
+                   "mc_comm_info")
+        return {"rank": r.value, "world": w.value, "overlap": bool(o.value), "collectives_per_exchange": n.value,
+                "launches": la.value, "library": path.value.decode()}
+
+    def comm_exposed_ms(self):
+        """how long the last overlapped exchange kept the stream waiting at the end of mc_backward (synchronises)"""
+        ms = C.c_float(-1.0)
+        _lib.check(self.h, self.lib.mc_comm_exposed_ms(self.h, C.byref(ms)), "mc_comm_exposed_ms")
+        return float(ms.value)
+
+    def allreduce_grads(self):
+        """every bound '<key>#grad' tensor <- its average over the ranks (for a backward that ran with overlap off)"""
+        with torch.cuda.device(self.device):
+            _lib.check(self.h, self.lib.mc_allreduce_grads(self.h, _stream()), "mc_allreduce_grads")
 
     def set_conv_cfg(self, cfg):
         """force a workgroup shape of the fused conv (tuning / tests); 0 = automatic."""

@@ -17,6 +17,7 @@ EXPORTS = (
     "mc_forward_infer", "mc_backbone_forward", "mc_neck_forward", "mc_head_forward", "mc_decode", "mc_make_targets", "mc_losses", "mc_losses_backward", "mc_losses_backward_pred", "mc_forward_train", "mc_backward", "mc_train_generation", "mc_head_forward_train", "mc_head_backward", "mc_train_debug_node", "mc_optim_bind", "mc_clip_adamw_step", "mc_op_conv", "mc_op_conv_wgrad", "mc_op_conv_dgrad", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
     "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_query_workspace", "mc_forward_cost",
     "mc_preprocess", "mc_profile_forward", "mc_profile_train", "mc_set_precision", "mc_set_conv_cfg", "mc_bench_conv", "mc_bench_mfma_peak",
+    "mc_comm_unique_id", "mc_comm_init", "mc_comm_destroy", "mc_comm_set_overlap", "mc_comm_info", "mc_comm_exposed_ms", "mc_allreduce_grads",
 )
 
 
@@ -99,6 +100,13 @@ def load():
     lib.mc_profile_train.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i), vp]
     lib.mc_preprocess.argtypes = [vp, vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, i, vp, vp]
     lib.mc_op_conv_dgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, vp, vp]
+    lib.mc_comm_unique_id.argtypes = [vp, vp]
+    lib.mc_comm_init.argtypes = [vp, i, i, vp]
+    lib.mc_comm_destroy.argtypes = [vp]
+    lib.mc_comm_set_overlap.argtypes = [vp, i]
+    lib.mc_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_ulonglong), C.c_char_p, i]
+    lib.mc_comm_exposed_ms.argtypes = [vp, fp]
+    lib.mc_allreduce_grads.argtypes = [vp, vp]
     lib.mc_set_precision.argtypes = [vp, i]
     lib.mc_set_conv_cfg.argtypes = [vp, i]
     lib.mc_bench_conv.argtypes = [vp, i, i, i, i, C.POINTER(i), i, i, i, i, i, fp]

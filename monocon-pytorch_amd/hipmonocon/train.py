@@ -109,7 +109,13 @@ class _HipTrainStep(torch.autograd.Function):
         with torch.cuda.device(g.device):
             rc = eng.lib.mc_backward(eng.h, C.c_void_p(g.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(eng.h, rc, "mc_backward")
-        tb.flat.allreduce_mean()                                  # data parallel: one RCCL all-reduce per step
+        # data parallel: with a communicator owned by the handle mc_backward already exchanged the gradients bucket by
+        # bucket, overlapped with the backbone's backward (csrc/mc_comm.hip); otherwise one all-reduce of the flat buffer
+        if eng.comm_world:
+            if not eng.comm_info()["overlap"]:
+                eng.allreduce_grads()
+        else:
+            tb.flat.allreduce_mean()
         out = []
         for n, p in tb.named:
             gb = tb.grads.get(n)
@@ -167,6 +173,8 @@ def forward_train(detector, data_dict):
         if p.grad is not None and p.grad.data_ptr() == tb.grads[n].data_ptr():
             p.grad = p.grad.clone()
     eng = detector._rt.get(tb.state(detector))
+    if not eng.comm_world and _dist.is_distributed():
+        _dist.ensure_engine_comm(eng)                         # 'rccl' backend: the handle exchanges the gradients itself
     params = [p for _, p in tb.named]
     out = _HipTrainStep.apply(detector, tb, eng, img.contiguous(), label, detector.head.max_objs, *params)
     losses, preds = out[:10], out[10:]

@@ -50,7 +50,7 @@ def test_product_never_imports_oracle():
 
 def test_bench_cli_contract_without_a_gpu():
     """`python bench.py --gpus N --steps K --warmup W` is the driver's contract: the flags exist, default to one GPU and a
-    run of minutes, and the headline precision mode is one of the two fp32 parity modes."""
+    run of minutes, and the headline precision mode is one of the three fp32 parity modes."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
@@ -58,4 +58,4 @@ def test_bench_cli_contract_without_a_gpu():
     for flag in ("--gpus", "--steps", "--warmup", "--batch", "--precision", "--no-cpu-baseline"):
         assert flag in r.stdout, flag
     src = open(os.path.join(REPO, "bench.py")).read()
-    assert 'choices=("bf16x3", "fp32")' in src and '"--gpus", type=int, default=1' in src
+    assert 'choices=("f16x2", "bf16x3", "fp32")' in src and '"--gpus", type=int, default=1' in src
