@@ -10,17 +10,25 @@ generation, the ten losses, backward (dgrad + wgrad), gradient all-reduce over R
 fused clip + AdamW and the cyclic schedule -- at B=32 images per GPU, 3x384x1280.
 
 Precision of the headline: fp32 VALUES everywhere (activations, gradients, weights, BN statistics,
-losses -- the reference trains in fp32), with the convolution arithmetic EMULATED on the bf16 matrix
-pipe ("bf16x3": every fp32 operand split into three bf16 pieces, six partial products, fp32
-accumulation).  It meets the same fp32 tolerances as the native fp32 MFMA path:
-every golden test of `pytest -m gpu` runs in both modes.  `native_fp32` repeats the measurement on
-v_mfma_f32_32x32x2_f32; `mixed_precision` (plain bf16 operands, BASELINE configs[2]) is a side
-figure -- it does NOT track the fp32 reference within the parity budget (numbers in DESIGN.md 3a).
+losses -- the reference trains in fp32), with the convolution arithmetic EMULATED on the fp16 matrix
+pipe ("f16x2": every operand tensor scaled by the power of two its max |x| dictates and split into
+two fp16 pieces, three partial products, fp32 accumulation).  It meets the same
+fp32 tolerances as the native fp32 MFMA path: every golden test of `pytest -m gpu` runs in all three
+fp32 modes, incl. the reference-fp64 train-step golden at the headline shape
+(tests/test_hip_train_full.py).  `native_fp32` repeats the measurement on v_mfma_f32_32x32x2_f32,
+`fp32_emulated_bf16x3` on the 3-way bf16 split (round 2's headline); `mixed_precision` (plain bf16
+operands, BASELINE configs[2]) is a side figure -- it does NOT track the fp32 reference within the
+parity budget (numbers in DESIGN.md 3a).  `realistic_loop` repeats the headline with what the
+reference's loop does around the step (engine/monocon_engine.py:84-102): fresh label tensors every
+step (label validation = a host sync), uint8 frames copied host -> device on a second stream and
+normalised / padded on the GPU, `total_loss.item()` every step.
 
 For N>1 the driver launches this file under torch.distributed.run (plain `python bench.py --gpus N`
 re-launches itself that way): one process per GPU, every rank steps its own B=32 shard (weak
-scaling), one all-reduce of the flat 78 MB gradient buffer per step; timing is barrier +
-synchronize bracketed and the MAX over ranks is reported.
+scaling), the 78 MB of gradients averaged over the ranks once per step -- four buckets on the
+handle's own RCCL communicator, launched from inside mc_backward as the backward completes them
+(csrc/mc_comm.hip) -- timing is barrier + synchronize bracketed and the MAX over ranks is reported;
+`multi_gpu` carries every rank's own step time and the exposed part of the exchange.
 
 Rank 0 prints ONE JSON line: the throughput, `roofline` of the dominant kernel family of the step
 (forward convolutions + data gradients, timed live with HIP events around every launch on the
@@ -59,8 +67,10 @@ def parse():
     ap.add_argument("--forward-steps", type=int, default=10,
                     help="also time this many eval forwards (BASELINE configs[1]); 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
-    ap.add_argument("--precision", default=os.environ.get("MONOCON_BENCH_PRECISION", "bf16x3"), choices=("f16x2", "bf16x3", "fp32"),
-                    help="precision mode of the headline value: both keep fp32 values and meet the fp32 parity tolerances")
+    ap.add_argument("--precision", default=os.environ.get("MONOCON_BENCH_PRECISION", "f16x2"), choices=("f16x2", "bf16x3", "fp32"),
+                    help="precision mode of the headline value: all three keep fp32 values and meet the fp32 parity tolerances")
+    ap.add_argument("--realistic-steps", type=int, default=6,
+                    help="steps of the realistic_loop leg (fresh labels + H2D of uint8 frames + loss.item() per step); 0 = skip")
     ap.add_argument("--no-extra-modes", action="store_true",
                     help="skip the fp32_emulated / mixed_precision legs (profiles/collect.sh: keeps the kernel trace on the headline path)")
     return ap.parse_args()
@@ -142,9 +152,11 @@ def cpu_baseline(sd, height, width, budget_s):
         return float(np.median(times)), len(times)
 
     med, n = timed(lambda: one_step(sd), budget_s)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {"value": round(2 / med, 3), "unit": "images/sec", "cores": threads, "kind": "port", "cpu": _cpu_model(),
            "sample": "oracle full train step (fwd + targets + losses + autograd bwd + clip + AdamW), B=2 x 3x%dx%d fp32, "
-                     "median of %d runs (%.3f s/run)" % (height, width, n, med)}
+                     "median of %d runs (%.3f s/run), %d threads (%s; %d logical CPUs visible)"
+                     % (height, width, n, med, threads, "the cgroup quota / the knee of a conv probe", avail)}
     legs = {}
     with torch.no_grad():
         img2 = batch["img"]
@@ -291,13 +303,73 @@ def main():
         for _ in range(steps):
             total = step()
         sync_all()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
+        mine = time.perf_counter() - t0
+        elapsed = max_over_ranks(mine)
         assert bool(torch.isfinite(total)), "non-finite loss in the timed region (%s)" % mode
         out = {"ms_per_step": elapsed / steps * 1e3, "images_per_sec": world * B * steps / elapsed}
+        if dist_on:       # every rank's own clock + how long the last exchange kept its stream waiting
+            eng_ = m._rt.engine
+            exposed = eng_.comm_exposed_ms() if eng_.comm_world else -1.0
+            t = torch.tensor([mine / steps * 1e3, exposed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            out["per_rank_ms_per_step"] = [round(float(x[0]), 3) for x in allt]
+            out["per_rank_exposed_allreduce_ms"] = [round(float(x[1]), 3) for x in allt]
+            out["comm"] = eng_.comm_info() if eng_.comm_world else {"path": "torch.distributed all_reduce after backward"}
         if profile and rank == 0:
             out["profile"] = m._rt.engine.profile_train(iters=2)   # HIP events around every launch on the launch stream
             out["workspace_gb"] = m._rt.engine.workspace_bytes() / 1e9
         return out
+
+    def realistic_leg(mode, steps):
+        """The headline step inside the loop the reference runs around it (engine/monocon_engine.py:84-102): every step
+        gets NEW label tensors (so the label validation -- a host sync -- happens, as it would with a DataLoader), its frames
+        arrive as uint8 HWC in pinned host memory, are copied to the device on a second stream (overlapping the previous
+        step) and normalised / padded by mc_preprocess, and `total_loss.item()` is read every step."""
+        m.train().set_precision(mode)
+        eng_ = m._rt.engine
+        nb_ = min(B, 8)
+        frames_host = [torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(77 + i)).pin_memory()
+                       for i in range(2)]
+        labels_host = [synth.make_batch(600 + i + 10 * rank, nb_, H, W)["label"] for i in range(steps + 2)]
+        copy_stream = torch.cuda.Stream()
+        slots = [torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        ev = [torch.cuda.Event() for _ in range(2)]
+
+        def feed(i):        # H2D of step i's frames + labels on the copy stream
+            with torch.cuda.stream(copy_stream):
+                slots[i % 2].copy_(frames_host[i % 2], non_blocking=True)
+                lab = {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:B].pin_memory().cuda(non_blocking=True)
+                       for k, v in labels_host[i].items()}
+                ev[i % 2].record(copy_stream)
+            return lab
+
+        def one(i, lab):
+            torch.cuda.current_stream().wait_event(ev[i % 2])
+            img, _ = eng_.preprocess(list(slots[i % 2].unbind(0)))
+            opt.zero_grad()
+            _, loss = m({"img": img, "label": lab, "img_metas": {"pad_shape": [(H, W)] * B}})
+            total = sum(v for v in loss.values())
+            total.backward()
+            opt.step()
+            sch.step()
+            return total
+
+        lab = feed(0)
+        nxt = feed(1)
+        one(0, lab).item()                      # warm-up (same plan as the headline leg)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(1, steps + 1):
+            lab, nxt = nxt, feed(i + 1)
+            v = one(i, lab).item()              # the reference logs the loss every step (monocon_engine.py:89)
+        sync_all()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert np.isfinite(v)
+        return {"ms_per_step": round(dt / steps * 1e3, 3), "images_per_sec": round(world * B * steps / dt, 2), "steps": steps,
+                "workload": "headline train step inside the reference's loop: fresh label tensors per step (label validation "
+                            "host sync), uint8 HWC frames host -> device (pinned, second stream, %.0f MB/step) + mc_preprocess, "
+                            "total_loss.item() every step" % (B * H * W * 3 / 1e6)}
 
     def forward_leg(mode, steps):
         m.eval().set_precision(mode)
@@ -365,9 +437,16 @@ def main():
             r.update({"conv_ms": round(fprof["conv_ms"], 3), "other_ms": round(fprof["other_ms"], 3)})
             fl = cost["conv_flops"] + cost["other_flops"]
             by = cost["conv_bytes"] + cost["other_bytes"]
+            # the bound of north_star's "fraction of the HBM roofline" in this mode: the forward cannot run faster than its
+            # matrix work allows (algorithmic FLOPs x MFMAs per multiply-add / dense peak of the pipe it runs on)
+            t_hbm = by / (PEAK_HBM_GBS * 1e9)
+            t_mfma = cost["conv_flops"] * MODES[mode]["mfma_per_mac"] / (MODES[mode]["peak"] * 1e12)
             out.update({"roofline": r, "gflop_per_image": round(fl / B / 1e9, 2), "model_hbm_mb_per_image": round(by / B / 1e6, 1),
                         "whole_forward_tflops_fp32_equivalent": round(fl / (leg["ms_per_step"] * 1e-3) / 1e12, 2),
-                        "whole_forward_frac_of_hbm_peak": round(by / (leg["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+                        "whole_forward_frac_of_hbm_peak": round(by / (leg["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                        "max_attainable_hbm_frac": round(t_hbm / max(t_hbm, t_mfma), 4),
+                        "max_attainable_note": "HBM time of the fusion-model bytes (%.2f ms) / max(that, matrix-pipe time of the "
+                                               "convolutions at the dense peak of this mode's pipe (%.2f ms))" % (t_hbm * 1e3, t_mfma * 1e3)})
         return out
 
     # ---------------------------------------------------------------- the train step (headline)
@@ -378,11 +457,15 @@ def main():
 
     extra = {}
     if args.forward_steps > 0 and not args.no_extra_modes:
-        other = "fp32" if headline_mode != "fp32" else "bf16x3"
-        _phase("mode %s" % other)
-        extra[other] = (train_leg(other, args.steps, 2, profile=True), forward_leg(other, args.forward_steps))
+        for other in [o for o in ("fp32", "bf16x3", "f16x2") if o != headline_mode]:
+            _phase("mode %s" % other)
+            extra[other] = (train_leg(other, args.steps, 2, profile=True), forward_leg(other, args.forward_steps))
         _phase("mode bf16")
         extra["bf16"] = (train_leg("bf16", args.steps, 2, profile=False), forward_leg("bf16", args.forward_steps))
+    real = None
+    if args.realistic_steps > 0:
+        _phase("realistic loop (fresh labels, H2D of uint8 frames on a second stream, loss.item() per step)")
+        real = realistic_leg(headline_mode, args.realistic_steps)
     m.set_precision(headline_mode)
     eng = m.eval()._engine()
 
@@ -446,9 +529,16 @@ def main():
             elif mode == "fp32":
                 blk["workload"] = "the same train step / eval forward on the native fp32 MFMA (v_mfma_f32_32x32x2_f32)"
                 out["native_fp32"] = blk
-            else:
+            elif mode == "bf16x3":
                 blk["workload"] = "the same train step / eval forward with fp32 emulated on the bf16 matrix pipe (3-way operand split)"
-                out["fp32_emulated"] = blk
+                out["fp32_emulated_bf16x3"] = blk
+            else:
+                blk["workload"] = "the same train step / eval forward with fp32 emulated on the fp16 matrix pipe (2-way operand split)"
+                out["fp32_emulated_f16x2"] = blk
+        if real is not None:
+            out["realistic_loop"] = real
+        if dist_on:
+            out["multi_gpu"] = {k: head[k] for k in ("per_rank_ms_per_step", "per_rank_exposed_allreduce_ms", "comm") if k in head}
         if dec is not None:
             out["decode_only"] = dec
         if not args.no_cpu_baseline:
