@@ -59,6 +59,12 @@ struct WgB16Cfg {
 };
 
 __device__ __forceinline__ int lds_skew(int channel) { return ((channel >> 4) & 3) * 16; }
+// Which channel of its wave's 32 a lane reads (MFMA row / column li <-> channel lane_chan(li), an involution).  The LDS
+// serves a ds_read_b128 in the lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+32): with the identity mapping
+// a group straddles two 16-channel blocks, whose rows lds_skew() shifts against each other by 16 bytes -- half the 16-byte
+// windows of a group then collide (PMC, rounds 2 / 3: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.67).  Swapping lanes
+// 4-11 with 20-27 gives every group the 16 channels of ONE block: window = (7 or 15) * channel + const mod 16, a bijection.
+__device__ __forceinline__ int lane_chan(int li) { return ((li & 15) >= 4 && (li & 15) < 12) ? (li ^ 16) : li; }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     bf16x2 v;
@@ -86,12 +92,16 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
     const int wn = wave / WC, wc = wave % WC;
     const int g = lane >> 5, li = lane & 31;
     const int bid = xcd_order(blockIdx.x, gridDim.x);      // the tiles of one split-K slice read the same pixels
-    const int ct = bid % a.c_tiles;
-    const int nt = (bid / a.c_tiles) % a.n_tiles;
-    const int ks = bid / (a.c_tiles * a.n_tiles);
+    // (integer division by a run-time value is a vector-ALU sequence: its results are wave-uniform by construction, but
+    //  the compiler only knows that once told -- else the tile origin, the source pointer and with them every buffer
+    //  descriptor count as divergent and each load is wrapped in a readfirstlane "waterfall" loop)
+    const int ct = __builtin_amdgcn_readfirstlane(bid % a.c_tiles);
+    const int nt = __builtin_amdgcn_readfirstlane((bid / a.c_tiles) % a.n_tiles);
+    const int ks = __builtin_amdgcn_readfirstlane(bid / (a.c_tiles * a.n_tiles));
     const int n0 = nt * NB, c0 = ct * CB;
     const long long G = (long long)a.B * a.groups_per_img;
-    const int g_begin = (int)(G * ks / a.ksplit), g_end = (int)(G * (ks + 1) / a.ksplit);
+    const int g_begin = __builtin_amdgcn_readfirstlane((int)(G * ks / a.ksplit));
+    const int g_end = __builtin_amdgcn_readfirstlane((int)(G * (ks + 1) / a.ksplit));
 
     f32x16 acc[T];
 #pragma unroll
@@ -142,14 +152,17 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
 
     f32x4 xv[PB][NIX][2], dv[PB][NID][2];
     auto fetch = [&](int gi, int p) {
-        const int img = gi / a.groups_per_img;
+        // (wave-uniform by construction; the integer division runs on the vector ALU, so say so -- otherwise every
+        //  buffer load below is wrapped in a readfirstlane "waterfall" loop over its descriptor)
+        const int img = __builtin_amdgcn_readfirstlane(gi / a.groups_per_img);
         const int pp = (gi - img * a.groups_per_img) * PB + p;
         const __amdgpu_buffer_rsrc_t r_x =
             make_rsrc(xsrc + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
         const __amdgpu_buffer_rsrc_t r_d =
             make_rsrc(a.dy + (size_t)img * a.Hout * a.Wout * a.dy_ld, (unsigned)(a.Hout * a.Wout * a.dy_ld) * 4u);
         const bool valid = pp < a.ppi;
-        const int oy = (pp / a.ppr) * 4, ox = valid ? (pp % a.ppr) * 8 : DEAD;
+        const int prow = __builtin_amdgcn_readfirstlane(pp / a.ppr);
+        const int oy = prow * 4, ox = valid ? (pp - prow * a.ppr) * 8 : DEAD;
         const int xb = (oy * a.Win + ox) * Cs * 4;
         const int db = (oy * a.Wout + ox) * a.dy_ld * 4;
 #pragma unroll
@@ -190,8 +203,9 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
             if (NT * (i + 1) <= DP || tid + NT * i < DP) put(dyt + p * NB * DCH + d_dst[i], DPL, dv[p][i][0], dv[p][i][1], DCH, d_scale);
     };
 
-    const unsigned char *a_base = dyt + (wn * 32 + li) * DCH + lds_skew(wn * 32 + li) + g * 16;
-    const unsigned char *b_base = xt + (wc * 32 + li) * XCH + lds_skew(wc * 32 + li) + g * XROW;
+    const int lc = lane_chan(li);
+    const unsigned char *a_base = dyt + (wn * 32 + lc) * DCH + lds_skew(wn * 32 + lc) + g * 16;
+    const unsigned char *b_base = xt + (wc * 32 + lc) * XCH + lds_skew(wc * 32 + lc) + g * XROW;
 
     if (g_begin < g_end) {
 #pragma unroll
@@ -227,7 +241,12 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
                         const u32x4 lo = *reinterpret_cast<const u32x4 *>(row + z * XPL);
                         b0[z] = lo;
                         if (KS == 3) {
-                            const unsigned hi = *reinterpret_cast<const unsigned *>(row + z * XPL + 16);
+                            // pixels 8, 9 of the row: a second 16-byte read (conflict-free, 4 LDS cycles) rather than a
+                            // ds_read_b32, whose 32-lane groups meet 4-way on channel rows that are multiples of 16 bytes
+                            // (the empty asm keeps the compiler from narrowing it back to the one dword that is used)
+                            u32x4 hi4 = *reinterpret_cast<const u32x4 *>(row + z * XPL + 16);
+                            asm volatile("" : "+v"(hi4));
+                            const unsigned hi = hi4[0];
                             b1[z][0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
                             b1[z][1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
                             b1[z][2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16);
@@ -250,13 +269,13 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
             }
     }
     // ---- epilogue: partial[ks][tap][n][c];  D row = n, D col (lane) = c
-    const int c = c0 + wc * 32 + li;
+    const int c = c0 + wc * 32 + lc;
     if (c < a.Cin && c - cbase < Cs) {
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const int n = n0 + wn * 32 + lane_chan((r & 3) + 8 * (r >> 2) + 4 * g);
                 if (n < a.Cout) a.partial[(((size_t)ks * T + t) * a.Cout + n) * a.Cin + c] = SPL == 2 ? acc[t][r] * omul : acc[t][r];
             }
     }
