@@ -101,9 +101,11 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
     }
 }
 
-// Measurement aid (never set in production): MONOCON_HIP_DEBUG_SKIP=fold,fin,bfin,aact,abwd,cred turns the named
-// launches into no-ops -- results are then WRONG; the step time without a kernel family bounds what fusing it away
-// can gain (scratch/skip_bounds.sh).
+// Measurement aid, compiled in ONLY with -DMC_DEBUG_HOOKS (never in the shipped library: a stray environment
+// variable must not be able to turn launches into silent no-ops): MONOCON_HIP_DEBUG_SKIP=fold,fin,bfin,aact,abwd,cred
+// skips the named launches -- results are then WRONG; the step time without a kernel family bounds what fusing it
+// away can gain (scratch/skip_bounds.sh builds such a library).
+#ifdef MC_DEBUG_HOOKS
 static bool dbg_skip(const char *what) {
     static const char *e = std::getenv("MONOCON_HIP_DEBUG_SKIP");
     if (!e) return false;
@@ -112,6 +114,9 @@ static bool dbg_skip(const char *what) {
     const char c = p[std::strlen(what)];
     return (p == e || p[-1] == ',') && (c == 0 || c == ',');
 }
+#else
+static constexpr bool dbg_skip(const char *) { return false; }
+#endif
 int chan_reduce_blocks(int B, int rows_per_img) {
     const int r = red_rows(B, rows_per_img);
     return B * ((rows_per_img + r - 1) / r);

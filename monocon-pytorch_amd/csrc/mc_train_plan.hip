@@ -7,6 +7,7 @@
 // of tensors with several consumers (tree children, residuals, neck skips) accumulate in place
 // through the fused conv's residual input, and every conv uses the MFMA dgrad (= the forward
 // kernel on transposed/flipped panels) and the MFMA split-K wgrad.
+#include <atomic>
 #include <deque>
 #include <functional>
 
@@ -86,6 +87,8 @@ struct TrainState {
     bool head_only = false;
     const float *feat_ext = nullptr;
     float *gfeat_ext = nullptr;
+    bool skip_feat_dgrad = false;    // head-only plan, mc_head_backward(grad_feat = NULL)
+    int feat_dgrad_closure = -1;     // index in `bwd` of the data gradient into the external feat node
     // precision mode 3: one max-|x| slot per activation / gradient tensor, zeroed at the start of every forward
     unsigned *amax_arena = nullptr;
     int amax_used = 0;
@@ -97,7 +100,7 @@ struct TrainState {
 
 // generation of the activations the plan currently holds: bumped by every mc_forward_train on the handle (the plan
 // keeps ONE set of saved activations, so mc_backward always differentiates the LATEST forward)
-static unsigned long long g_train_generation = 0;
+static std::atomic<unsigned long long> g_train_generation{0};
 
 static void train_free(TrainState *t) {
     if (!t) return;
@@ -703,6 +706,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         ts->pack_fns.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_copy_batch(w3cb, st)); return 0; });
         if (h->prec == 3) h->w_amax_of[w3dense] = h->head3.w_amax;     // the dense copy shares the fused head panel's maximum
         b.emit_dgrad(w3dense, dxT, CP, 64, 3, 1, 0, feat, CP);
+        if (head_only) ts->feat_dgrad_closure = (int)ts->bwd.size() - 1;
     }
     // everything enqueued so far writes head gradients (bucket 0)
     ts->bucket_after[0] = (int)ts->bwd.size() - 1;
@@ -766,6 +770,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         const float *gp = ts->nodes[feat].g;
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
             if (ts->gfeat_ext) HIPCHK(hh, launch_nhwc_to_nchw(gp, B, 64, fh, fw, ts->gfeat_ext, st));
+            ts->gfeat_ext = nullptr;      // written once, for the call that asked for it: never a stale pointer later
             return 0;
         });
     }
@@ -835,8 +840,8 @@ static int forward_train_impl(mc_handle *h, const float *img, const mc_labels *l
         }
     }
     HIPCHK(h, ts->pack_batch.launch(st));
-    ++g_train_generation;
-    h->train_generation = g_train_generation;
+    h->train_generation = ++g_train_generation;
+    ts->gfeat_ext = nullptr;      // (a previous mc_head_backward's output tensor may be gone by now)
     for (auto &f : ts->fwd)
         if (f(h, st)) return -1;
     return 0;
@@ -897,11 +902,19 @@ int mc_train_debug_node(mc_handle *h, int node, int which, float *out_nchw, int 
     return 0;
 }
 
+static int backward_impl(mc_handle *h, TrainState *ts, const float *grad_losses, void *stream);
+
 int mc_backward(mc_handle *h, const float *grad_losses, void *stream) {
     if (!h) return -1;
     if (!grad_losses) return fail(h, "mc_backward: grad_losses is NULL");
+    if (h->train && h->train->head_only)
+        return fail(h, "mc_backward: the handle holds a heads-only plan (mc_head_forward_train): use mc_head_backward");
     TrainState *ts = h->train;
     if (!ts || !ts->img) return fail(h, "mc_backward: call mc_forward_train first");
+    return backward_impl(h, ts, grad_losses, stream);
+}
+
+static int backward_impl(mc_handle *h, TrainState *ts, const float *grad_losses, void *stream) {
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     ts->grad_losses = grad_losses;
@@ -912,6 +925,7 @@ int mc_backward(mc_handle *h, const float *grad_losses, void *stream) {
     const bool dp = !ts->head_only && mc_comm_overlap_active(h);
     if (dp && mc_comm_prepare(h)) return -1;
     for (size_t i = 0; i < ts->bwd.size(); ++i) {
+        if (ts->skip_feat_dgrad && (int)i == ts->feat_dgrad_closure) continue;
         if (ts->dual && ts->bwd_side[i] && k < ts->side_ev.size()) {
             // everything this closure reads (dY of its layer, forward activations) is ready at this point of
             // the main stream; its outputs (the weight gradient) are first needed after mc_backward
@@ -943,8 +957,10 @@ int mc_head_backward(mc_handle *h, const float *grad_losses, float *grad_feat, v
     if (!h) return -1;
     TrainState *ts = h->train;
     if (!ts || !ts->head_only || !ts->feat_ext) return fail(h, "mc_head_backward: call mc_head_forward_train first");
+    if (!grad_losses) return fail(h, "mc_head_backward: grad_losses is NULL");
     ts->gfeat_ext = grad_feat;
-    return mc_backward(h, grad_losses, stream);
+    ts->skip_feat_dgrad = grad_feat == nullptr;      // feat does not require grad: its 3x3 data gradient is not computed
+    return backward_impl(h, ts, grad_losses, stream);
 }
 
 int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], double bytes[3], int launches[3],

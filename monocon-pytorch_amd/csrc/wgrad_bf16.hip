@@ -287,11 +287,16 @@ static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
     if (a.pb != Cfg::PB) return hipErrorInvalidValue;
     auto kern = wgrad_bf16_kernel<KS, WN, WC, SPL>;
     static bool attr_set = false;
-    // experiment knob: MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the workgroups per CU
+    // experiment knob (only with -DMC_DEBUG_HOOKS): MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the
+    // workgroups per CU
     static const size_t lds_req = [] {
+#ifdef MC_DEBUG_HOOKS
         const char *e = std::getenv("MONOCON_HIP_WGRAD_LDS_KB");
         const size_t pad = e ? (size_t)std::atoi(e) * 1024 : 0;
         return pad > Cfg::LDS_BYTES ? pad : (size_t)Cfg::LDS_BYTES;
+#else
+        return (size_t)Cfg::LDS_BYTES;
+#endif
     }();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -112,12 +112,22 @@ class BaseEngine:
             if self.val_period > 0 and epoch % self.val_period == 0:
                 self.model.eval()
                 self._say("Evaluating on Epoch %d..." % epoch, indent=True)
-                # rank 0 evaluates (result export / the AP evaluator write files); the others wait at the barrier
+                # rank 0 evaluates (result export / the AP evaluator write files); the others wait for its verdict.  A
+                # failure on rank 0 (missing evaluator dependency, IO error) must not leave them parked in a collective
+                # until the watchdog kills the job: the success flag is all-reduced, and every rank raises together
+                eval_error = None
                 if self.is_main:
-                    eval_dict = self.evaluate()
-                    self._update_dict_to_writer(eval_dict, tag='eval')
+                    try:
+                        eval_dict = self.evaluate()
+                        self._update_dict_to_writer(eval_dict, tag='eval')
+                    except Exception as e:      # noqa: BLE001
+                        eval_error = e
                 if hdist.is_distributed():
-                    torch.distributed.barrier()
+                    ok = hdist.all_ranks_ok(eval_error is None, torch.device("cuda", torch.cuda.current_device()))
+                    if not ok and eval_error is None:
+                        raise RuntimeError("evaluation failed on rank 0 (see its log)")
+                if eval_error is not None:
+                    raise eval_error
                 self.model.train()
                 self.save_checkpoint(post_fix=None)
         self.save_checkpoint(post_fix='final')

@@ -158,6 +158,18 @@ def ensure_engine_comm(engine, force=False):
     return True
 
 
+def all_ranks_ok_many(flags, device=None):
+    """element-wise logical AND over ranks of several per-rank flags, in ONE collective"""
+    flags = [bool(f) for f in flags]
+    if not is_distributed():
+        return flags
+    import torch.distributed as dist
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return [bool(v) for v in t.tolist()]
+
+
 class FlatGrads:
     """One contiguous buffer holding the gradients of ``named`` (name, tensor-like with .shape/.numel)
     in order; ``views[name]`` aliases the slice of each tensor.  Slices start at multiples of 4

@@ -62,6 +62,13 @@ def _loss_grad_vector(grads, like):
     return torch.stack([zero if g is None else g.detach().reshape(()).float() for g in grads])
 
 
+def _own_scalars(vec):
+    """the entries of a device vector as 0-dim tensors with storage of their own (one multi-tensor copy)"""
+    out = [torch.empty((), dtype=vec.dtype, device=vec.device) for _ in range(vec.numel())]
+    torch._foreach_copy_(out, list(vec.unbind(0)))
+    return out
+
+
 class _HipTrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, detector, tb, eng, img, label, max_objs, *params):
@@ -90,9 +97,11 @@ class _HipTrainStep(torch.autograd.Function):
         torch.autograd.graph.increment_version(tb.buffers)        # running statistics were updated in place
         ctx.eng, ctx.tb, ctx.keep = eng, tb, (img, keep, preds, losses)
         ctx.mark_non_differentiable(*preds)
-        # ten separate 0-dim outputs (views of the one device vector the kernel wrote): the backward then receives the ten
-        # upstream gradients directly, instead of ten select-backward nodes each filling a zero vector and adding it
-        return (*losses.unbind(0), *preds)
+        # ten separate 0-dim outputs: the backward then receives the ten upstream gradients directly, instead of ten
+        # select-backward nodes each filling a zero vector and adding it.  They own their storage (one multi-tensor copy
+        # out of the device vector the kernel wrote): as outputs that are views of one buffer, an in-place loss weighting
+        # (loss_dict[k] *= w) would trip autograd's "output of a function that returns multiple views" check
+        return (*_own_scalars(losses), *preds)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -134,11 +143,17 @@ def _require_objects(detector, label, pad_hw, num_classes=3):
     """The reference asserts on empty targets (losses/l1_loss.py:15, README.MD:208-210) and fails with an index
     error for an object whose centre falls outside the feature map or whose class id is out of range
     (utils/target_generator.py:70-75: the heat-map / gather index is out of bounds); so does this path, before
-    anything is launched.  Reading the verdict back is a host sync, so a label set that was already validated
+    anything is launched.  One deliberate divergence: a NEGATIVE class id raises here, while the reference's Python
+    indexing wraps it silently (class -1 would splat into the last heat-map channel) -- a label error either way.  Reading the verdict back is a host sync, so a label set that was already validated
     (the SAME mask tensor object, unmodified: a resident batch stepped repeatedly) is not read back again."""
     mask = label["mask"]
     seen = getattr(detector, "_mask_validated", None)
-    if seen is not None and seen[0]() is mask and seen[1] == mask._version:
+    cached = seen is not None and seen[0]() is mask and seen[1] == mask._version
+    if _dist.is_distributed():
+        # every rank must take the same branch: a rank that skipped the validation while another one runs its
+        # collective would leave the latter hanging.  One MIN all-reduce decides -- all skip, or all validate.
+        cached = _dist.all_ranks_ok(cached, mask.device)
+    if cached:
         return
     H, W = pad_hw
     fh, fw = H // 4, W // 4
@@ -150,10 +165,12 @@ def _require_objects(detector, label, pad_hw, num_classes=3):
     yi = ((bb[..., 1] + bb[..., 3]) * hr / 2.0).trunc()
     bad = ((xi < 0) | (xi >= fw) | (yi < 0) | (yi >= fh) | (cls < 0) | (cls >= num_classes)) & (mask != 0)
     n_valid, n_bad = torch.stack([mask.sum(), bad.sum().to(mask.dtype)]).tolist()
-    if not _dist.all_ranks_ok(n_valid != 0, mask.device):
-        # data parallel: every rank raises together (a lone raise would leave the others in the all-reduce)
+    # data parallel: every rank raises together (a lone raise would leave the others in the all-reduce); both verdicts
+    # travel in ONE two-element MIN all-reduce
+    ok_valid, ok_inside = _dist.all_ranks_ok_many((n_valid != 0, n_bad == 0), mask.device)
+    if not ok_valid:
         raise AssertionError("no valid objects in the batch: l1_loss requires target.numel() > 0")
-    if not _dist.all_ranks_ok(n_bad == 0, mask.device):
+    if not ok_inside:
         raise IndexError("%d labelled object(s) with a box centre outside the %dx%d feature map or a class id outside "
                          "[0, %d): the reference's target generator indexes out of bounds for such labels"
                          % (int(n_bad), fh, fw, num_classes))
@@ -228,7 +245,7 @@ class _HipHeadTrainStep(torch.autograd.Function):
         torch.autograd.graph.increment_version(tb.buffers)
         ctx.eng, ctx.tb, ctx.keep, ctx.feat_shape = eng, tb, (feat, keep, preds, losses), feat.shape
         ctx.mark_non_differentiable(*preds)
-        return (*losses.unbind(0), *preds)
+        return (*_own_scalars(losses), *preds)
 
     @staticmethod
     def backward(ctx, *grads):

@@ -26,6 +26,7 @@ class AdamW(Optimizer):
         self.max_grad_norm = max_grad_norm
         self._engine = engine
         self._bound_sig = None
+        self._step_cache = None         # host-side copy of the common step count (None: re-read from the state)
         self.last_grad_norm = None      # device scalar of the most recent pre-clip norm
 
     def set_engine(self, engine):
@@ -38,6 +39,7 @@ class AdamW(Optimizer):
         tensors, which torch replaces here: the binding is dropped and rebuilt on the next step()."""
         super().load_state_dict(state_dict)
         self._bound_sig = None
+        self._step_cache = None
         # torch hands the caller's own 'step' (and same-device moment) tensors through uncopied; step() updates
         # them in place, so take private copies -- loading one checkpoint dict into two optimizers stays safe
         for st in self.state.values():
@@ -48,14 +50,22 @@ class AdamW(Optimizer):
     def __setstate__(self, state):
         super().__setstate__(state)
         self._bound_sig = None
+        self._step_cache = None
 
     def _common_step(self, plist):
         """The bias-correction step lives in ``state[p]['step']`` only (so it survives state_dict round trips);
-        the fused kernel applies one step number to all tensors, as they always share it in this train loop."""
+        the fused kernel applies one step number to all tensors, as they always share it in this train loop.  Reading
+        it back is one ``int()`` per tensor -- a host sync each if a resumed checkpoint left the step tensors on the
+        device -- so it is read once (after construction / load_state_dict / a change of the parameter list) and
+        tracked on the host from then on."""
+        key = len(plist)
+        if self._step_cache is not None and self._step_cache[0] == key:
+            return self._step_cache[1]
         steps = {int(self.state[p]['step']) for p in plist}
         if len(steps) != 1:
             raise NotImplementedError("fused AdamW: parameters at different step counts %s" % sorted(steps))
-        return steps.pop()
+        self._step_cache = (key, steps.pop())
+        return self._step_cache[1]
 
     def _bind(self, plist):
         eng = self._engine
@@ -102,6 +112,7 @@ class AdamW(Optimizer):
             return loss
         eng = self._bind(plist)
         step = self._common_step(plist) + 1
+        self._step_cache = (len(plist), step)
         for p in plist:
             self.state[p]['step'] += 1
         if self.last_grad_norm is None:

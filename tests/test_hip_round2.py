@@ -397,3 +397,48 @@ def test_bench_multi_rank_path_end_to_end(tmp_path):
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["steps"] == 2
     assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) <= 0.02 * d["value"]      # whole-job images / second
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0
+
+
+# ------------------------------------------------------------------------------------- round 3: advisor findings
+def test_loss_dict_entries_can_be_weighted_in_place(golden_sd):
+    """the ten losses are independent 0-dim tensors (not views of one buffer): `loss_dict[k] *= w` -- legal on the
+    reference's loss_dict -- works, and the backward sees the weight"""
+    batch = to_cuda(synth.make_batch(GOLDEN_SEED + 41, 2, 64, 128))
+    m = build(golden_sd)
+    _, loss = m(batch)
+    sum(loss.values()).backward()
+    g1 = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).clone()
+    m2 = build(golden_sd)
+    _, loss2 = m2(batch)
+    for k in loss2:
+        loss2[k] *= 2.0
+    sum(loss2.values()).backward()
+    g2 = torch.cat([p.grad.flatten() for p in m2.parameters() if p.grad is not None])
+    assert float((g2 - 2.0 * g1).abs().max()) <= 1e-6 * float(g1.abs().max()) + 1e-12
+
+
+def test_heads_only_plan_rules(golden_sd):
+    """mc_backward refuses a heads-only plan (mc_head_backward is its entry), and a heads-only backward whose feat does
+    not require grad skips the data gradient into feat yet leaves the same parameter gradients"""
+    import ctypes as C
+    from model import MonoConDenseHeads
+    from hipmonocon import lib as hlib
+    heads = MonoConDenseHeads(in_ch=64).cuda().train()
+    heads.load_state_dict({k[5:]: v for k, v in golden_sd.items() if k.startswith("head.")}, strict=True)
+    batch = to_cuda(synth.make_batch(GOLDEN_SEED + 42, 2, 64, 128))
+    feat = torch.randn(2, 64, 16, 32, device="cuda")
+    grads = []
+    for rg in (True, False):
+        for p in heads.parameters():
+            p.grad = None
+        f = feat.clone().requires_grad_(rg)
+        _, loss = heads.forward_train(f, batch)
+        sum(loss.values()).backward()
+        grads.append(torch.cat([p.grad.flatten() for p in heads.parameters()]).clone())
+        assert (f.grad is not None) == rg
+    # (the second forward starts from moved running statistics, whose mean is the shift of the variance sums: round-off only)
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-4 * float(grads[0].abs().max())
+    eng = heads._rt.engine
+    g = torch.ones(10, device="cuda")
+    rc = eng.lib.mc_backward(eng.h, C.c_void_p(g.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b"heads-only" in eng.lib.mc_last_error(eng.h)
