@@ -56,16 +56,9 @@ class MonoconEngine(BaseEngine):
             dataset = SyntheticMonoConDataset(length=n if is_train else max(n // 4, 1), height=int(hw[0]), width=int(hw[1]),
                                               max_objs=self.cfg.MODEL.HEAD.MAX_OBJS, seed=1 if is_train else 2)
         else:
-            # the KITTI file dataset (cv2 / pandas IO + augmentation) is outside the hot path;
-            # it is taken from the reference tree when that is importable
-            try:
-                from dataset.monocon_dataset import MonoConDataset
-            except ImportError as e:
-                from hipmonocon.lib import MonoconHipError
-                raise MonoconHipError(
-                    "DATA.ROOT=%r needs the KITTI file dataset (dataset/monocon_dataset.py, cv2 + pandas IO), which this "
-                    "package does not ship: put the reference tree on PYTHONPATH, or run with `DATA.ROOT synthetic` "
-                    "(import failed with: %s)" % (self.cfg.DATA.ROOT, e)) from e
+            # the KITTI file dataset (dataset/monocon_dataset.py: PIL decode, deterministic transforms; the random
+            # training augmentations of the reference are not built -- SURVEY 8f-4)
+            from dataset.monocon_dataset import MonoConDataset
             dataset = MonoConDataset(base_root=self.cfg.DATA.ROOT,
                                      split=self.cfg.DATA.TRAIN_SPLIT if is_train else self.cfg.DATA.TEST_SPLIT,
                                      max_objs=self.cfg.MODEL.HEAD.MAX_OBJS,

@@ -235,6 +235,7 @@ def main():
     dp_shards(sd_stats=stats)
     init_pins()
     train_full(sd_stats=stats)
+    dataset_pins()
 
 
 # ==================================================================== round-2 additions
@@ -415,8 +416,101 @@ def init_pins():
     save("init_pins.npz", **out)
 
 
+# ==================================================================== round-3 additions: input pipeline
+KITTI_MINI = os.path.join(HERE, "kitti_mini")
+# one line per labelled object: class, truncation, occlusion, alpha, bbox(4), h w l, x y z (camera 0, bottom centre), ry.
+# Frame 000007 is built so that every filter rule of dataset/monocon_dataset.py:96-125 fires exactly once:
+#   row 0 kept; row 1 occlusion 3; row 2 truncation 0.8; row 3 box height 10 < 25; row 4 depth 80 > 65; (DontCare: not an
+#   object row at all); row 5 kept, partly outside the image (keypoints off-frame); row 6 depth 1.2 < 2.
+MINI_LABELS = {
+    "000007": [
+        "Car 0.00 0 -1.58 587.01 173.33 614.12 200.12 1.65 1.67 3.64 -0.65 1.71 46.70 -1.59",
+        "Pedestrian 0.00 3 0.21 423.17 173.67 433.17 224.03 1.60 0.38 0.30 -5.87 1.63 23.11 -0.03",
+        "Cyclist 0.80 1 1.92 0.00 192.37 200.17 374.00 1.72 0.78 1.71 -4.61 1.70 5.10 1.19",
+        "Car 0.00 0 1.63 700.10 180.00 720.55 190.00 1.50 1.60 3.90 6.10 1.60 60.00 1.73",
+        "Car 0.00 1 -1.61 600.00 160.00 640.00 195.00 1.55 1.62 3.70 1.20 1.50 80.00 -1.60",
+        "DontCare -1 -1 -10 503.89 169.71 590.61 190.13 -1 -1 -1 -1000 -1000 -1000 -10",
+        "Car 0.30 0 -2.10 1100.00 150.00 1241.00 330.00 1.48 1.58 4.10 4.70 1.55 6.80 -1.50",
+        "Pedestrian 0.00 0 0.10 500.00 100.00 560.00 370.00 1.75 0.60 0.80 0.10 1.60 1.20 0.10",
+    ],
+    "000011": [
+        "Cyclist 0.00 0 -1.70 676.60 163.95 688.98 193.93 1.86 0.60 2.02 4.59 1.32 45.84 -1.60",
+        "Car 0.10 2 1.55 280.38 185.10 344.90 215.59 1.49 1.76 4.01 -15.71 2.16 38.26 1.16",
+        "DontCare -1 -1 -10 365.14 169.00 405.25 184.84 -1 -1 -1 -1000 -1000 -1000 -10",
+    ],
+}
+MINI_SHAPES = {"000007": (375, 1242), "000011": (370, 1224)}
+
+
+def write_kitti_mini():
+    """a two-frame KITTI tree: calibration in the benchmark's text layout (KITTI-typical numbers, jittered per frame),
+    the labels above, and smooth synthetic PNG frames (a few KB each)"""
+    from PIL import Image
+    for sub in ("image_2", "calib", "label_2"):
+        os.makedirs(os.path.join(KITTI_MINI, "training", sub), exist_ok=True)
+    os.makedirs(os.path.join(KITTI_MINI, "ImageSets"), exist_ok=True)
+    with open(os.path.join(KITTI_MINI, "ImageSets", "val.txt"), "w") as f:
+        f.write("\n".join(sorted(MINI_LABELS)) + "\n")
+    for k, (pid, lines) in enumerate(sorted(MINI_LABELS.items())):
+        H, W = MINI_SHAPES[pid]
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = np.stack([(xx * 255 // W + 17 * k) % 256, (yy * 255 // H) % 256, ((xx // 64 + yy // 32) * 40 + 60 * k) % 256], -1)
+        Image.fromarray(img.astype(np.uint8)).save(os.path.join(KITTI_MINI, "training", "image_2", pid + ".png"), optimize=True)
+        fx, cx, cy = 721.5377 - 3.7 * k, 609.5593 + 2.2 * k, 172.854 - 1.1 * k
+        def P(bx, by=0.0, bz=0.0):
+            return "%.6e %.6e %.6e %.6e %.6e %.6e %.6e %.6e %.6e %.6e %.6e %.6e" % (fx, 0, cx, bx, 0, fx, cy, by, 0, 0, 1, bz)
+        calib = ["P0: " + P(0.0), "P1: " + P(-387.5744), "P2: " + P(44.85728, 0.2163791, 0.002745884), "P3: " + P(-339.5242, 2.199936, 0.002729905),
+                 "R0_rect: 9.999239e-01 9.837760e-03 -7.445048e-03 -9.869795e-03 9.999421e-01 -4.278459e-03 7.402527e-03 4.351614e-03 9.999631e-01",
+                 "Tr_velo_to_cam: 7.533745e-03 -9.999714e-01 -6.166020e-04 -4.069766e-03 1.480249e-02 7.280733e-04 -9.998902e-01 -7.631618e-02 9.998621e-01 7.523790e-03 1.480755e-02 -2.717806e-01",
+                 "Tr_imu_to_velo: 9.999976e-01 7.553071e-04 -2.035826e-03 -8.086759e-01 -7.854027e-04 9.998898e-01 -1.482298e-02 3.195559e-01 2.024406e-03 1.482454e-02 9.998881e-01 -7.997231e-01"]
+        with open(os.path.join(KITTI_MINI, "training", "calib", pid + ".txt"), "w") as f:
+            f.write("\n".join(calib) + "\n")
+        with open(os.path.join(KITTI_MINI, "training", "label_2", pid + ".txt"), "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+def dataset_pins():
+    """(10) the reference's KITTICalibration / KITTISingleObject / KITTIMultiObjects (utils/data_classes.py, importable)
+    on the mini tree: calibration matrices and derived intrinsics, and per object -- after convert_cam(0 -> 2) and
+    convert_yaw(global -> local), in the order dataset/monocon_dataset.py:84-125 reads them -- class, box, location,
+    dimensions, local yaw, projected centre (+ depth), the 9 projected keypoints with their in-front flags, level.
+    (dataset/, transforms/ themselves need cv2 and cannot be imported: the label loop is NOT pinned by this.)"""
+    from utils.data_classes import KITTICalibration, KITTIMultiObjects            # noqa: E402  (reference)
+    write_kitti_mini()
+    out = {}
+    for pid in sorted(MINI_LABELS):
+        cf = os.path.join(KITTI_MINI, "training", "calib", pid + ".txt")
+        lf = os.path.join(KITTI_MINI, "training", "label_2", pid + ".txt")
+        calib = KITTICalibration(cf)
+        for k in ("P0", "P1", "P2", "P3", "R0", "V2C", "C2V", "I2V", "V2I"):
+            out["%s.calib.%s" % (pid, k)] = getattr(calib, k)
+        out["%s.calib.intr" % pid] = np.array([calib.cu, calib.cv, calib.fu, calib.fv, calib.tx, calib.ty], dtype=np.float64)
+        objs = KITTIMultiObjects.get_objects_from_label(lf, calib)
+        out["%s.n" % pid] = len(objs)
+        objs.convert_cam(src_cam=0, dst_cam=2)
+        objs.convert_yaw(src_type="global", dst_type="local")
+        for i, o in enumerate(objs):
+            tag = "%s.obj%d." % (pid, i)
+            out[tag + "cls"] = o.cls_num
+            out[tag + "occ_trunc_level"] = np.array([o.occlusion, o.truncation, o.level], dtype=np.float64)
+            out[tag + "box2d"] = o.box2d.copy()
+            out[tag + "box3d"] = np.concatenate([o.loc, o.dim, np.array([o.ry])], axis=0).astype(np.float64)
+            pc = o.projected_center
+            out[tag + "center"] = np.asarray(pc, dtype=np.float64).copy()
+            kp = o.projected_kpts
+            out[tag + "kpts"] = np.zeros((0, 3)) if kp is None else np.asarray(kp, dtype=np.float64)
+        info = objs.original_objects.info_dict
+        for k, v in info.items():
+            if k != "name":
+                out["%s.info.%s" % (pid, k)] = np.asarray(v, dtype=np.float64)
+    save("kitti_objects.npz", **out)
+
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "train_full":
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        dataset_pins()
+    elif len(sys.argv) > 1 and sys.argv[1] == "train_full":
         _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
         train_full(sd_stats=_stats)
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
