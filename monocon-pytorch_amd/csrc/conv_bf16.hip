@@ -179,15 +179,30 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                     (PLANAR ? 2 * m * CPL + ((tap / Cfg::KW) * RS + (tap % Cfg::KW)) * 16
                             : ((tap / Cfg::KW) * IW + (tap % Cfg::KW)) * ROWB + m * 32));
     };
-    pc8 bcur[SPL][WTN];
-    load_b(bcur, 0, 0);
+    // B (weight) fragments come straight from L2 and are fetched DB - 1 K-steps ahead into a register ring: slot s % DB
+    // holds step s.  One step ahead (round 2) covered 192 cycles of MFMA work for the one-tile-wide shapes -- less than an
+    // L2 round trip under load, so every step stalled on its weights (PMC: waves parked 40 % of the time); and the loads
+    // return in order, so a weight fetch issued behind the staging prefetch of the next chunk waits for HBM.
+    // Depth: as many slots as 48 registers hold (a slot is SPL * WTN fragments of 4 registers), among the divisors of NS.
+    constexpr int DB_FIT = 48 / (SPL * WTN * 4);
+    constexpr int DB = (WTM * WTN > 2) ? 2 : ((DB_FIT >= 6 && NS % 6 == 0) ? 6 : ((DB_FIT >= 3 && NS % 3 == 0) ? 3 : 2));
+    static_assert(NS % DB == 0, "ring slots must line up across K-chunks");
+    pc8 bq[DB][SPL][WTN];
+#pragma unroll
+    for (int j = 0; j < DB - 1; ++j) load_b(bq[j], 0, j);
 
-    int kbase = 0;
-    for (int si = 0; si < a.nsrc; ++si) {
-        const int Cs = a.src[si].C;
-        const __amdgpu_buffer_rsrc_t r_in =
-            make_rsrc(a.src[si].p + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
-        int voff[NIT], sdst[NIT];
+    // ---- K loop: one iteration per 32-channel chunk of the virtual concat.  Where the registers allow it (PF), the raw
+    //      fp32 data of chunk i+1 is fetched into registers BEFORE the MFMA phase of chunk i and converted / written to
+    //      LDS after it: the HBM / L2 latency of the staging loads is hidden behind this workgroup's own matrix work
+    //      instead of relying on the co-resident workgroup being in its MFMA phase at the right moment.
+    constexpr bool PF = NIT <= 8 && WTM * WTN <= 2;
+    constexpr int UB = NIT > 8 ? 8 : NIT;
+    f32x4 pv[PF ? NIT : 1];
+    int voff[NIT], sdst[NIT];
+    int si = 0, c0 = 0, kc = 0;
+    int Cs = a.src[0].C;
+    __amdgpu_buffer_rsrc_t r_in = make_rsrc(a.src[0].p + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
+    auto lane_offsets = [&](int cs) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int e = tid + NT * i;
@@ -198,13 +213,38 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
             const int y = pinfo[p * 4 + 1] * S - PAD + iy;
             const int x = pinfo[p * 4 + 2] * S - PAD + ix;
             const bool ok = e < TOTAL && pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
-            voff[i] = ok ? ((y * a.Win + x) * Cs + c4 * 4) * 4 : BUF_OOB;
+            voff[i] = ok ? ((y * a.Win + x) * cs + c4 * 4) * 4 : BUF_OOB;
             sdst[i] = PLANAR ? (c4 >> 1) * CPL + (p >> 1) * PPB + (iy * RS + ix + IW * (p & 1)) * 16 + (c4 & 1) * 8
                              : (int)(stage_dst - lds_raw) + i * (NT / C4) * ROWB;
         }
-        for (int c0 = 0; c0 < Cs; c0 += CK) {
-            if (kbase + c0 > 0) __syncthreads();
-            constexpr int UB = NIT > 8 ? 8 : NIT;
+    };
+    auto stage_one = [&](const f32x4 &v, int i) {       // split one float4 into its pieces and write them to the LDS planes
+        if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL)) {
+            pc4 q[SPL];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float r = SPL == 2 ? v[j] * a_scale : v[j];
+#pragma unroll
+                for (int pz = 0; pz < SPL; ++pz) {   // h = rnd(x), m = rnd(x - h), l = rnd(x - h - m)
+                    q[pz][j] = (pc_t)r;
+                    r -= (float)q[pz][j];
+                }
+            }
+#pragma unroll
+            for (int pz = 0; pz < SPL; ++pz) *reinterpret_cast<pc4 *>(lds_raw + sdst[i] + pz * PLANE) = q[pz];
+        }
+    };
+    lane_offsets(Cs);
+    if (PF) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) pv[i] = buf_load4(r_in, voff[i], 0);
+    }
+    for (bool first = true;; first = false) {
+        if (!first) __syncthreads();
+        if (PF) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) stage_one(pv[i], i);
+        } else {
 #pragma unroll
             for (int i0 = 0; i0 < NIT; i0 += UB) {
                 f32x4 v[UB];
@@ -212,38 +252,36 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                 for (int u = 0; u < UB; ++u)
                     if (i0 + u < NIT) v[u] = buf_load4(r_in, voff[i0 + u], c0 * 4);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const int i = i0 + u;
-                    if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL)) {
-                        pc4 q[SPL];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float r = SPL == 2 ? v[u][j] * a_scale : v[u][j];
-#pragma unroll
-                            for (int pz = 0; pz < SPL; ++pz) {   // h = rnd(x), m = rnd(x - h), l = rnd(x - h - m)
-                                q[pz][j] = (pc_t)r;
-                                r -= (float)q[pz][j];
-                            }
-                        }
-#pragma unroll
-                        for (int pz = 0; pz < SPL; ++pz)
-                            *reinterpret_cast<pc4 *>(lds_raw + sdst[i] + pz * PLANE) = q[pz];
-                    }
-                }
+                for (int u = 0; u < UB; ++u) stage_one(v[u], i0 + u);
             }
-            __syncthreads();
-            const int kc = kbase + c0;
+        }
+        __syncthreads();
+        // the chunk after this one (possibly the first of the next source): descriptors / lane offsets now, and with PF
+        // its loads go out before the MFMA phase
+        int nsi = si, nc0 = c0 + CK;
+        if (nc0 >= Cs) { ++nsi; nc0 = 0; }
+        const bool more = nsi < a.nsrc;
+        if (more && nsi != si) {
+            Cs = a.src[nsi].C;
+            r_in = make_rsrc(a.src[nsi].p + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
+            lane_offsets(Cs);
+        }
+        if (PF && more) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) pv[i] = buf_load4(r_in, voff[i], nc0 * 4);
+        }
+        {
             const int kc_next = (kc + CK < a.Cin) ? kc + CK : kc;
             pc8 acur[SPL][WTM];
             load_a(acur, 0);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                pc8 anext[SPL][WTM], bnext[SPL][WTN];
-                if (s + 1 < NS) {
-                    load_a(anext, s + 1);
-                    load_b(bnext, kc, s + 1);
-                } else {
-                    load_b(bnext, kc_next, 0);
+                pc8 anext[SPL][WTM];
+                if (s + 1 < NS) load_a(anext, s + 1);
+                {   // weights of step s + DB - 1 (of this chunk or the next) into the slot step s - 1 just released
+                    const int t = s + DB - 1;
+                    if (t < NS) load_b(bq[t % DB], kc, t);
+                    else load_b(bq[t % DB], kc_next, t - NS);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // partial products, smallest first: (piece of A, piece of B) with weight 2^-8*(i+j) >= 2^-16 relative
@@ -258,9 +296,9 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
                         for (int tn = 0; tn < WTN; ++tn) {
                             if (NACC == 2 && pp < NP - 1)
-                                accm[tm][tn] = mfma_k16(acur[PA[pp]][tm], bcur[PBv[pp]][tn], accm[tm][tn]);
+                                accm[tm][tn] = mfma_k16(acur[PA[pp]][tm], bq[s % DB][PBv[pp]][tn], accm[tm][tn]);
                             else
-                                acc[tm][tn] = mfma_k16(acur[SPL == 1 ? 0 : PA[pp]][tm], bcur[SPL == 1 ? 0 : PBv[pp]][tn], acc[tm][tn]);
+                                acc[tm][tn] = mfma_k16(acur[SPL == 1 ? 0 : PA[pp]][tm], bq[s % DB][SPL == 1 ? 0 : PBv[pp]][tn], acc[tm][tn]);
                         }
                 if (s + 1 < NS) {
 #pragma unroll
@@ -268,13 +306,10 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
                         for (int tm = 0; tm < WTM; ++tm) acur[q][tm] = anext[q][tm];
                 }
-#pragma unroll
-                for (int q = 0; q < SPL; ++q)
-#pragma unroll
-                    for (int tn = 0; tn < WTN; ++tn) bcur[q][tn] = bnext[q][tn];
             }
         }
-        kbase += Cs;
+        if (!more) break;
+        si = nsi; c0 = nc0; kc += CK;
     }
 
     if (NACC == 2) {
