@@ -56,6 +56,9 @@ def load():
         raise MonoconHipError(
             "libmonocon_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C monocon-pytorch_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    # torch first: it ships its own libamdhip64, and the process must end up with ONE HIP runtime -- loaded before torch,
+    # this library would bind the system runtime and then see no device next to torch's (measured on the GPU box)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     fp = C.POINTER(C.c_float)
