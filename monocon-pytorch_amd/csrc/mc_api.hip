@@ -1039,6 +1039,23 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
     a.out = alloc_fill((size_t)B * a.Hout * a.Wout * Cout, 0.0f);
     if (!a.wpk || !a.scale || !a.bias || !a.out) return fail(h, "mc_bench_conv: out of memory");
     a.out_ld = Cout; a.relu = 1; a.cfg = cfg;
+    if (h->prec >= 1 && cin % 32 == 0) {        // bf16 / fp16 pipe: piece panels (random finite bit patterns) + unit maxima
+        const size_t wn = (size_t)ksize * ksize * cin * a.CoutP;
+        std::vector<unsigned short> hw(wn * 3);
+        unsigned s16 = 777u;
+        for (auto &v : hw) { s16 = s16 * 1664525u + 1013904223u; v = (unsigned short)(0x2c00u + ((s16 >> 12) & 0x3ffu) + ((s16 >> 31) << 15)); }
+        void *q = nullptr;
+        if (hipMalloc(&q, hw.size() * 2) != hipSuccess) return fail(h, "mc_bench_conv: out of memory");
+        bufs.push_back(q);
+        (void)hipMemcpy(q, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+        a.wpk16 = q; a.prec = h->prec;
+        std::vector<unsigned> one((size_t)5 * AMAX_WORDS, 0x3f800000u);
+        if (hipMalloc(&q, one.size() * 4) != hipSuccess) return fail(h, "mc_bench_conv: out of memory");
+        bufs.push_back(q);
+        (void)hipMemcpy(q, one.data(), one.size() * 4, hipMemcpyHostToDevice);
+        for (int i = 0; i < nsrc; ++i) a.amax_in[i] = static_cast<unsigned *>(q) + (size_t)i * AMAX_WORDS;
+        a.amax_w = static_cast<unsigned *>(q) + (size_t)4 * AMAX_WORDS;
+    }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
