@@ -70,20 +70,19 @@ struct HeadBwdArgs {
     float *d, *dw_partial, *red_partial;
     int HW, rows_per_block, blocks_per_img;
 };
+// The rows of draw are the same for all lanes of a wave.  Round 2 took them down the scalar path (s_load per pixel):
+// measured in round 3 (rocprofv3: 2.07 ms, 2.4 TB/s, waves parked 85 % of the time) that path has no prefetch -- every
+// pixel of the 24-row head waited a full memory round trip for its 96 bytes.  Now a workgroup stages the rows of HB_PX
+// pixels in LDS with coalesced 16-byte loads (fetched one block ahead into registers) and every wave reads its rows as
+// LDS broadcasts.
+constexpr int HB_PX = 32, HB_LD = 80;
 template <int RB, int NR>
-__device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, int h, int lane, size_t p0, int np, int blk, int b) {
+__device__ __forceinline__ void head_bwd_block(const HeadBwdArgs &a, const float (*gsh)[HB_LD], int lane, int n, const float *xp,
+                                               const float *zp, float *dp, bool rez, float zsc, float zsh, const float (&w)[NR],
+                                               float (&acc)[NR], float &s1, float &s2) {
     constexpr int CP = NUM_HEADS * HEAD_CH;
-    typedef const float __attribute__((address_space(4))) cfloat;
-    float w[NR], acc[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) { w[r] = a.w1[(RB + r) * HEAD_CH + lane]; acc[r] = 0.f; }
-    float s1 = 0.f, s2 = 0.f;
-    const bool rez = a.z == nullptr;
-    const float zsc = rez ? a.scale[(size_t)b * CP + h * HEAD_CH + lane] : 0.f, zsh = rez ? a.shift[(size_t)b * CP + h * HEAD_CH + lane] : 0.f;
-    const float *xp = a.x + p0 * CP + h * HEAD_CH + lane, *zp = rez ? xp : a.z + p0 * CP + h * HEAD_CH + lane;
-    float *dp = a.d + p0 * CP + h * HEAD_CH + lane;
     auto one = [&](int i, float zv, float xv) {
-        cfloat *g = (cfloat *)(uintptr_t)(a.draw + (p0 + i) * a.ld + RB);
+        const float *g = &gsh[i][RB];
         float dh = 0.f;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -96,9 +95,9 @@ __device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, int h, int l
         s2 = fmaf(dv, xv, s2);
         dp[(size_t)i * CP] = dv;
     };
-    constexpr int U = 8;
+    constexpr int U = 8;                              // x loads in flight
     int i = 0;
-    for (; i + U <= np; i += U) {
+    for (; i + U <= n; i += U) {
         float zv[U], xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -106,11 +105,54 @@ __device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, int h, int l
             if (!rez) zv[u] = zp[(size_t)(i + u) * CP];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) one(i + u, rez ? fmaxf(fmaf(xv[u], zsc, zsh), 0.f) : zv[u], xv[u]);
+        for (int u = 0; u < U; ++u) {
+            one(i + u, rez ? fmaxf(fmaf(xv[u], zsc, zsh), 0.f) : zv[u], xv[u]);
+            if (NR > 8) __builtin_amdgcn_sched_barrier(0);      // keep the wide heads from hoisting 8 pixels x NR row values into registers
+        }
     }
-    for (; i < np; ++i) {
+    for (; i < n; ++i) {
         const float xv1 = xp[(size_t)i * CP];
         one(i, rez ? fmaxf(fmaf(xv1, zsc, zsh), 0.f) : zp[(size_t)i * CP], xv1);
+    }
+}
+template <int RB, int NR>
+__device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, float (*gsh)[HB_LD], int h, int lane, size_t p0, int np, int blk,
+                                              int b) {
+    constexpr int CP = NUM_HEADS * HEAD_CH;
+    constexpr int NT = NUM_HEADS * 64, F4 = HB_PX * HB_LD / 4, NL = (F4 + NT - 1) / NT;      // float4 loads per thread and block
+    float w[NR], acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { w[r] = a.w1[(RB + r) * HEAD_CH + lane]; acc[r] = 0.f; }
+    float s1 = 0.f, s2 = 0.f;
+    const bool rez = a.z == nullptr;
+    const float zsc = rez ? a.scale[(size_t)b * CP + h * HEAD_CH + lane] : 0.f, zsh = rez ? a.shift[(size_t)b * CP + h * HEAD_CH + lane] : 0.f;
+    const float *xp = a.x + p0 * CP + h * HEAD_CH + lane, *zp = rez ? xp : a.z + p0 * CP + h * HEAD_CH + lane;
+    float *dp = a.d + p0 * CP + h * HEAD_CH + lane;
+    const int tid = threadIdx.x;
+    // rows of draw: pixel-major, a.ld == HB_LD floats per pixel -> a block of HB_PX pixels is one contiguous run
+    const float4 *gsrc = reinterpret_cast<const float4 *>(a.draw + p0 * a.ld);
+    float4 pre[NL];
+    auto fetch = [&](int px0) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int e = tid + k * NT;
+            const bool ok = e < F4 && px0 + e / (HB_LD / 4) < np;
+            pre[k] = ok ? gsrc[(size_t)px0 * (HB_LD / 4) + e] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(0);
+    for (int px0 = 0; px0 < np; px0 += HB_PX) {
+        __syncthreads();                              // the previous block's rows are no longer read
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int e = tid + k * NT;
+            if (e < F4) reinterpret_cast<float4 *>(&gsh[0][0])[e] = pre[k];
+        }
+        __syncthreads();
+        if (px0 + HB_PX < np) fetch(px0 + HB_PX);     // next block's rows travel while this one is processed
+        const int n = min(HB_PX, np - px0);
+        head_bwd_block<RB, NR>(a, gsh, lane, n, xp + (size_t)px0 * CP, zp + (size_t)px0 * CP, dp + (size_t)px0 * CP, rez, zsc, zsh, w, acc,
+                               s1, s2);
     }
 #pragma unroll
     for (int r = 0; r < NR; ++r) a.dw_partial[((size_t)blk * NUM_OUT_ROWS + RB + r) * HEAD_CH + lane] = acc[r];
@@ -119,6 +161,7 @@ __device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, int h, int l
     rp[1] = s2;
 }
 __global__ __launch_bounds__(NUM_HEADS * 64) void head_bwd_kernel(const HeadBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float gsh[HB_PX][HB_LD];
     const int lane = threadIdx.x & 63;
     const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = blockIdx.x;
@@ -127,15 +170,15 @@ __global__ __launch_bounds__(NUM_HEADS * 64) void head_bwd_kernel(const HeadBwdA
     const int np = min(a.HW, r0 + a.rows_per_block) - r0;
     const size_t p0 = (size_t)b * a.HW + r0;
     switch (h) {   // (first row, row count) of each head in HeadRow order
-        case 0: head_bwd_rows<0, 3>(a, h, lane, p0, np, blk, b); break;
-        case 1: head_bwd_rows<3, 2>(a, h, lane, p0, np, blk, b); break;
-        case 2: head_bwd_rows<5, 2>(a, h, lane, p0, np, blk, b); break;
-        case 3: head_bwd_rows<7, 18>(a, h, lane, p0, np, blk, b); break;
-        case 4: head_bwd_rows<25, 9>(a, h, lane, p0, np, blk, b); break;
-        case 5: head_bwd_rows<34, 2>(a, h, lane, p0, np, blk, b); break;
-        case 6: head_bwd_rows<36, 3>(a, h, lane, p0, np, blk, b); break;
-        case 7: head_bwd_rows<39, 2>(a, h, lane, p0, np, blk, b); break;
-        default: head_bwd_rows<41, 24>(a, h, lane, p0, np, blk, b); break;
+        case 0: head_bwd_rows<0, 3>(a, gsh, h, lane, p0, np, blk, b); break;
+        case 1: head_bwd_rows<3, 2>(a, gsh, h, lane, p0, np, blk, b); break;
+        case 2: head_bwd_rows<5, 2>(a, gsh, h, lane, p0, np, blk, b); break;
+        case 3: head_bwd_rows<7, 18>(a, gsh, h, lane, p0, np, blk, b); break;
+        case 4: head_bwd_rows<25, 9>(a, gsh, h, lane, p0, np, blk, b); break;
+        case 5: head_bwd_rows<34, 2>(a, gsh, h, lane, p0, np, blk, b); break;
+        case 6: head_bwd_rows<36, 3>(a, gsh, h, lane, p0, np, blk, b); break;
+        case 7: head_bwd_rows<39, 2>(a, gsh, h, lane, p0, np, blk, b); break;
+        default: head_bwd_rows<41, 24>(a, gsh, h, lane, p0, np, blk, b); break;
     }
 }
 // blocks = chan_reduce_blocks(B, HW); rows_per_block = that partition's row count (kernels_train.hip)
@@ -146,7 +189,7 @@ hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const floa
     static const int RB[NUM_HEADS + 1] = {0, 3, 5, 7, 25, 34, 36, 39, 41, 65};
     for (int i = 0; i <= NUM_HEADS; ++i)
         if (rbeg[i] != RB[i]) return hipErrorInvalidValue;      // the switch above hard-codes the HeadRow table
-    if (blocks % B) return hipErrorInvalidValue;
+    if (blocks % B || ld != HB_LD || (reinterpret_cast<uintptr_t>(draw) & 15)) return hipErrorInvalidValue;
     HeadBwdArgs a;
     if (!z && (!scale || !shift)) return hipErrorInvalidValue;
     a.draw = draw; a.ld = ld; a.z = z; a.x = x; a.w1 = w1; a.d = d; a.dw_partial = dw_partial; a.red_partial = red_partial;
