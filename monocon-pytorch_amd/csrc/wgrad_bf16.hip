@@ -150,8 +150,13 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
         d_dst[i] = (dn4 * 4) * DCH + lds_skew(dn4 * 4) + my * 16 + mx * 2;
     }
 
-    f32x4 xv[PB][NIX][2], dv[PB][NID][2];
-    auto fetch = [&](int gi, int p) {
+    // raw fp32 data of the pixel groups in flight.  PD = how many groups ahead the loads run: with one group ahead (round
+    // 2) a workgroup had 23 KB outstanding -- 2 workgroups per CU x 23 KB per ~4 us loaded memory latency = 3 TB/s of L2 /
+    // HBM pull for the whole chip (Little's law), which is what the kernel was observed to sustain; compiling the loads
+    // out took 2.6 ms off the step (scratch/ab/run_exp.sh).  The split kernels (one patch per group) fetch two ahead.
+    constexpr int PD = PB == 1 ? 2 : 1;
+    f32x4 xv[PD][PB][NIX][2], dv[PD][PB][NID][2];
+    auto fetch = [&](int gi, int p, int slot) {
         // (wave-uniform by construction; the integer division runs on the vector ALU, so say so -- otherwise every
         //  buffer load below is wrapped in a readfirstlane "waterfall" loop over its descriptor)
         const int img = __builtin_amdgcn_readfirstlane(gi / a.groups_per_img);
@@ -168,14 +173,14 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
             const int xx = ox + x_ix[i];
-            xv[p][i][0] = buf_load4(r_x, (xx >= 0 && xx < a.Win) ? xb + x_stat[i] : BUF_OOB, 0);
-            xv[p][i][1] = buf_load4(r_x, (xx + 1 >= 0 && xx + 1 < a.Win) ? xb + x_stat[i] + Cs * 4 : BUF_OOB, 0);
+            xv[slot][p][i][0] = buf_load4(r_x, (xx >= 0 && xx < a.Win) ? xb + x_stat[i] : BUF_OOB, 0);
+            xv[slot][p][i][1] = buf_load4(r_x, (xx + 1 >= 0 && xx + 1 < a.Win) ? xb + x_stat[i] + Cs * 4 : BUF_OOB, 0);
         }
 #pragma unroll
         for (int i = 0; i < NID; ++i) {
             const int xx = ox + d_mx[i];
-            dv[p][i][0] = buf_load4(r_d, (xx >= 0 && xx < a.Wout) ? db + d_stat[i] : BUF_OOB, 0);
-            dv[p][i][1] = buf_load4(r_d, (xx >= 0 && xx + 1 < a.Wout) ? db + d_stat[i] + a.dy_ld * 4 : BUF_OOB, 0);
+            dv[slot][p][i][0] = buf_load4(r_d, (xx >= 0 && xx < a.Wout) ? db + d_stat[i] : BUF_OOB, 0);
+            dv[slot][p][i][1] = buf_load4(r_d, (xx >= 0 && xx + 1 < a.Wout) ? db + d_stat[i] + a.dy_ld * 4 : BUF_OOB, 0);
         }
     };
     // piece q of (a, b): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (mode 2), packed pixel pair per channel
@@ -194,32 +199,42 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
             }
         }
     };
-    auto store = [&](int p) {
+    auto store = [&](int p, int slot) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i)
-            if (NT * (i + 1) <= XP || tid + NT * i < XP) put(xt + p * CB * XCH + x_dst[i], XPL, xv[p][i][0], xv[p][i][1], XCH, x_scale);
+            if (NT * (i + 1) <= XP || tid + NT * i < XP) put(xt + p * CB * XCH + x_dst[i], XPL, xv[slot][p][i][0], xv[slot][p][i][1], XCH, x_scale);
 #pragma unroll
         for (int i = 0; i < NID; ++i)
-            if (NT * (i + 1) <= DP || tid + NT * i < DP) put(dyt + p * NB * DCH + d_dst[i], DPL, dv[p][i][0], dv[p][i][1], DCH, d_scale);
+            if (NT * (i + 1) <= DP || tid + NT * i < DP) put(dyt + p * NB * DCH + d_dst[i], DPL, dv[slot][p][i][0], dv[slot][p][i][1], DCH, d_scale);
     };
 
     const int lc = lane_chan(li);
     const unsigned char *a_base = dyt + (wn * 32 + lc) * DCH + lds_skew(wn * 32 + lc) + g * 16;
     const unsigned char *b_base = xt + (wc * 32 + lc) * XCH + lds_skew(wc * 32 + lc) + g * XROW;
 
-    if (g_begin < g_end) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) fetch(g_begin, p);
-    }
-    for (int gi = g_begin; gi < g_end; ++gi) {
-        __syncthreads();   // fragment reads of the previous group are done
+    for (int d = 0; d < PD; ++d)
+        if (g_begin + d < g_end) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) store(p);
-        __syncthreads();
-        if (gi + 1 < g_end) {
-#pragma unroll
-            for (int p = 0; p < PB; ++p) fetch(gi + 1, p);
+            for (int p = 0; p < PB; ++p) fetch(g_begin + d, p, d);
         }
+    for (int g0 = g_begin; g0 < g_end; g0 += PD)
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        const int gi = g0 + d;
+        if (gi >= g_end) break;       // (uniform over the workgroup)
+        __syncthreads();   // fragment reads of the previous group are done
+#ifndef MC_EXP_NO_STORE
+#pragma unroll
+        for (int p = 0; p < PB; ++p) store(p, d);
+#endif
+        __syncthreads();
+#ifndef MC_EXP_NO_FETCH
+        if (gi + PD < g_end) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) fetch(gi + PD, p, d);
+        }
+#endif
         // partial products (piece of dY, piece of X), smallest first; mode 1: the single (0, 0)
         constexpr int NP = SPL == 1 ? 1 : (SPL == 2 ? 3 : 6);
         constexpr int PA[6] = {SPL == 2 ? 1 : 0, SPL == 2 ? 0 : 2, SPL == 2 ? 0 : 1, 0, 1, 0};
@@ -257,6 +272,11 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
 #pragma unroll
                     for (int pp = 0; pp < NP; ++pp) {
                         const int za = SPL == 1 ? 0 : PA[pp], zx = SPL == 1 ? 0 : PX[pp];
+#ifdef MC_EXP_NO_MFMA
+                        asm volatile("" ::"v"(av[za]), "v"(b0[zx]), "v"(b1[zx]), "v"(b2[zx]));
+                        if (true) {
+                        } else
+#endif
                         if (KS == 1) {
                             acc[0] = wmfma_k16(av[za], __builtin_bit_cast(pc8, b0[zx]), acc[0]);
                         } else {
