@@ -1011,7 +1011,11 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
     ConvArgs a{};
     int cin = 0;
     std::vector<void *> bufs;
+    // MONOCON_BENCH_ZERO=1: all-zero operands (same instruction stream, minimal toggling): how much of a launch's time is
+    // the power limit (DVFS) rather than stalls
+    const bool zero_data = std::getenv("MONOCON_BENCH_ZERO") != nullptr;
     auto alloc_fill = [&](size_t n, float scale) -> float * {
+        if (zero_data) scale = 0.f;
         void *q = nullptr;
         if (hipMalloc(&q, n * sizeof(float)) != hipSuccess) return nullptr;
         bufs.push_back(q);
@@ -1043,7 +1047,7 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
         const size_t wn = (size_t)ksize * ksize * cin * a.CoutP;
         std::vector<unsigned short> hw(wn * 3);
         unsigned s16 = 777u;
-        for (auto &v : hw) { s16 = s16 * 1664525u + 1013904223u; v = (unsigned short)(0x2c00u + ((s16 >> 12) & 0x3ffu) + ((s16 >> 31) << 15)); }
+        for (auto &v : hw) { s16 = s16 * 1664525u + 1013904223u; v = zero_data ? 0 : (unsigned short)(0x2c00u + ((s16 >> 12) & 0x3ffu) + ((s16 >> 31) << 15)); }
         void *q = nullptr;
         if (hipMalloc(&q, hw.size() * 2) != hipSuccess) return fail(h, "mc_bench_conv: out of memory");
         bufs.push_back(q);
