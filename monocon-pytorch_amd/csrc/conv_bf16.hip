@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     pc8 bq[DB][SPL][WTN];
 #pragma unroll
     for (int j = 0; j < DB - 1; ++j) load_b(bq[j], 0, j);
+    const EpiCoef<WTN> coef = conv_epi_coef<WN, WTN, BM>(a, n0, wn, li);      // (see conv_mfma.h: before the K loop, not after)
 
     // ---- K loop: one iteration per 32-channel chunk of the virtual concat.  Where the registers allow it (PF), the raw
     //      fp32 data of chunk i+1 is fetched into registers BEFORE the MFMA phase of chunk i and converted / written to
@@ -234,13 +235,22 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
             for (int pz = 0; pz < SPL; ++pz) *reinterpret_cast<pc4 *>(lds_raw + sdst[i] + pz * PLANE) = q[pz];
         }
     };
+#ifdef MC_PHASE_TIMERS
+    unsigned long long tp_stage = 0, tp_bar = 0, tp_mfma = 0, tp_epi = 0;
+    const unsigned long long tp_t0 = __builtin_readcyclecounter();
+#define TP_NOW() __builtin_readcyclecounter()
+#else
+#define TP_NOW() 0ull
+#endif
     lane_offsets(Cs);
     if (PF) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) pv[i] = buf_load4(r_in, voff[i], 0);
     }
     for (bool first = true;; first = false) {
+        [[maybe_unused]] unsigned long long tp_a = TP_NOW();
         if (!first) __syncthreads();
+        [[maybe_unused]] unsigned long long tp_b = TP_NOW();
         if (PF) {
 #pragma unroll
             for (int i = 0; i < NIT; ++i) stage_one(pv[i], i);
@@ -255,7 +265,9 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                 for (int u = 0; u < UB; ++u) stage_one(v[u], i0 + u);
             }
         }
+        [[maybe_unused]] unsigned long long tp_c = TP_NOW();
         __syncthreads();
+        [[maybe_unused]] unsigned long long tp_d = TP_NOW();
         // the chunk after this one (possibly the first of the next source): descriptors / lane offsets now, and with PF
         // its loads go out before the MFMA phase
         int nsi = si, nc0 = c0 + CK;
@@ -308,9 +320,13 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                 }
             }
         }
+#ifdef MC_PHASE_TIMERS
+        { const unsigned long long tp_e = TP_NOW(); tp_bar += (tp_b - tp_a) + (tp_d - tp_c); tp_stage += tp_c - tp_b; tp_mfma += tp_e - tp_d; }
+#endif
         if (!more) break;
         si = nsi; c0 = nc0; kc += CK;
     }
+    [[maybe_unused]] const unsigned long long tp_f = TP_NOW();
 
     if (NACC == 2) {
 #pragma unroll
@@ -320,7 +336,16 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accm[tm][tn][r];
     }
-    conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li, omul);
+    conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li, coef, omul);
+#ifdef MC_PHASE_TIMERS
+    if (a.phase_prof && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long tp_g = TP_NOW();
+        tp_epi = tp_g - tp_f;
+        unsigned long long *o = a.phase_prof + ((size_t)blockIdx.x * (NT / 64) + wave) * 5;
+        o[0] = tp_stage; o[1] = tp_bar; o[2] = tp_mfma; o[3] = tp_epi; o[4] = tp_g - tp_t0;
+    }
+#endif
 }
 
 // ---- weight packing: OIHW fp32 -> [tap][Cin/8][CoutP][8] bf16 (forward) and the dgrad variants

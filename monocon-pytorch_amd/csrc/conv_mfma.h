@@ -83,6 +83,8 @@ struct ConvArgs {
     const unsigned *amax_in[4];   // per source of the virtual concat
     const unsigned *amax_w;       // of the master weight(s) the panel was cut from
     unsigned *amax_out;           // optional: max |out| of this launch is folded in (eval plans: the consumer's amax_in)
+    unsigned long long *phase_prof;   // measurement aid (-DMC_PHASE_TIMERS, mc_bench_conv): per workgroup and wave, cycles spent in
+                                      // [0] staging, [1] barriers, [2] MFMA phases, [3] epilogue, [4] total
 };
 
 // ---- power-of-two operand scaling of the fp16-split mode ---------------------------------------------------------
@@ -201,10 +203,33 @@ __device__ __forceinline__ int xcd_order(int b, int n) {
 // Epilogue shared by both kernel variants.  C/D layout of v_mfma_f32_32x32x2: column = lane&31,
 // row m = (r&3) + 8*(r>>2) + 4*(lane>>5); row m of a 4x8 patch is pixel (oy0 + (m>>3), ox0 + (m&7))
 // = (oy0 + (r>>2), ox0 + (r&3) + 4*(lane>>5)).
+// per-column coefficients of the epilogue.  Loaded BEFORE the K loop (conv_epi_coef): they are plain global loads, and
+// fetched at the top of the epilogue each workgroup paid a full memory round trip for them with nothing to overlap
+// (measured with the phase timers of mc_bench_conv, round 3: the epilogue took half as long as the workgroup's own MFMAs).
+template <int WTN>
+struct EpiCoef {
+    float sc[WTN], bi[WTN], sh[WTN], ma[WTN], mb[WTN];
+};
+template <int WN, int WTN, bool BM>
+__device__ __forceinline__ EpiCoef<WTN> conv_epi_coef(const ConvArgs &a, int n0, int wn, int li) {
+    EpiCoef<WTN> c;
+#pragma unroll
+    for (int tn = 0; tn < WTN; ++tn) {
+        const int n = n0 + (wn * WTN + tn) * 32 + li;
+        const bool nok = n < a.Cout;
+        c.sc[tn] = (a.scale && nok) ? a.scale[n] : 1.f;
+        c.bi[tn] = (a.bias && nok) ? a.bias[n] : 0.f;
+        c.sh[tn] = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
+        c.ma[tn] = (BM && a.bm_relu == 2 && nok) ? a.bm_a[n] : 0.f;
+        c.mb[tn] = (BM && a.bm_relu == 2 && nok) ? a.bm_b[n] : 0.f;
+    }
+    return c;
+}
+
 template <int WM, int WN, int WTM, int WTN, int BNT, bool BM = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[WTM][WTN], const int *pinfo,
                                               int patch0, int img, int n0, int wm, int wn, int g, int li,
-                                              float omul = 1.f) {
+                                              const EpiCoef<WTN> &coef, float omul = 1.f) {
     // omul: power-of-two rescale of the accumulator (fp16-split mode: undoes the operand scaling, exact); 1 otherwise
     const bool do_stats = a.stats != nullptr;
     float vmax = 0.f;                            // max |stored value| of this lane (ConvArgs::amax_out)
@@ -225,11 +250,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
     for (int tn = 0; tn < WTN; ++tn) {
         const int n = n0 + (wn * WTN + tn) * 32 + li;
         const bool nok = n < a.Cout;
-        const float sc = ((a.scale && nok) ? a.scale[n] : 1.f) * omul;
-        const float bi = (a.bias && nok) ? a.bias[n] : 0.f;
-        const float sh = (a.stat_shift && nok) ? a.stat_shift[n] : 0.f;
-        const float ma = (bm && bm_relu == 2 && nok) ? a.bm_a[n] : 0.f;
-        const float mb = (bm && bm_relu == 2 && nok) ? a.bm_b[n] : 0.f;
+        const float sc = coef.sc[tn] * omul, bi = coef.bi[tn], sh = coef.sh[tn], ma = coef.ma[tn], mb = coef.mb[tn];
         const int v_out = nok ? (4 * g * a.o_px + a.out_coff + n) * 4 : BUF_OOB;
         const int v_res = nok ? (4 * g * a.r_px + n) * 4 : BUF_OOB;
         const int v_bm = nok ? (4 * g * a.o_px + n) * 4 : BUF_OOB;      // y / z share the dense layout of the output
@@ -398,6 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvAr
     };
     f32x4 bcur[WTN];
     load_b(bcur, 0, 0);   // weights do not depend on the staged tile: in flight across the barriers
+    const EpiCoef<WTN> coef = conv_epi_coef<WN, WTN, BM>(a, n0, wn, li);
 
     int kbase = 0;   // channel offset of the current source inside the virtual concat
     for (int si = 0; si < a.nsrc; ++si) {
@@ -471,7 +493,7 @@ __global__ __launch_bounds__(64 * WM * WN, 3) void conv_mfma_kernel(const ConvAr
         kbase += Cs;
     }
 
-    conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
+    conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li, coef);
 }
 
 // ---- wave-specialised variant -------------------------------------------------------------
@@ -594,6 +616,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(con
         };
         f32x4 bcur[WTN];
         load_b(bcur, 0, 0);
+        const EpiCoef<WTN> coef = conv_epi_coef<WN, WTN, false>(a, n0, wn, li);
         const int nch = a.Cin / CK;
         __syncthreads();   // chunk 0 staged
         for (int ci = 0; ci < nch; ++ci) {
@@ -636,7 +659,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 1), 3) void conv_mfma_ws_kernel(con
             }
             if (ci + 1 < nch) __syncthreads();   // chunk ci+1 staged, chunk ci released
         }
-        conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li);
+        conv_epilogue<WM, WN, WTM, WTN, BNT>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li, coef);
     }
 }
 

@@ -1060,6 +1060,16 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
         for (int i = 0; i < nsrc; ++i) a.amax_in[i] = static_cast<unsigned *>(q) + (size_t)i * AMAX_WORDS;
         a.amax_w = static_cast<unsigned *>(q) + (size_t)4 * AMAX_WORDS;
     }
+#ifdef MC_PHASE_TIMERS
+    const size_t prof_n = (size_t)1 << 22;          // (workgroups x waves x 5) upper bound
+    {
+        void *q = nullptr;
+        if (hipMalloc(&q, prof_n * 8) != hipSuccess) return fail(h, "mc_bench_conv: out of memory");
+        bufs.push_back(q);
+        (void)hipMemset(q, 0, prof_n * 8);
+        a.phase_prof = static_cast<unsigned long long *>(q);
+    }
+#endif
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
@@ -1073,6 +1083,18 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
         float ms = 0;
         (void)hipEventElapsedTime(&ms, e0, e1);
         *ms_avg = ms / iters;
+#ifdef MC_PHASE_TIMERS
+        if (a.phase_prof) {
+            std::vector<unsigned long long> hp(prof_n);
+            (void)hipMemcpy(hp.data(), a.phase_prof, prof_n * 8, hipMemcpyDeviceToHost);
+            double sum[5] = {0, 0, 0, 0, 0};
+            size_t n = 0;
+            for (size_t i = 0; i + 5 <= prof_n; i += 5)
+                if (hp[i + 4]) { for (int k = 0; k < 5; ++k) sum[k] += (double)hp[i + k]; ++n; }
+            if (n) std::fprintf(stderr, "[phase] waves %zu  avg cycles per wave: stage %.0f  barriers %.0f  mfma-phase %.0f  epilogue %.0f  total %.0f\n",
+                                n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n);
+        }
+#endif
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

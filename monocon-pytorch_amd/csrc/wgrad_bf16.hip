@@ -150,11 +150,10 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
         d_dst[i] = (dn4 * 4) * DCH + lds_skew(dn4 * 4) + my * 16 + mx * 2;
     }
 
-    // raw fp32 data of the pixel groups in flight.  PD = how many groups ahead the loads run: with one group ahead (round
-    // 2) a workgroup had 23 KB outstanding -- 2 workgroups per CU x 23 KB per ~4 us loaded memory latency = 3 TB/s of L2 /
-    // HBM pull for the whole chip (Little's law), which is what the kernel was observed to sustain; compiling the loads
-    // out took 2.6 ms off the step (scratch/ab/run_exp.sh).  The split kernels (one patch per group) fetch two ahead.
-    constexpr int PD = PB == 1 ? 2 : 1;
+    // raw fp32 data of the pixel groups in flight; PD = how many groups ahead the loads run.  Two ahead (24 more registers)
+    // was tried in round 3 on a Little's-law argument (2 workgroups per CU x 23 KB in flight): A/B in one session 59.5 ms
+    // (PD 1) vs 60.1 ms (PD 2) per step -- slower; it stays at one.
+    constexpr int PD = 1;
     f32x4 xv[PD][PB][NIX][2], dv[PD][PB][NID][2];
     auto fetch = [&](int gi, int p, int slot) {
         // (wave-uniform by construction; the integer division runs on the vector ALU, so say so -- otherwise every

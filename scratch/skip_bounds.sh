@@ -1,6 +1,6 @@
 #!/bin/bash
 # step time with kernel families turned into no-ops (WRONG numerics): upper bounds on what removing them can gain
-# needs a library built with the debug hooks: make -C monocon-pytorch_amd/csrc clean && make -C monocon-pytorch_amd/csrc CXXFLAGS+=-DMC_DEBUG_HOOKS
+# needs a library built with the debug hooks: make -C monocon-pytorch_amd/csrc clean && make -C monocon-pytorch_amd/csrc EXTRA=-DMC_DEBUG_HOOKS
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export MONOCON_HIP_TUNE_CACHE=/tmp/tune_$1.txt
 for skip in none fold,fin,bfin aact abwd cred aact,abwd,cred fold,fin,bfin,aact,abwd,cred; do
