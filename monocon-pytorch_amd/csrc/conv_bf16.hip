@@ -184,7 +184,10 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     // L2 round trip under load, so every step stalled on its weights (PMC: waves parked 40 % of the time); and the loads
     // return in order, so a weight fetch issued behind the staging prefetch of the next chunk waits for HBM.
     // Depth: as many slots as 48 registers hold (a slot is SPL * WTN fragments of 4 registers), among the divisors of NS.
-    constexpr int DB_FIT = 48 / (SPL * WTN * 4);
+#ifndef MC_CONV_DB_REGS
+#define MC_CONV_DB_REGS 48
+#endif
+    constexpr int DB_FIT = MC_CONV_DB_REGS / (SPL * WTN * 4);
     constexpr int DB = (WTM * WTN > 2) ? 2 : ((DB_FIT >= 6 && NS % 6 == 0) ? 6 : ((DB_FIT >= 3 && NS % 3 == 0) ? 3 : 2));
     static_assert(NS % DB == 0, "ring slots must line up across K-chunks");
     pc8 bq[DB][SPL][WTN];
@@ -196,7 +199,10 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     //      fp32 data of chunk i+1 is fetched into registers BEFORE the MFMA phase of chunk i and converted / written to
     //      LDS after it: the HBM / L2 latency of the staging loads is hidden behind this workgroup's own matrix work
     //      instead of relying on the co-resident workgroup being in its MFMA phase at the right moment.
-    constexpr bool PF = NIT <= 8 && WTM * WTN <= 2;
+#ifndef MC_CONV_PF
+#define MC_CONV_PF 1
+#endif
+    constexpr bool PF = MC_CONV_PF && NIT <= 8 && WTM * WTN <= 2;
     constexpr int UB = NIT > 8 ? 8 : NIT;
     f32x4 pv[PF ? NIT : 1];
     int voff[NIT], sdst[NIT];
