@@ -24,6 +24,9 @@ namespace mc {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef CS_PD
+#define CS_PD 2          // groups in flight ahead of the one being computed (A/B in one session: 1 -> 2 = -0.23 ms per step, 3 = slower)
+#endif
 template <int S, int CIN, int NTN>
 __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     constexpr int KG = CIN / 16;          // 16-byte channel groups per lane and tap
@@ -85,8 +88,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) ssum[q][nt] = ssq[q][nt] = 0.f;
 
-        auto group = [&](int x0, bool edge) {
-            f32x4 av[NI * 3][KG];
+        auto fetch = [&](int x0, bool edge, f32x4 (&av)[NI * 3][KG]) {
 #pragma unroll
             for (int r = 0; r < NI; ++r)
 #pragma unroll
@@ -101,6 +103,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
                                 r_x[r], (px >= 0 && px < a.Win) ? (px * CIN + kg * 16 + kq * 4) * 4 : BUF_OOB, 0);
                         }
                     }
+        };
+        auto compute = [&](int x0, const f32x4 (&av)[NI * 3][KG]) {
             f32x4v acc[NR][NTN];
 #pragma unroll
             for (int q = 0; q < NR; ++q)
@@ -146,9 +150,39 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
                     }
                 }
         };
-        group(0, true);
-        for (int x0 = 16; x0 < a.Wout - 16; x0 += 16) group(x0, false);
-        if (a.Wout > 16) group(a.Wout - 16, true);
+        // the 16-pixel groups of a row as a software pipeline: the loads of group g + PD are in flight while group g runs
+        // its MFMAs and stores (no branch between a fetch and the steady-state MFMAs: the compiler's wait counts are
+        // path-insensitive)
+        constexpr int PD = KG == 1 ? CS_PD : 1;           // (32 input channels: two groups ahead would not fit 256 registers)
+        f32x4 ring[PD][NI * 3][KG], ev[NI * 3][KG];
+        const int n = (a.Wout - 32) / 16;             // interior groups: output pixels 16 .. Wout - 17
+        fetch(0, true, ev);
+        int g = 0;
+        if (n >= 2 * PD) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) fetch(16 + 16 * d, false, ring[d]);
+            compute(0, ev);
+            for (; g + 2 * PD <= n; g += PD) {
+#pragma unroll
+                for (int d = 0; d < PD; ++d) {
+                    compute(16 + 16 * (g + d), ring[d]);
+                    fetch(16 + 16 * (g + PD + d), false, ring[d]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < PD; ++d) compute(16 + 16 * (g + d), ring[d]);
+            g += PD;
+        } else {
+            compute(0, ev);
+        }
+        for (; g < n; ++g) {
+            fetch(16 + 16 * g, false, ev);
+            compute(16 + 16 * g, ev);
+        }
+        if (a.Wout > 16) {
+            fetch(a.Wout - 16, true, ev);
+            compute(a.Wout - 16, ev);
+        }
 
         if (do_stats) {
 #pragma unroll

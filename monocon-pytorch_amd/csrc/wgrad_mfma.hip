@@ -234,6 +234,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 // adds.  The four waves of a workgroup are summed through LDS into one split-K partial.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef WGS_PD
+#define WGS_PD 3
+#endif
 template <int S, int NTN>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
     constexpr int CIN = 16, COUT = 16 * NTN;
@@ -265,31 +268,61 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
             const bool ok = iy >= 0 && iy < a.Hin;
             r_x[r] = make_rsrc(xsrc + ((size_t)img * a.Hin + (ok ? iy : 0)) * a.Win * CIN, ok ? (unsigned)(a.Win * CIN) * 4u : 0u);
         }
-        auto group = [&](int x0, bool edge) {
-            float av[NTN], bv[9];
+        auto fetch = [&](int x0, bool edge, float (&v)[NTN + 9]) {
 #pragma unroll
-            for (int nt = 0; nt < NTN; ++nt) av[nt] = buf_load1(r_dy, va + nt * 64, x0 * COUT * 4);
+            for (int nt = 0; nt < NTN; ++nt) v[nt] = buf_load1(r_dy, va + nt * 64, x0 * COUT * 4);
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     if (!edge) {
-                        bv[r * 3 + s] = buf_load1(r_x[r], vx + s * CIN * 4, (x0 * S - 1) * CIN * 4);
+                        v[NTN + r * 3 + s] = buf_load1(r_x[r], vx + s * CIN * 4, (x0 * S - 1) * CIN * 4);
                     } else {
                         const int px = (x0 + k) * S + s - 1;
-                        bv[r * 3 + s] = buf_load1(r_x[r], (px >= 0 && px < a.Win) ? (px * CIN + j) * 4 : BUF_OOB, 0);
+                        v[NTN + r * 3 + s] = buf_load1(r_x[r], (px >= 0 && px < a.Win) ? (px * CIN + j) * 4 : BUF_OOB, 0);
                     }
                 }
+        };
+        auto mma = [&](const float (&v)[NTN + 9]) {
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt)
-                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nt], bv[t], acc[t][nt], 0, 0, 0);
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nt], v[NTN + t], acc[t][nt], 0, 0, 0);
         };
-        group(0, true);
-#pragma unroll 2
-        for (int x0 = 4; x0 < a.Wout - 4; x0 += 4) group(x0, false);
-        if (a.Wout > 4) group(a.Wout - 4, true);
+        // the groups of a row run as a software pipeline PD groups deep: the 9 + NTN dword loads of group g + PD are in
+        // flight while the MFMAs of group g issue (without it every group paid one full memory latency: the kernel sat at
+        // 21 % of the fp32 MFMA rate with the matrix pipe idle most of the time)
+        constexpr int PD = WGS_PD;
+        float ring[PD][NTN + 9], ev[NTN + 9];
+        const int n = (a.Wout - 8) / 4;               // interior groups: output pixels 4 .. Wout - 5
+        fetch(0, true, ev);
+        mma(ev);
+        int g = 0;
+        if (n >= 2 * PD) {
+            // (no conditional code between the fetches and the MFMAs of the steady state: the compiler's wait counts are
+            // path-insensitive, one branch around a fetch and every MFMA waits for ALL loads in flight)
+#pragma unroll
+            for (int d = 0; d < PD; ++d) fetch(4 + 4 * d, false, ring[d]);
+            for (; g + 2 * PD <= n; g += PD) {
+#pragma unroll
+                for (int d = 0; d < PD; ++d) {
+                    mma(ring[d]);
+                    fetch(4 + 4 * (g + PD + d), false, ring[d]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < PD; ++d) mma(ring[d]);
+            g += PD;
+        }
+        for (; g < n; ++g) {
+            fetch(4 + 4 * g, false, ev);
+            mma(ev);
+        }
+        if (a.Wout > 4) {
+            fetch(a.Wout - 4, true, ev);
+            mma(ev);
+        }
     }
 
     // ---- workgroup reduction (wave after wave through one LDS image: fixed order, deterministic).
