@@ -265,6 +265,42 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
 int mc_preprocess(mc_handle *h, const void *img_hwc, int dtype, int H, int W, const double mean[3],
                   const double std[3], int pad_h, int pad_w, float *out_chw, void *stream);
 
+/* ---- KITTI AP evaluation (last row) -------------------------------------------------------------
+ * Device part: pairwise overlaps of rotated boxes.  All pointers are device pointers; results are row-major (N, K).
+ *
+ * mc_rotate_iou_eval replaces rotate_iou_gpu_eval / rotate_iou_kernel_eval, the reference's only GPU kernel
+ * (engine/kitti_eval/rotate_iou.py:280-378): boxes (N,5) and query_boxes (K,5) float32 [cx, cy, dx, dy, angle], angle
+ * clockwise-positive (camera-frame bird's-eye view); criterion -1: IoU, 0: intersection / area(query box),
+ * 1: intersection / area(box), any other value: the bare intersection area (rotate_iou.py:252-277).  The host wrapper's
+ * H2D / D2H copies are the caller's business here (engine/kitti_eval/rotate_iou.py of this package does them).
+ *
+ * mc_box3d_overlap replaces d3_box_overlap (engine/kitti_eval/eval.py:128-164: the same GPU kernel asked for bare
+ * areas, then a numba CPU pass for the height overlap) in ONE launch: boxes (N,7), query_boxes (K,7) float64 camera-frame
+ * [x, y, z, l, h, w, ry] (y = bottom face, pointing down); criterion -1: 3D IoU, 0: / volume(box), 1: / volume(query). */
+int mc_rotate_iou_eval(mc_handle *h, const float *boxes, const float *query_boxes, long long N, long long K,
+                       int criterion, float *iou, void *stream);
+int mc_box3d_overlap(mc_handle *h, const double *boxes, const double *query_boxes, long long N, long long K,
+                     int criterion, double *overlap, void *stream);
+
+/* Host part (no handle, no device: runs on any box): the loops the reference JIT-compiles with numba.
+ * mc_kitti_image_overlap = image_box_overlap (eval.py:90-119): axis-aligned (x1,y1,x2,y2) boxes, criterion -1 IoU,
+ * 0: / area(box), 1: / area(query), else the bare intersection.
+ * mc_kitti_statistics_part runs compute_statistics_jit (eval.py:167-285) over the frames of one "part" (frames whose
+ * boxes were concatenated, eval.py:347-422): overlaps is the part's (sum dt_nums, sum gt_nums) matrix, gt_datas
+ * (sum gt, 5) = bbox + alpha, dt_datas (sum dt, 6) = bbox + alpha + score, dontcares (sum dc, 4), ignore flags as
+ * produced by clean_data (eval.py:35-87).  mode 0: scores of the true positives without false-positive accounting,
+ * appended to scores_out (capacity sum gt_nums) -- the first pass of eval_class (eval.py:490-505); mode 1:
+ * fused_compute_statistics (eval.py:297-344), pr[n_thresholds][4] += (tp, fp, fn, similarity).  Returns 0, or -1 on a
+ * bad argument. */
+int mc_kitti_image_overlap(const double *boxes, long long N, const double *query_boxes, long long K, int criterion,
+                           double *overlap);
+int mc_kitti_statistics_part(int mode, const double *overlaps, long long n_frames, const long long *gt_nums,
+                             const long long *dt_nums, const long long *dc_nums, const double *gt_datas,
+                             const double *dt_datas, const double *dontcares, const long long *ignored_gts,
+                             const long long *ignored_dets, int metric, double min_overlap, const double *thresholds,
+                             long long n_thresholds, int compute_aos, double *pr, double *scores_out,
+                             long long *n_scores);
+
 /* Device memory a plan of the handle needs for one input shape, WITHOUT building it (lets the caller size
  * the batch against the 288 GB of HBM before the first step; the plan builder runs dry -- nothing is allocated or
  * launched).  mode 0: inference forward (mc_forward_infer), 1: train step (mc_forward_train + mc_backward), 2: heads-only

@@ -10,7 +10,8 @@ Differences from the reference, all on the host side of the hot path:
     the sample ids are taken from the image directory listing;
   * the random training augmentations are not built (transforms/default_transforms.py header): the train split runs
     the deterministic transform list too;
-  * ``evaluate`` writes KITTI result files; the AP evaluator (engine/kitti_eval, numba) is out of scope.
+  * ``evaluate`` runs the AP evaluator of engine/kitti_eval (HIP overlap kernels + native matching instead of numba);
+    ``write_kitti_results`` additionally writes the benchmark's txt submission files.
 The label assembly restates monocon_dataset.py:89-158 by reading (the reference module needs cv2 to import): the
 per-object quantities it copies are pinned against the reference's data classes (tests/golden/kitti_objects.npz), the
 filter rules are covered by a fixture built so that each rule fires exactly once (tests/test_input_pipeline.py).
@@ -151,25 +152,58 @@ class MonoConDataset(BaseKITTIMono3DDataset):
             out['label'] = {k: torch.cat([d['label'][k] for d in batched], dim=0) for k in batched[0]['label']}
         return out
 
-    def evaluate(self, kitti_format_results: Dict[str, Any], eval_classes=None, eval_types=None, verbose: bool = True,
-                 save_path: str = None) -> Dict[str, float]:
-        """KITTI result files (one txt per frame, the benchmark's submission format) under ``save_path`` when given;
-        returns detection counts.  Average precision needs the benchmark's evaluator, which is out of scope."""
-        counts = {}
+    def collect_gt_infos(self, verbose: bool = False) -> List[Dict[str, Any]]:
+        """per frame {'image', 'calib', 'annos'}: the annotation dict of ALL labelled objects, DontCare included -- the
+        evaluator needs them (base_dataset.py:85-115)"""
+        out = []
+        for idx in range(len(self)):
+            _, metas = self.load_image(idx)
+            objs = self.load_label(idx)
+            if objs.ignore_dontcare:
+                objs = objs.original_objects
+            out.append({'image': metas, 'calib': self.load_calib(idx).get_info_dict(), 'annos': objs.info_dict})
+        return out
+
+    def write_kitti_results(self, kitti_format_results: Dict[str, Any], save_dir: str) -> None:
+        """one txt per frame and result set in the benchmark's submission format (not in the reference, which only keeps
+        the dicts in memory)"""
         for name, results in kitti_format_results.items():
-            counts[name + '/num_frames'] = float(len(results))
-            counts[name + '/num_detections'] = float(sum(len(r.get('name', [])) for r in results))
-            if save_path is not None:
-                d = os.path.join(save_path, name)
-                os.makedirs(d, exist_ok=True)
-                for r in results:
-                    sid = int(np.asarray(r['sample_idx']).reshape(-1)[0]) if len(np.asarray(r['sample_idx']).reshape(-1)) else 0
-                    with open(os.path.join(d, '%06d.txt' % sid), 'w') as f:
-                        for i in range(len(r['name'])):
-                            bb, dm, lc = r['bbox'][i], r['dimensions'][i], r['location'][i]
-                            f.write('%s -1 -1 %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f\n'
-                                    % (r['name'][i], r['alpha'][i], bb[0], bb[1], bb[2], bb[3], dm[1], dm[2], dm[0],
-                                       lc[0], lc[1], lc[2], r['rotation_y'][i], r['score'][i]))
-        if verbose:
-            print("[MonoConDataset.evaluate] KITTI result files written; AP evaluation is outside this package: %s" % counts)
-        return counts
+            d = os.path.join(save_dir, name)
+            os.makedirs(d, exist_ok=True)
+            for r in results:
+                ids = np.asarray(r['sample_idx']).reshape(-1)
+                sid = int(ids[0]) if len(ids) else 0
+                with open(os.path.join(d, '%06d.txt' % sid), 'w') as f:
+                    for i in range(len(r['name'])):
+                        bb, dm, lc = r['bbox'][i], r['dimensions'][i], r['location'][i]
+                        f.write('%s -1 -1 %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f\n'
+                                % (r['name'][i], r['alpha'][i], bb[0], bb[1], bb[2], bb[3], dm[1], dm[2], dm[0],
+                                   lc[0], lc[1], lc[2], r['rotation_y'][i], r['score'][i]))
+
+    def evaluate(self, kitti_format_results: Dict[str, Any], eval_classes: List[str] = ('Pedestrian', 'Cyclist', 'Car'),
+                 eval_types: List[str] = ('bbox', 'bev', '3d'), verbose: bool = True, save_path: str = None) -> Dict[str, float]:
+        """KITTI AP40 of every result set in ``kitti_format_results`` ({'img_bbox': [...], 'img_bbox2d': [...]}) against the
+        labels of this split -> {'<set>/KITTI/<Class>_<3D|BEV|2D>_AP40_<difficulty>_<strict|loose>': value}, written as
+        json to ``save_path`` when given (base_dataset.py:117-152).  The overlap kernels run on the GPU and the matching in
+        native host code (engine/kitti_eval)."""
+        import json
+        from engine.kitti_eval import kitti_eval
+        if self.split == 'test' or not self.label_files:
+            raise RuntimeError("evaluate() needs labels: the %r split has none" % self.split)
+        if getattr(self, 'gt_annos', None) is None:
+            self.gt_annos = [info['annos'] for info in self.collect_gt_infos(verbose=verbose)]
+        ap_dict = {}
+        for name, result in kitti_format_results.items():
+            if len(result) != len(self.gt_annos):
+                raise ValueError("%s: %d result frames for %d labelled frames" % (name, len(result), len(self.gt_annos)))
+            types = ['bbox'] if '2d' in name else list(eval_types)
+            result_string, result_dict = kitti_eval(gt_annos=self.gt_annos, dt_annos=result, current_classes=list(eval_classes),
+                                                    eval_types=types)
+            for ap_type, ap_value in result_dict.items():
+                ap_dict['%s/%s' % (name, ap_type)] = float('%.4f' % ap_value)
+            if verbose and '2d' not in name:
+                print(result_string)
+        if save_path is not None:
+            with open(save_path, 'w') as f:
+                json.dump(ap_dict, f)
+        return ap_dict

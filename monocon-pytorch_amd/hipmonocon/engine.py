@@ -186,6 +186,39 @@ class Engine:
     def workspace_bytes(self):
         return int(self.lib.mc_workspace_bytes(self.h))
 
+    # ------------------------------------------------------------------ KITTI evaluation (device part)
+    def rotate_iou(self, boxes, query_boxes, criterion=-1):
+        """(N,5), (K,5) float32 CUDA tensors [cx, cy, dx, dy, angle] -> (N,K) float32 CUDA tensor (mc_rotate_iou_eval)."""
+        if torch.is_tensor(boxes) and torch.is_tensor(query_boxes):
+            boxes, query_boxes = boxes.contiguous(), query_boxes.contiguous()
+        _need_cuda(boxes, "boxes"); _need_cuda(query_boxes, "query_boxes")
+        if boxes.dtype != torch.float32 or query_boxes.dtype != torch.float32:
+            raise _lib.MonoconHipError("rotate_iou: boxes must be float32")
+        if boxes.dim() != 2 or boxes.shape[1] != 5 or query_boxes.dim() != 2 or query_boxes.shape[1] != 5:
+            raise _lib.MonoconHipError("rotate_iou: boxes must be (N,5) and (K,5)")
+        N, K = boxes.shape[0], query_boxes.shape[0]
+        out = torch.zeros((N, K), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.mc_rotate_iou_eval(self.h, _ptr(boxes), _ptr(query_boxes), N, K, int(criterion), _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_rotate_iou_eval")
+        return out
+
+    def box3d_overlap(self, boxes, query_boxes, criterion=-1):
+        """(N,7), (K,7) float64 CUDA tensors, camera-frame [x, y, z, l, h, w, ry] -> (N,K) float64 (mc_box3d_overlap)."""
+        if torch.is_tensor(boxes) and torch.is_tensor(query_boxes):
+            boxes, query_boxes = boxes.contiguous(), query_boxes.contiguous()
+        _need_cuda(boxes, "boxes"); _need_cuda(query_boxes, "query_boxes")
+        if boxes.dtype != torch.float64 or query_boxes.dtype != torch.float64:
+            raise _lib.MonoconHipError("box3d_overlap: boxes must be float64")
+        if boxes.dim() != 2 or boxes.shape[1] != 7 or query_boxes.dim() != 2 or query_boxes.shape[1] != 7:
+            raise _lib.MonoconHipError("box3d_overlap: boxes must be (N,7) and (K,7)")
+        N, K = boxes.shape[0], query_boxes.shape[0]
+        out = torch.zeros((N, K), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.mc_box3d_overlap(self.h, _ptr(boxes), _ptr(query_boxes), N, K, int(criterion), _ptr(out), _stream())
+        _lib.check(self.h, rc, "mc_box3d_overlap")
+        return out
+
     # ------------------------------------------------------------------ decode
     def decode(self, pred, P2, P2inv, pad_hw, topk, thres, want_keep=False):
         """Dense decode.  pred: dict of NCHW CUDA maps; P2 (B,3,4), P2inv (B,4,4) CUDA fp32."""

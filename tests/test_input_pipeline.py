@@ -158,12 +158,13 @@ def test_dataset_samples_and_collate():
 @pytest.mark.gpu
 def test_detector_trains_and_evaluates_on_the_file_dataset(golden_sd, tmp_path):
     """the file dataset feeds the detector end to end on the GPU: a train step on a collated batch, batch_eval in KITTI
-    format on the same frames, result files written by dataset.evaluate"""
+    format on the same frames, AP evaluation (engine/kitti_eval) and result files through the dataset"""
+    import json
     from dataset.monocon_dataset import MonoConDataset
     from model import MonoConDetector
     from utils.engine_utils import move_data_device
     ds = MonoConDataset(MINI, "val")
-    batch = move_data_device(MonoConDataset.collate_fn([ds[0], ds[0]]), torch.device("cuda"))
+    batch = move_data_device(MonoConDataset.collate_fn([ds[0], ds[1]]), torch.device("cuda"))
     m = MonoConDetector(34, pretrained_backbone=False)
     m.load_state_dict(golden_sd, strict=True)
     m = m.cuda().train()
@@ -175,5 +176,11 @@ def test_detector_trains_and_evaluates_on_the_file_dataset(golden_sd, tmp_path):
     with torch.no_grad():
         res = m.batch_eval(batch)
     assert set(res) == {"img_bbox", "img_bbox2d"} and len(res["img_bbox"]) == 2
-    counts = ds.evaluate(res, save_path=str(tmp_path), verbose=False)
-    assert counts["img_bbox/num_frames"] == 2.0 and os.path.isfile(os.path.join(str(tmp_path), "img_bbox", "000007.txt"))
+    out_json = os.path.join(str(tmp_path), "ap.json")
+    ap = ds.evaluate(res, save_path=out_json, verbose=False)
+    # 3 classes x 3 difficulties x (strict, loose) + 3 overall, for 3D / BEV / 2D of the 3D set and 2D of the 2D set
+    assert len(ap) == 4 * 21 and all(k.startswith(("img_bbox/KITTI/", "img_bbox2d/KITTI/")) for k in ap)
+    assert all(0.0 <= v <= 100.0 for v in ap.values())                  # random weights: the values are ~0, but defined
+    assert json.load(open(out_json)) == ap
+    ds.write_kitti_results(res, str(tmp_path))
+    assert os.path.isfile(os.path.join(str(tmp_path), "img_bbox", "000007.txt"))
