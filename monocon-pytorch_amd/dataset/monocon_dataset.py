@@ -8,8 +8,8 @@ Differences from the reference, all on the host side of the hot path:
   * the split lists (ImageSets/{train,val,trainval,test}.txt -- data the reference ships inside its source tree) are
     looked up under ``<base_root>/ImageSets``, ``$MONOCON_IMAGESETS`` or an explicit ``imageset_dir``; without one
     the sample ids are taken from the image directory listing;
-  * the random training augmentations are not built (transforms/default_transforms.py header): the train split runs
-    the deterministic transform list too;
+  * the random training augmentations (transforms/augmentations.py) are numpy restatements without cv2 and can draw from
+    an explicit ``np.random.Generator`` (``aug_rng=``) so that data-parallel ranks / loader workers are seeded apart;
   * ``evaluate`` runs the AP evaluator of engine/kitti_eval (HIP overlap kernels + native matching instead of numba);
     ``write_kitti_results`` additionally writes the benchmark's txt submission files.
 The label assembly restates monocon_dataset.py:89-158 by reading (the reference module needs cv2 to import): the
@@ -23,7 +23,8 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from transforms import Compose, Normalize, Pad, ToTensor
+from transforms import (Compose, Normalize, Pad, PhotometricDistortion, RandomCrop3D, RandomHorizontalFlip, RandomShift,
+                        ToTensor)
 from utils.data_classes import KITTICalibration, KITTIMultiObjects
 
 DEFAULT_FILTER_CONFIG = {'min_height': 25, 'min_depth': 2, 'max_depth': 65, 'max_truncation': 0.5, 'max_occlusion': 2}
@@ -31,7 +32,17 @@ IMG_MEAN, IMG_STD = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
 
 
 def default_transforms():
+    """the test / validation list (dataset/monocon_dataset.py:38-42)"""
     return [Normalize(mean=IMG_MEAN, std=IMG_STD), Pad(size_divisor=32), ToTensor()]
+
+
+def default_train_transforms(rng=None):
+    """the reference's training list (dataset/monocon_dataset.py:22-35).  ``rng``: one np.random.Generator for all the random
+    decisions (seed it per rank / worker / epoch); None = numpy's global state."""
+    return [PhotometricDistortion(brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, rng=rng),
+            RandomShift(prob=0.5, shift_range=(-32, 32), hide_kpts_in_shift_area=True, rng=rng),
+            RandomHorizontalFlip(prob=0.5, rng=rng),
+            RandomCrop3D(prob=0.5, crop_size=(320, 960), hide_kpts_in_crop_area=True, rng=rng)] + default_transforms()
 
 
 def _find_imageset(base_root: str, split: str, imageset_dir: Optional[str]) -> Optional[str]:
@@ -86,10 +97,12 @@ class BaseKITTIMono3DDataset(Dataset):
 
 class MonoConDataset(BaseKITTIMono3DDataset):
     def __init__(self, base_root: str, split: str, max_objs: int = 30, transforms=None, filter_configs: Dict[str, Any] = None,
-                 **kwargs):
+                 aug_rng=None, **kwargs):
         super().__init__(base_root=base_root, split=split, **kwargs)
         self.max_objs = max_objs
-        self.transforms = Compose(default_transforms() if transforms is None else transforms)
+        if transforms is None:          # as the reference: augmentations for 'train' only (monocon_dataset.py:58-63)
+            transforms = default_train_transforms(aug_rng) if split == 'train' else default_transforms()
+        self.transforms = Compose(transforms)
         cfg = dict(DEFAULT_FILTER_CONFIG)
         if filter_configs is not None:
             unknown = [k for k in filter_configs if k not in DEFAULT_FILTER_CONFIG]

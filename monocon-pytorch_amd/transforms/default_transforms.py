@@ -2,9 +2,7 @@
 (transforms/default_transforms.py:375-452; dataset/monocon_dataset.py:32-33,39-40) -- on the host, plus
 ``GpuNormalizePad`` which does all three on the device through ``mc_preprocess``.
 
-The random training augmentations (PhotometricDistortion, RandomShift, RandomHorizontalFlip, RandomCrop3D:
-default_transforms.py:24-373, cv2-based) are NOT built: SURVEY 8f-4 lists them last and the reference module cannot
-be imported here to pin them (needs cv2).  Parity of this file is unpinned for the same reason; the arithmetic is
+The random training augmentations live in transforms/augmentations.py.  Parity of this file is unpinned (the reference module imports cv2, absent here); the arithmetic is
 restated by reading: ``(uint8 -> float32 - mean(float64)) / std(float64)`` is a float64 image, zero-padded to a
 multiple of ``size_divisor`` and rounded ONCE to float32 by ``torch.Tensor(...)``.
 """
