@@ -241,6 +241,9 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a measurement must not die on the communicator: if the handle cannot build its own RCCL communicator on this
+        # node, fall back to torch.distributed's all-reduce (also RCCL) -- `multi_gpu.comm` in the JSON says which ran
+        os.environ.setdefault("MONOCON_HIP_DP_FALLBACK", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
