@@ -358,11 +358,13 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restri
 
 // ------------------------------------------------------------------ dy = P*d + Q*y + R,  d = relu ? dz*[z>0] : dz
 // gres_mode: 0 none, 1 gres = d, 2 gres += d (gradient of the residual input)
-__global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *__restrict__ dz, const f32x4 *__restrict__ z,
+// (dz and dy are NOT restrict-qualified: the train plan writes dy in place over dz; every element is read and then
+//  written once, by the same thread)
+__global__ __launch_bounds__(256) void affine_bwd_kernel(const f32x4 *dz, const f32x4 *__restrict__ z,
                                                          const f32x4 *__restrict__ y, const float *__restrict__ coef,
                                                          int C4, int RG, int rows_per_img, int blocks_per_img,
                                                          int rows_per_block, int per_sample, int relu,
-                                                         f32x4 *__restrict__ dy, f32x4 *__restrict__ gres, int gres_mode,
+                                                         f32x4 *dy, f32x4 *__restrict__ gres, int gres_mode,
                                                          const float *__restrict__ fa, const float *__restrict__ fb,
                                                          float *__restrict__ csum /*[blocks][4*C4][2] or null*/,
                                                          unsigned *__restrict__ amax /*max |dy| or null*/) {

@@ -71,6 +71,10 @@ struct TrainState {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> side_ev;
     hipEvent_t side_done = nullptr;
+    // gradient-map pool (see TB::g_acquire): before main-stream closure `first` writes into a recycled buffer it waits for
+    // side-stream closure number `second` (the weight gradient that read the buffer's previous content)
+    std::map<int, int> wait_side;
+    std::vector<hipEvent_t> side_fin;
     bool dual = true;
     std::vector<PackJob> packs;
     mc::PackBatch pack_batch;        // the data-gradient panels of `packs`, one grid per forward
@@ -105,6 +109,8 @@ static std::atomic<unsigned long long> g_train_generation{0};
 static void train_free(TrainState *t) {
     if (!t) return;
     for (hipEvent_t e : t->side_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : t->side_fin)
+        if (e) (void)hipEventDestroy(e);
     if (t->side_done) (void)hipEventDestroy(t->side_done);
     if (t->side) (void)hipStreamDestroy(t->side);
     for (void *q : t->bufs) (void)hipFree(q);
@@ -151,13 +157,58 @@ struct TB {   // train plan builder
         p = static_cast<float *>(q);
         return p;
     }
+    // ---- gradient maps.  The backward closures are BUILT in the order they run, so the life of a map's gradient is known
+    // while building: it starts at its first writer (a data-gradient conv, a pooling / deconv backward, the residual
+    // share of an affine pass) and ends with the layer that produced the map (whose affine pass turns dZ into dY in
+    // place; dY is then read by that layer's data- and weight-gradient launches).  Buffers are handed out at the first
+    // write and returned after the producing layer, oldest first; a buffer whose last reader ran on the weight-gradient
+    // stream carries that closure's number, and its next first writer waits for it (TrainState::wait_side).
+    // MONOCON_HIP_GRAD_POOL=0: one private buffer per map.  Measured at B=32 (one session, scratch/ab/pool_ab.sh):
+    // 37.7 GB / 59.77 ms without the pool, 32.9 GB / 60.09 ms recycling immediately, 33.8 GB / 59.89 ms with two buffers
+    // of head start (the default).
+    struct PoolBuf { float *p; int side_k; };
+    std::map<size_t, std::deque<PoolBuf>> gpool;
+    bool pool_on = [] { const char *e = std::getenv("MONOCON_HIP_GRAD_POOL"); return !e || std::atoi(e) != 0; }();
+    // a returned buffer is handed out again only once `pool_cool` younger ones of its size wait behind it: the weight
+    // gradient that still reads it has then had that many layers of head start, and the wait is a formality
+    int pool_cool = [] { const char *e = std::getenv("MONOCON_HIP_GRAD_POOL_COOL"); return e ? std::atoi(e) : 2; }();
+    float *g_acquire(int node) {
+        TNode &n = ts->nodes[node];
+        if (n.g) return n.g;
+        const size_t ne = n.t.numel();
+        auto &q = gpool[ne];
+        if (pool_on && (int)q.size() > pool_cool) {
+            const PoolBuf b = q.front();
+            q.pop_front();
+            if (b.side_k >= 0) {
+                auto it = ts->wait_side.find((int)ts->bwd.size());
+                if (it == ts->wait_side.end()) ts->wait_side[(int)ts->bwd.size()] = b.side_k;
+                else it->second = std::max(it->second, b.side_k);
+            }
+            n.g = b.p;
+        } else {
+            n.g = alloc(ne);
+        }
+        return n.g;
+    }
+    void g_release(int node, int side_k) {
+        TNode &n = ts->nodes[node];
+        if (!pool_on || !n.g) return;
+        gpool[n.t.numel()].push_back({n.g, side_k});
+        n.g = nullptr;
+    }
+    int last_side_closure() const {       // number (among the side-stream closures) of the last one pushed, -1 if none
+        int k = 0;
+        for (char c : ts->bwd_side) k += c != 0;
+        return k - 1;
+    }
     int node(int B, int H, int W, int C, bool needs_grad = true) {
         TNode n;
         n.t.B = B; n.t.H = H; n.t.W = W; n.t.C = C;
         n.t.p = alloc(n.t.numel());
         n.t.amax = slot();
         n.needs_grad = needs_grad;
-        if (needs_grad) n.g = alloc(n.t.numel());
+        if (needs_grad && !pool_on) n.g = alloc(n.t.numel());
         ts->nodes.push_back(n);
         return (int)ts->nodes.size() - 1;
     }
@@ -323,6 +374,7 @@ struct TB {   // train plan builder
                     int CoutPad) {
         TNode &sn = ts->nodes[srcnode];
         if (!sn.needs_grad) return;
+        g_acquire(srcnode);
         if (stride == 2 && ks == 3) {
             // four output-parity classes, each a small stride-1 window conv over dY that scatters to every
             // second pixel of g_src (no zero-dilated copy of dY, 9 instead of 36 tap-MACs per output quad)
@@ -399,7 +451,9 @@ struct TB {   // train plan builder
     Tensor bn_backward(const Rec &r, const std::string &bn) {
         TNode &zn = ts->nodes[r.z];
         Tensor dy = r.y;
-        dy.p = alloc(r.y.numel());
+        // dY (the gradient wrt the raw conv output) is written IN PLACE over dZ: the affine pass is elementwise and the
+        // gradient of z has no reader after it (the residual branch receives its share in the same pass)
+        dy.p = zn.g;
         dy.amax = slot();
         unsigned *dymax = dy.amax;
         const int B = r.y.B, C = r.y.C, rows = r.y.H * r.y.W;
@@ -412,7 +466,7 @@ struct TB {   // train plan builder
         float *gres = nullptr;
         int gmode = 0;
         if (r.res >= 0 && ts->nodes[r.res].needs_grad) {
-            gres = ts->nodes[r.res].g;
+            gres = g_acquire(r.res);
             gmode = ts->nodes[r.res].ginit ? 2 : 1;
             ts->nodes[r.res].ginit = true;
             ts->nodes[r.res].last_conv = nullptr;
@@ -646,7 +700,8 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         const int nbr = chan_reduce_blocks(B, HW), rb_per_img = nbr / B;
         float *dh = b.alloc(xh.numel());
         float *dw1p = b.alloc((size_t)nbr * NUM_OUT_ROWS * HEAD_CH);
-        float *partial = b.alloc((size_t)nbr * CP * 2), *coef = b.alloc((size_t)B * CP * 4), *dx = b.alloc(xh.numel());
+        float *partial = b.alloc((size_t)nbr * CP * 2), *coef = b.alloc((size_t)B * CP * 4);
+        float *dx = dh;        // the AttnBN backward (an elementwise affine pass) runs in place on the masked gradient
         // scatter dw1 / db1 rows to the parameter gradient tensors (rows are in concatenation order)
         const int *rb = head_row_begin();
         struct Seg { float *dst_w, *dst_b; int r0, nr; };
@@ -723,18 +778,19 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             const TNode &o = ts->nodes[r.z];
             if (!o.ginit || !in.needs_grad) continue;
             const float *xp = in.t.p, *go = o.g;
-            float *gi = in.g;
+            float *gi = b.g_acquire(r.in);
             const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C, acc = in.ginit;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_maxpool2_bwd(xp, go, Bq, Hq, Wq, Cq, gi, acc, st)); return 0; });
             in.ginit = true;
             in.last_conv = nullptr;
+            b.g_release(r.z, -1);
         } else if (r.kind == REC_DECONV) {
             TNode &in = ts->nodes[r.in];
             const TNode &o = ts->nodes[r.z];
             if (!o.ginit) continue;
             if (in.ginit) { ts->ok = false; h->err = "train plan: deconv input has more than one consumer"; }
             const float *xp = in.t.p, *go = o.g, *wp = r.D->wpk;
-            float *gi = in.g, *dw = b.G(r.D->name + ".weight");
+            float *gi = b.g_acquire(r.in), *dw = b.G(r.D->name + ".weight");
             const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C;
             float *part = b.alloc(deconv4_bwd_w_partial_floats(Bq, Hq, Cq));
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
@@ -744,6 +800,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             });
             in.ginit = true;
             in.last_conv = nullptr;
+            b.g_release(r.z, -1);
         } else if (r.kind == REC_CONV) {
             if (r.dead || !ts->nodes[r.z].ginit) continue;
             Tensor dy = b.bn_backward(r, r.bn);
@@ -756,6 +813,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
                 b.emit_dgrad(wm, dy, r.L->cout, r.L->cin, r.L->ks, r.L->stride, c_off, s, r.L->cout);
                 c_off += ts->nodes[s].t.C;
             }
+            b.g_release(r.z, b.last_side_closure());     // dZ / dY of this layer: last read by its weight gradient
         } else if (r.kind == REC_STEM) {
             if (!ts->nodes[r.z].ginit) continue;
             Tensor dy = b.bn_backward(r, r.bn);
@@ -764,6 +822,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             ts->bwd_side.resize(ts->bwd.size(), 0);
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_stem_wgrad(ts->img, dyp, B, H, W, part, dw, st)); return 0; });
             ts->bwd_side.resize(ts->bwd.size(), 1);
+            b.g_release(r.z, b.last_side_closure());
         }
     }
     if (head_only) {
@@ -786,6 +845,11 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         ts->side_ev.resize(ts->dual ? nside : 0);
         for (auto &ev : ts->side_ev)
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ts->dual = false; break; }
+        // one "finished" event per side closure that a recycled gradient buffer waits for
+        ts->side_fin.assign(ts->dual ? nside : 0, nullptr);
+        for (const auto &w : ts->wait_side)
+            if (ts->dual && w.second >= 0 && w.second < (int)nside && !ts->side_fin[w.second] &&
+                hipEventCreateWithFlags(&ts->side_fin[w.second], hipEventDisableTiming) != hipSuccess) { ts->dual = false; break; }
     }
     if (hipDeviceSynchronize() != hipSuccess) return nullptr;
     return tsp.release();
@@ -931,11 +995,17 @@ static int backward_impl(mc_handle *h, TrainState *ts, const float *grad_losses,
             // the main stream; its outputs (the weight gradient) are first needed after mc_backward
             HIPCHK(h, hipEventRecord(ts->side_ev[k], st));
             HIPCHK(h, hipStreamWaitEvent(ts->side, ts->side_ev[k], 0));
-            ++k;
             if (ts->bwd[i](h, ts->side)) return -1;
+            if (k < ts->side_fin.size() && ts->side_fin[k]) HIPCHK(h, hipEventRecord(ts->side_fin[k], ts->side));
+            ++k;
             used_side = true;
-        } else if (ts->bwd[i](h, st)) {
-            return -1;
+        } else {
+            if (used_side) {      // a recycled gradient buffer: its previous content was read on the side stream
+                auto w = ts->wait_side.find((int)i);
+                if (w != ts->wait_side.end() && w->second < (int)ts->side_fin.size() && ts->side_fin[w->second])
+                    HIPCHK(h, hipStreamWaitEvent(st, ts->side_fin[w->second], 0));
+            }
+            if (ts->bwd[i](h, st)) return -1;
         }
         if (dp)
             for (int b = 0; b < MC_NUM_GRAD_BUCKETS; ++b)

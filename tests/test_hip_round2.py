@@ -260,7 +260,7 @@ def test_query_workspace_predicts_what_the_plans_allocate(golden_sd):
     assert eng.workspace_bytes() - base == q_tr
     # full size, without building anything: the number DESIGN.md quotes for B=32
     q32 = eng.query_workspace(32, 384, 1280, "train")
-    assert 40e9 < q32 < 50e9, q32
+    assert 26e9 < q32 < 34e9, q32      # (45.3 GB before round 3: dY in place over dZ, recycled gradient maps)
 
 
 # ------------------------------------------------------------------------------------- guards
