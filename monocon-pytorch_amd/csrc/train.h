@@ -184,7 +184,7 @@ void wgrad_plan(WgradArgs &a, int ks, int stride);            // fills the tilin
 size_t wgrad_partial_floats(const WgradArgs &a, int ks);
 hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st);
 bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride);
-hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st);
+hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int stride, int WN, int WC, hipStream_t st);
 int wgrad_bf16_patches(int prec);
 
 }  // namespace mc

@@ -19,7 +19,7 @@
 //     their tensor's max |x| dictates (WgradArgs::amax_dy / amax_x), staged as two fp16 pieces each, three partial
 //     products per tap; the partial sums leave the kernel multiplied by the exact inverse of both scales.
 // Accumulation, split-K partials and the deterministic reduce stay fp32 (wgrad_reduce_kernel).
-// Stride-2 layers (five in DLA-34) and the 16-channel layers keep their fp32 kernels.
+// Stride-2 3x3 layers (round 3): template parameter S = 2, see WgB16Cfg.  The 16-channel layers keep their fp32 kernel.
 #include <algorithm>
 #include <cstdlib>
 #include "conv_mfma.h"
@@ -38,20 +38,27 @@ template <> struct WPiece<2> { typedef _Float16 T; typedef f16x8 V8; typedef f16
 __device__ __forceinline__ f32x16 wmfma_k16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 wmfma_k16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-template <int KS, int WN, int WC, int SPL>
+template <int KS, int S, int WN, int WC, int SPL>
 struct WgB16Cfg {
+    static_assert(S == 1 || (S == 2 && KS == 3), "stride 2: 3x3 only");
     static constexpr int PB = SPL == 1 ? 2 : 1;                 // patches per staged group (WgradArgs::pb)
     static constexpr int NB = 32 * WN, CB = 32 * WC, NT = 64 * WN * WC;
     static constexpr int PAD = KS / 2;
-    static constexpr int IH = 3 + KS, IW = 7 + KS;              // 6 x 10 (3x3) or 4 x 8 (1x1)
-    static constexpr int XROW = KS == 3 ? 32 : 16;              // bytes per staged halo row (16 / 8 pixels)
+    // stride 1: halo tile 6 x 10 (3x3) or 4 x 8 (1x1).  stride 2: the 4 x 8 output patch reads input rows 2y-1 .. 2y+7 and
+    // columns 2x-1 .. 2x+15; a staged row holds the ODD columns (2x-1+2j, j = 0..8, 16 slots) followed by the EVEN ones
+    // (2x+2j, j = 0..7), so that the 8 pixels a tap column needs are again 8 consecutive slots: tap 0 = odd slots 0..7,
+    // tap 1 = even slots 0..7, tap 2 = odd slots 1..8
+    static constexpr int IH = S == 2 ? 9 : 3 + KS, IW = 7 + KS;
+    static constexpr int XROW = S == 2 ? 48 : (KS == 3 ? 32 : 16);   // bytes per staged halo row
     // Bytes per channel row.  The staging writes of a wave go to 16 channel groups x 4 pixel pairs: with 16-byte aligned
     // rows the 4-channel stride is a multiple of 16 banks whatever the padding, i.e. 4 distinct banks for 16 lanes (a
     // 4-way conflict on every ds_write_b32; PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.75).  Every group of 16
     // channels is therefore skewed by another 16 bytes (lds_skew): the 16 channel groups land on 16 distinct multiples
     // of 4 banks and the pixel pairs fill the gaps -- conflict-free writes; the fragment reads (8 lanes = 8 consecutive
     // channels, same skew) keep their disjoint banks.  Rows grow by the largest skew (48 bytes).
-    static constexpr int XCH = IH * XROW + 48;                  // 240 (3x3) / 112 (1x1)
+    // (stride 2: 9 * 48 + 64 = 496 = 31 * 16 -- an odd number of 16-byte windows per channel keeps the fragment reads of 16
+    //  consecutive channels on 16 distinct windows, as 15 does for stride 1)
+    static constexpr int XCH = IH * XROW + (S == 2 ? 64 : 48);   // 240 (3x3) / 112 (1x1) / 496 (3x3 stride 2)
     static constexpr int DCH = 4 * 16 + 48;                     // bytes per dY channel: 112
     static constexpr int X_PLANE = PB * CB * XCH, D_PLANE = PB * NB * DCH;   // one bf16 piece of each tile
     static constexpr int X_BYTES = SPL * X_PLANE, D_BYTES = SPL * D_PLANE;
@@ -73,9 +80,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int KS, int WN, int WC, int SPL>
-__global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const WgradArgs a) {
-    using Cfg = WgB16Cfg<KS, WN, WC, SPL>;
+template <int KS, int S, int WN, int WC, int SPL>
+// stride 2 stages 2.7x the halo of stride 1 (6 instead of 2 float4 pairs per thread in flight across the MFMA phase): at
+// two workgroups per CU (256 registers) the kernel spills 17-23 registers; one workgroup per CU without spills is faster
+// (one-session A/B, weight-gradient bucket per step: fp32 kernel 14.6 ms, two per CU 14.0, one per CU 13.6)
+#ifndef MC_WG16_S2_OCC
+#define MC_WG16_S2_OCC 1
+#endif
+__global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgrad_bf16_kernel(const WgradArgs a) {
+    using Cfg = WgB16Cfg<KS, S, WN, WC, SPL>;
     typedef typename WPiece<SPL>::T pc_t;
     typedef typename WPiece<SPL>::V8 pc8;
     typedef typename WPiece<SPL>::V2 pc2;
@@ -124,10 +137,11 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
 
     // ---- staging plan.  X item = (halo row, pixel pair, channel group) of a patch, channel group fastest;
     //      dY item = (patch row, pixel pair, channel group).
-    constexpr int XC4 = CB / 4, XPAIRS = IW / 2, XP = IH * XPAIRS * XC4, NIX = (XP + NT - 1) / NT;
+    constexpr int XC4 = CB / 4, XPAIRS = S == 2 ? 9 : IW / 2, XP = IH * XPAIRS * XC4, NIX = (XP + NT - 1) / NT;
     constexpr int NC4 = NB / 4, DP = 4 * 4 * NC4, NID = (DP + NT - 1) / NT;
     static_assert(NT % XC4 == 0 && NT % NC4 == 0 && IW % 2 == 0, "static channel group per thread");
     constexpr int DEAD = -(1 << 24);
+    constexpr int XSTEP = S;                 // the two pixels of a staged pair are S columns apart in the image
     const int xc4 = tid % XC4, dn4 = tid % NC4;
     const bool xc_ok = cs0 + xc4 * 4 < Cs && c0 + xc4 * 4 < a.Cin;
     const bool dn_ok = n0 + dn4 * 4 + 3 < a.dy_ld;
@@ -135,10 +149,18 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
 #pragma unroll
     for (int i = 0; i < NIX; ++i) {
         const int e = tid + NT * i, item = (e / XC4) % (IH * XPAIRS);
-        const int iy = item / XPAIRS, ix = (item % XPAIRS) * 2;
-        x_ix[i] = (xc_ok && e < XP) ? ix - PAD : DEAD;
-        x_stat[i] = (((iy - PAD) * a.Win + ix - PAD) * Cs + cs0 + xc4 * 4) * 4;
-        x_dst[i] = (xc4 * 4) * XCH + lds_skew(xc4 * 4) + iy * XROW + ix * 2;
+        const int iy = item / XPAIRS, pr = item % XPAIRS;
+        // column of the pair's first pixel relative to the tile origin (S * ox), and its byte offset inside the staged row
+        int ix, roff;
+        if (S == 2) {
+            if (pr < 5) { ix = 4 * pr - 1; roff = 4 * pr; }                 // odd plane, slots 2pr, 2pr + 1
+            else { ix = 4 * (pr - 5); roff = 32 + 4 * (pr - 5); }           // even plane
+        } else {
+            ix = pr * 2 - PAD; roff = pr * 4;
+        }
+        x_ix[i] = (xc_ok && e < XP) ? ix : DEAD;
+        x_stat[i] = (((iy - PAD) * a.Win + ix) * Cs + cs0 + xc4 * 4) * 4;
+        x_dst[i] = (xc4 * 4) * XCH + lds_skew(xc4 * 4) + iy * XROW + roff;
     }
     int d_stat[NID], d_mx[NID], d_dst[NID];
 #pragma unroll
@@ -167,13 +189,13 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
         const bool valid = pp < a.ppi;
         const int prow = __builtin_amdgcn_readfirstlane(pp / a.ppr);
         const int oy = prow * 4, ox = valid ? (pp - prow * a.ppr) * 8 : DEAD;
-        const int xb = (oy * a.Win + ox) * Cs * 4;
+        const int xb = (oy * S * a.Win + ox * S) * Cs * 4;
         const int db = (oy * a.Wout + ox) * a.dy_ld * 4;
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
-            const int xx = ox + x_ix[i];
+            const int xx = ox * S + x_ix[i];
             xv[slot][p][i][0] = buf_load4(r_x, (xx >= 0 && xx < a.Win) ? xb + x_stat[i] : BUF_OOB, 0);
-            xv[slot][p][i][1] = buf_load4(r_x, (xx + 1 >= 0 && xx + 1 < a.Win) ? xb + x_stat[i] + Cs * 4 : BUF_OOB, 0);
+            xv[slot][p][i][1] = buf_load4(r_x, (xx + XSTEP >= 0 && xx + XSTEP < a.Win) ? xb + x_stat[i] + XSTEP * Cs * 4 : BUF_OOB, 0);
         }
 #pragma unroll
         for (int i = 0; i < NID; ++i) {
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
 
     const int lc = lane_chan(li);
     const unsigned char *a_base = dyt + (wn * 32 + lc) * DCH + lds_skew(wn * 32 + lc) + g * 16;
-    const unsigned char *b_base = xt + (wc * 32 + lc) * XCH + lds_skew(wc * 32 + lc) + g * XROW;
+    const unsigned char *b_base = xt + (wc * 32 + lc) * XCH + lds_skew(wc * 32 + lc) + g * S * XROW;
 
 #pragma unroll
     for (int d = 0; d < PD; ++d)
@@ -248,7 +270,7 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
                     av[z] = *reinterpret_cast<const pc8 *>(a_base + z * DPL + p * NB * DCH + (2 * q) * 16);
 #pragma unroll
                 for (int r = 0; r < KS; ++r) {
-                    const unsigned char *row = b_base + p * CB * XCH + (2 * q + r) * XROW;
+                    const unsigned char *row = b_base + p * CB * XCH + (2 * q * S + r) * XROW;
                     u32x4 b0[SPL], b1[SPL], b2[SPL];     // the three tap columns of every piece of X
 #pragma unroll
                     for (int z = 0; z < SPL; ++z) {
@@ -261,11 +283,18 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
                             u32x4 hi4 = *reinterpret_cast<const u32x4 *>(row + z * XPL + 16);
                             asm volatile("" : "+v"(hi4));
                             const unsigned hi = hi4[0];
-                            b1[z][0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
-                            b1[z][1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
-                            b1[z][2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16);
-                            b1[z][3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
-                            b2[z][0] = lo[1]; b2[z][1] = lo[2]; b2[z][2] = lo[3]; b2[z][3] = hi;
+                            u32x4 sh;                        // slots 1..8 of the plane `lo` starts
+                            sh[0] = __builtin_amdgcn_alignbit(lo[1], lo[0], 16);
+                            sh[1] = __builtin_amdgcn_alignbit(lo[2], lo[1], 16);
+                            sh[2] = __builtin_amdgcn_alignbit(lo[3], lo[2], 16);
+                            sh[3] = __builtin_amdgcn_alignbit(hi, lo[3], 16);
+                            if (S == 2) {                    // odd columns: taps 0 and 2; even columns: tap 1
+                                b1[z] = *reinterpret_cast<const u32x4 *>(row + z * XPL + 32);
+                                b2[z] = sh;
+                            } else {
+                                b1[z] = sh;
+                                b2[z][0] = lo[1]; b2[z][1] = lo[2]; b2[z][2] = lo[3]; b2[z][3] = hi;
+                            }
                         }
                     }
 #pragma unroll
@@ -300,11 +329,11 @@ __global__ __launch_bounds__(64 * WN * WC, 2) void wgrad_bf16_kernel(const Wgrad
     }
 }
 
-template <int KS, int WN, int WC, int SPL>
+template <int KS, int S, int WN, int WC, int SPL>
 static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
-    using Cfg = WgB16Cfg<KS, WN, WC, SPL>;
+    using Cfg = WgB16Cfg<KS, S, WN, WC, SPL>;
     if (a.pb != Cfg::PB) return hipErrorInvalidValue;
-    auto kern = wgrad_bf16_kernel<KS, WN, WC, SPL>;
+    auto kern = wgrad_bf16_kernel<KS, S, WN, WC, SPL>;
     static bool attr_set = false;
     // experiment knob (only with -DMC_DEBUG_HOOKS): MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the
     // workgroups per CU
@@ -328,8 +357,15 @@ static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
 }
 
 bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride) {
-    if (a.small || stride != 1 || (ks != 3 && ks != 1)) return false;
-    if (a.Wout != a.Win || a.Hout != a.Hin) return false;
+    if (a.small || (ks != 3 && ks != 1)) return false;
+#ifdef MC_WG16_NO_S2
+    if (stride == 2) return false;
+#endif
+    if (stride == 2) {        // the five stride-2 3x3 layers of DLA-34 (the 16-channel one keeps its own kernel: a.small)
+        if (ks != 3 || a.Hin != 2 * a.Hout || a.Win != 2 * a.Wout) return false;
+    } else if (stride != 1 || a.Wout != a.Win || a.Hout != a.Hin) {
+        return false;
+    }
     for (int i = 0; i < a.nsrc; ++i)
         if (a.src[i].C % 4) return false;
     if (a.prec == 3) {        // the fp16 split needs the maxima of both operand tensors
@@ -345,19 +381,20 @@ int wgrad_bf16_patches(int prec) { return prec >= 2 ? 1 : 2; }
 
 // the main kernel of launch_wgrad in the bf16-pipe modes (the split-K reduce is shared); WN / WC as planned
 template <int SPL>
-static hipError_t launch_wgrad_b16_spl(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st) {
-#define WG16(KS_)                                                        \
-    if (WN == 2 && WC == 2) return launch_wg16<KS_, 2, 2, SPL>(a, st);   \
-    if (WN == 4) return launch_wg16<KS_, 4, 1, SPL>(a, st);              \
-    if (WN == 2) return launch_wg16<KS_, 2, 1, SPL>(a, st);              \
-    return launch_wg16<KS_, 1, 1, SPL>(a, st);
-    if (ks == 3) { WG16(3) }
-    WG16(1)
+static hipError_t launch_wgrad_b16_spl(const WgradArgs &a, int ks, int stride, int WN, int WC, hipStream_t st) {
+#define WG16(KS_, S_)                                                        \
+    if (WN == 2 && WC == 2) return launch_wg16<KS_, S_, 2, 2, SPL>(a, st);   \
+    if (WN == 4) return launch_wg16<KS_, S_, 4, 1, SPL>(a, st);              \
+    if (WN == 2) return launch_wg16<KS_, S_, 2, 1, SPL>(a, st);              \
+    return launch_wg16<KS_, S_, 1, 1, SPL>(a, st);
+    if (ks == 3 && stride == 2) { WG16(3, 2) }
+    if (ks == 3) { WG16(3, 1) }
+    WG16(1, 1)
 #undef WG16
 }
-hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int WN, int WC, hipStream_t st) {
-    if (a.prec == 3) return launch_wgrad_b16_spl<2>(a, ks, WN, WC, st);
-    return a.prec == 2 ? launch_wgrad_b16_spl<3>(a, ks, WN, WC, st) : launch_wgrad_b16_spl<1>(a, ks, WN, WC, st);
+hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int stride, int WN, int WC, hipStream_t st) {
+    if (a.prec == 3) return launch_wgrad_b16_spl<2>(a, ks, stride, WN, WC, st);
+    return a.prec == 2 ? launch_wgrad_b16_spl<3>(a, ks, stride, WN, WC, st) : launch_wgrad_b16_spl<1>(a, ks, stride, WN, WC, st);
 }
 
 }  // namespace mc

@@ -438,7 +438,7 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
         wgrad_shape(a, &WN, &WC);
         if (!wgrad_sources_ok(a)) return hipErrorInvalidValue;
         if (a.prec >= 1 && wgrad_bf16_ok(a, ks, stride)) {
-            e = launch_wgrad_bf16(a, ks, WN, WC, st);
+            e = launch_wgrad_bf16(a, ks, stride, WN, WC, st);
         } else {
 #define WG_DISPATCH(KS_, S_)                                                     \
     if (WN == 4) e = launch_wg<KS_, S_, 4, 1>(a, st);                            \

@@ -246,6 +246,29 @@ def test_wgrad_split_emulation_is_fp32_accurate(eng_split, case):
 
 
 @pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 5e-6), (3, 5e-6)], ids=["bf16", "split", "f16x2"])
+@pytest.mark.parametrize("case", [(2, 16, 32, [32], 64), (1, 24, 48, [64], 128), (2, 8, 16, [128], 256), (1, 10, 24, [64], 64),
+                                  (1, 12, 40, [256], 512), (1, 16, 16, [32, 32], 64)],
+                         ids=["32_64", "64_128", "128_256", "ragged_patches", "256_512", "two_sources"])
+def test_stride2_wgrad_on_the_bf16_pipe(mode, tol, case):
+    """3x3 stride-2 weight gradient (round 3: the odd / even column planes of wgrad_bf16_kernel<3, 2, ...>) vs autograd in
+    fp64, in all three modes; incl. output sizes that are not multiples of the 4 x 8 patch and a concatenated input"""
+    from hipmonocon.engine import Engine
+    B, H, W, cins, cout = case
+    xs = [rnd(4321, "x%d" % i, (B, c, H, W)) for i, c in enumerate(cins)]
+    dy = rnd(4321, "dy", (B, cout, H // 2, W // 2))
+    w = torch.zeros(cout, sum(cins), 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(torch.cat(xs, 1).double(), w, None, 2, 1).backward(dy.double())
+    eng = Engine()
+    eng.set_precision(mode)
+    try:
+        got = eng.op_conv_wgrad([nhwc(x).cuda() for x in xs], nhwc(dy).cuda(), 3, 2).cpu()
+    finally:
+        eng.close()
+    assert got.shape == w.grad.shape
+    assert rel_err(got, w.grad) < tol, rel_err(got, w.grad)
+
+
+@pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 5e-6), (3, 5e-6)], ids=["bf16", "split", "f16x2"])
 @pytest.mark.parametrize("case", [(2, 16, 24, 64, 0, 64, 64, 3, 1), (1, 8, 16, 192, 64, 64, 64, 3, 1),
                                   (2, 16, 32, 32, 0, 32, 64, 3, 2), (1, 24, 48, 64, 0, 64, 128, 3, 2),
                                   (1, 12, 16, 448, 256, 64, 128, 1, 1)],
