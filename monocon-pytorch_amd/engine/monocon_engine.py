@@ -56,8 +56,8 @@ class MonoconEngine(BaseEngine):
             dataset = SyntheticMonoConDataset(length=n if is_train else max(n // 4, 1), height=int(hw[0]), width=int(hw[1]),
                                               max_objs=self.cfg.MODEL.HEAD.MAX_OBJS, seed=1 if is_train else 2)
         else:
-            # the KITTI file dataset (dataset/monocon_dataset.py: PIL decode, deterministic transforms; the random
-            # training augmentations of the reference are not built -- SURVEY 8f-4)
+            # the KITTI file dataset (dataset/monocon_dataset.py: PIL decode; the 'train' split runs the reference's random
+            # augmentations, transforms/augmentations.py, every other split the deterministic list)
             from dataset.monocon_dataset import MonoConDataset
             dataset = MonoConDataset(base_root=self.cfg.DATA.ROOT,
                                      split=self.cfg.DATA.TRAIN_SPLIT if is_train else self.cfg.DATA.TEST_SPLIT,
@@ -66,9 +66,19 @@ class MonoconEngine(BaseEngine):
         sampler = None
         if self.world > 1 and is_train:
             sampler = DistributedSampler(dataset, num_replicas=self.world, rank=self.rank, shuffle=True, drop_last=True)
+        rank = self.rank
+
+        def seed_worker(worker_id):
+            # torch seeds numpy per WORKER from a base seed that is the same on every rank (replicas start from rank 0's
+            # seed): offset it per rank, or all ranks would draw the same augmentation decisions for their shards
+            import numpy as np
+            np.random.seed((torch.initial_seed() + 1000003 * (rank + 1)) % (2 ** 32))
+        if is_train and self.cfg.DATA.NUM_WORKERS == 0 and self.world > 1:
+            seed_worker(0)
         loader = DataLoader(dataset, batch_size=self.cfg.DATA.BATCH_SIZE, num_workers=self.cfg.DATA.NUM_WORKERS,
                             shuffle=(is_train and sampler is None), sampler=sampler, collate_fn=dataset.collate_fn,
-                            drop_last=(self.world > 1 and is_train))
+                            drop_last=(self.world > 1 and is_train),
+                            worker_init_fn=seed_worker if (is_train and self.cfg.DATA.NUM_WORKERS > 0) else None)
         return dataset, loader
 
     @decorator_timer
