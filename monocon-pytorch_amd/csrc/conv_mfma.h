@@ -737,6 +737,8 @@ hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal,
 // (single_word: a weight slot -- one word; otherwise a tensor slot of AMAX_WORDS words)
 hipError_t launch_absmax(const float *x, size_t n, unsigned *slot, hipStream_t st, bool single_word = false);
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st);
+bool conv_thin_ok(const ConvArgs &a, int ks, int stride);            // conv_thin.hip
+hipError_t launch_conv_thin(const ConvArgs &a, hipStream_t st);
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);
 

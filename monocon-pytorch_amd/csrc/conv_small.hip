@@ -217,6 +217,7 @@ bool conv_small_ok(const ConvArgs &a, int ks, int stride) {
 }
 
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st) {
+    if (conv_thin_ok(a, 3, stride)) return launch_conv_thin(a, st);      // mode 3: the fp16-pipe kernel (conv_thin.hip)
     const int nr = (stride == 1 && a.Cin == 16) ? 2 : 1;             // rows per wave pass (see the kernel)
     const int rows = a.B * ((a.Hout + nr - 1) / nr);
     int blocks = (rows + 3) / 4;

@@ -215,6 +215,45 @@ def test_conv_split_emulation_is_fp32_accurate(eng_split, case):
     assert rel_err(got, base) < 2e-6
 
 
+THIN_CASES = [
+    # 16 -> 16, 3x3, stride 1: the full-resolution layers.  (name, B, H, W, residual, relu, scale of x)
+    ("two_strips", 2, 16, 128, True, True, 1.0),
+    ("ragged_rows_and_strip", 1, 19, 48, False, True, 1.0),         # H % 8 != 0, W < one 64-pixel strip
+    ("three_strips_last_partial", 1, 8, 144, False, False, 1.0),
+    ("tiny_values", 1, 9, 64, True, False, 1e-12),
+    ("one_row", 1, 1, 32, False, True, 3e4),
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES, ids=[c[0] for c in THIN_CASES])
+def test_thin16_conv_on_the_fp16_pipe(case):
+    """csrc/conv_thin.hip (mode 3 only: the LDS-staged fp16-split kernel that replaces the fp32 row kernel for the 16-channel
+    3x3 layers): fp32-accurate vs fp64 (5e-6, the op-level gate of every fp32 path) and within 2e-6 of the fp32 row kernel"""
+    from hipmonocon.engine import Engine
+    name, B, H, W, use_res, relu, xs_scale = case
+    seed = 1300 + THIN_CASES.index(case)
+    x = rnd(seed, "x", (B, 16, H, W)) * xs_scale
+    w = rnd(seed, "w", (16, 16, 3, 3), (2.0 / (9 * 16)) ** 0.5)
+    bias = 0.1 * xs_scale * rnd(seed, "bi", (16,))
+    res = xs_scale * rnd(seed, "res", (B, 16, H, W)) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1) + bias.double()[None, :, None, None]
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    eng = Engine()
+    try:
+        args = ([nhwc(x).cuda()], w.cuda(), 1, None, bias.cuda(), nhwc(res).cuda() if use_res else None, relu)
+        eng.set_precision(3)
+        got = eng.op_conv(*args).cpu()
+        eng.set_precision(0)
+        base = eng.op_conv(*args).cpu()
+    finally:
+        eng.close()
+    assert rel_err(got.permute(0, 3, 1, 2), ref) < 5e-6
+    assert rel_err(got, base) < 2e-6
+
+
 @pytest.mark.parametrize("mode", [2, 3], ids=["bf16x3", "f16x2"])
 def test_forward_split_emulation_meets_the_fp32_parity_gate(golden_sd, mode):
     """eval forward at 64x128 in modes 2 / 3 against the REFERENCE's fp64 golden: the same 1e-4 gate as the fp32 path."""
