@@ -35,8 +35,12 @@ struct CopyBatch {
 hipError_t launch_copy_batch(const CopyBatch &cb, hipStream_t st);
 
 // ---- backbone / neck element kernels -----------------------------------------------------
+// prec 3: the fp16-pipe kernel (stem_f16.hip), every other mode the VALU kernel; amax: max |out| folded into the slot
 hipError_t launch_stem(const float *img_nchw, int B, int H, int W, const float *wpk, const float *scale,
-                       const float *shift, float *out_nhwc, hipStream_t st, int relu = 1);
+                       const float *shift, float *out_nhwc, hipStream_t st, int relu = 1, int prec = 0,
+                       unsigned *amax = nullptr);
+hipError_t launch_stem_f16(const float *img, int B, int H, int W, const float *wpk, const float *scale, const float *shift,
+                           float *out, hipStream_t st, int relu, unsigned *amax_out);
 hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out,
                           hipStream_t st, unsigned *amax = nullptr);   // amax: max |out| folded into the slot (conv_mfma.h)

@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
 }
 
 hipError_t launch_stem(const float *img, int B, int H, int W, const float *wpk, const float *scale,
-                       const float *shift, float *out, hipStream_t st, int relu) {
+                       const float *shift, float *out, hipStream_t st, int relu, int prec, unsigned *amax) {
+#ifndef MC_NO_STEM_F16
+    if (prec == 3) return launch_stem_f16(img, B, H, W, wpk, scale, shift, out, st, relu, amax);
+#endif
     const int tiles = ((W + ST_TW - 1) / ST_TW) * ((H + ST_TH - 1) / ST_TH);
     hipLaunchKernelGGL(stem_kernel, dim3(B * tiles), dim3(256), 0, st, img, B, H, W, wpk, scale, shift, out, relu);
     return hipGetLastError();

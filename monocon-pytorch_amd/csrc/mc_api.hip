@@ -391,6 +391,7 @@ static Plan *get_plan(mc_handle *h, int B, int H, int W) {
         op.kind = OP_STEM;
         op.out = x0.p; op.B = B; op.H = H; op.W = W;
         op.w = h->stem_w; op.scale = h->stem_scale; op.shift = h->stem_shift;
+        op.amax = x0.amax;
         op.flops = 2.0 * B * H * W * 16.0 * 147.0;
         op.bytes = 4.0 * ((double)B * 3 * H * W + (double)x0.numel());
         pl->stem_op = (int)pl->ops.size();
@@ -481,7 +482,7 @@ static int plan_absmax(mc_handle *h, const Tensor &t, hipStream_t st) {
 static int run_op(mc_handle *h, const Op &op, hipStream_t st) {
     switch (op.kind) {
         case OP_STEM:
-            HIPCHK(h, launch_stem(op.in, op.B, op.H, op.W, op.w, op.scale, op.shift, op.out, st));
+            HIPCHK(h, launch_stem(op.in, op.B, op.H, op.W, op.w, op.scale, op.shift, op.out, st, 1, h->prec, op.amax));
             break;
         case OP_CONV:
             HIPCHK(h, launch_conv(op.ca, op.ks, op.stride, st));
@@ -920,7 +921,7 @@ int mc_op_stem(mc_handle *h, const float *img, int B, int H, int W, const float 
     ScratchBuf wpk;
     HIPCHK(h, wpk.alloc(147 * 16 * sizeof(float)));
     HIPCHK(h, launch_pack_stem_w(weight_oihw, wpk.as<float>(), st));
-    hipError_t e = launch_stem(img, B, H, W, wpk.as<float>(), scale, bias, out, st);
+    hipError_t e = launch_stem(img, B, H, W, wpk.as<float>(), scale, bias, out, st, 1, h->prec);
     hipError_t e2 = hipStreamSynchronize(st);
     HIPCHK(h, e);
     HIPCHK(h, e2);

@@ -552,7 +552,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         float *yp = stem.y.p, *zp = ts->nodes[stem.z].t.p, *rm = b.P(stem.bn + ".running_mean");
         const float *sw = h->stem_w;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_stem(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0));
+            HIPCHK(hh, launch_stem(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, hh->prec));
             HIPCHK(hh, launch_chan_reduce(yp, nullptr, nullptr, rm, B, H * W, 16, 0, 0, partial, 16, st));
             return 0;
         });

@@ -254,6 +254,31 @@ def test_thin16_conv_on_the_fp16_pipe(case):
     assert rel_err(got, base) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(2, 16, 64, 1.0), (1, 33, 65, 1.0), (1, 8, 200, 1e-9), (1, 21, 130, 2e4), (1, 5, 7, 1.0)],
+                         ids=["one_tile", "ragged_33x65", "tiny_values_4_tiles", "large_values", "smaller_than_the_halo"])
+def test_stem_on_the_fp16_pipe(case):
+    """csrc/stem_f16.hip (mode 3): the 7x7 stem with folded BN + ReLU vs fp64, at the op-level gate of the fp32 kernel (5e-6
+    norm-wise) and within 2e-6 of it; the per-workgroup operand scale makes the image's magnitude irrelevant"""
+    from hipmonocon.engine import Engine
+    B, H, W, mag = case
+    seed = 1400 + H
+    x = rnd(seed, "x", (B, 3, H, W)) * mag
+    w = rnd(seed, "w", (16, 3, 7, 7), (2.0 / 147) ** 0.5)
+    sc = 1.0 + 0.1 * rnd(seed, "sc", (16,))
+    bi = 0.2 * mag * rnd(seed, "bi", (16,))
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, 1, 3) * sc.double()[None, :, None, None] + bi.double()[None, :, None, None])
+    eng = Engine()
+    try:
+        eng.set_precision(3)
+        got = eng.op_stem(x.cuda(), w.cuda(), sc.cuda(), bi.cuda()).cpu()
+        eng.set_precision(0)
+        base = eng.op_stem(x.cuda(), w.cuda(), sc.cuda(), bi.cuda()).cpu()
+    finally:
+        eng.close()
+    assert rel_err(got.permute(0, 3, 1, 2), ref) < 5e-6
+    assert rel_err(got, base) < 2e-6
+
+
 @pytest.mark.parametrize("mode", [2, 3], ids=["bf16x3", "f16x2"])
 def test_forward_split_emulation_meets_the_fp32_parity_gate(golden_sd, mode):
     """eval forward at 64x128 in modes 2 / 3 against the REFERENCE's fp64 golden: the same 1e-4 gate as the fp32 path."""
