@@ -39,8 +39,11 @@ hipError_t launch_copy_batch(const CopyBatch &cb, hipStream_t st);
 hipError_t launch_stem(const float *img_nchw, int B, int H, int W, const float *wpk, const float *scale,
                        const float *shift, float *out_nhwc, hipStream_t st, int relu = 1, int prec = 0,
                        unsigned *amax = nullptr);
+// the fp16-pipe kernel; stats (optional): [B][H][16][2] partial sums of (out - stat_shift), (out - stat_shift)^2 per output row
 hipError_t launch_stem_f16(const float *img, int B, int H, int W, const float *wpk, const float *scale, const float *shift,
-                           float *out, hipStream_t st, int relu, unsigned *amax_out);
+                           float *out, hipStream_t st, int relu, unsigned *amax_out, float *stats = nullptr,
+                           const float *stat_shift = nullptr);
+bool stem_f16_enabled();       // false when compiled out (-DMC_NO_STEM_F16)
 hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out,
                           hipStream_t st, unsigned *amax = nullptr);   // amax: max |out| folded into the slot (conv_mfma.h)

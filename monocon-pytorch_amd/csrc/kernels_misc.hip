@@ -160,6 +160,13 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
     }
 }
 
+bool stem_f16_enabled() {
+#ifdef MC_NO_STEM_F16
+    return false;
+#else
+    return true;
+#endif
+}
 hipError_t launch_stem(const float *img, int B, int H, int W, const float *wpk, const float *scale,
                        const float *shift, float *out, hipStream_t st, int relu, int prec, unsigned *amax) {
 #ifndef MC_NO_STEM_F16

@@ -546,19 +546,27 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     {
         std::vector<float> one(16, 1.f);
         if (!h->dry_alloc && hipMemcpy(ones16, one.data(), 64, hipMemcpyHostToDevice) != hipSuccess) ts->ok = false;
-        const int nb = chan_reduce_blocks(B, H * W);
+        // mode 3: the fp16-pipe stem leaves the (sum, sum of squares) partials per output row itself; the other modes reduce
+        // the raw map in a second pass
+        const bool fused_stats = h->prec == 3 && stem_f16_enabled();
+        const int nb = fused_stats ? B * H : chan_reduce_blocks(B, H * W);
         float *partial = b.alloc((size_t)nb * 16 * 2), *ca = b.alloc(16), *cb = b.alloc(16);
         stem.mean = b.alloc(16); stem.rstd = b.alloc(16);
         float *yp = stem.y.p, *zp = ts->nodes[stem.z].t.p, *rm = b.P(stem.bn + ".running_mean");
+        unsigned *zmax = ts->nodes[stem.z].t.amax;
         const float *sw = h->stem_w;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_stem(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, hh->prec));
-            HIPCHK(hh, launch_chan_reduce(yp, nullptr, nullptr, rm, B, H * W, 16, 0, 0, partial, 16, st));
+            if (fused_stats) {
+                HIPCHK(hh, launch_stem_f16(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, nullptr, partial, rm));
+            } else {
+                HIPCHK(hh, launch_stem(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, hh->prec));
+                HIPCHK(hh, launch_chan_reduce(yp, nullptr, nullptr, rm, B, H * W, 16, 0, 0, partial, 16, st));
+            }
             return 0;
         });
         b.bn_train_ops(stem.y, partial, nb, 16, stem.bn, 1e-5f, 0.1f, ca, cb, stem.mean, stem.rstd);
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_affine_act(yp, ca, cb, nullptr, B, (size_t)H * W, 16, 0, 1, zp, st));
+            HIPCHK(hh, launch_affine_act(yp, ca, cb, nullptr, B, (size_t)H * W, 16, 0, 1, zp, st, zmax));
             return 0;
         });
         ts->recs.push_back(stem);

@@ -33,7 +33,9 @@ constexpr int SNI = (SPIX + 255) / 256;          // 4 pixels per thread
 __global__ __launch_bounds__(256) void stem_f16_kernel(const float *__restrict__ img, int B, int H, int W,
                                                        const float *__restrict__ wpk /*[c][r][s][16]*/,
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
-                                                       float *__restrict__ out, int relu, unsigned *__restrict__ amax_out) {
+                                                       float *__restrict__ out, int relu, unsigned *__restrict__ amax_out,
+                                                       float *__restrict__ stats /*[B][H][16][2] or null*/,
+                                                       const float *__restrict__ stat_shift) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SPIX * 8];     // [piece][row][pixel] x (4 x fp16)
     __shared__ unsigned s_max;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -74,7 +76,9 @@ __global__ __launch_bounds__(256) void stem_f16_kernel(const float *__restrict__
         }
 
     const float sc = scale[li], sf = shift[li];
+    const float sh = (stats && stat_shift) ? stat_shift[li] : 0.f;
     float vmax = 0.f;
+    float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};     // train mode: sum (v - shift), sum (v - shift)^2 of this wave's two rows
 
     // ---- a workgroup walks its band of 8 rows in strips of 64 pixels (the filter registers are loaded once per band);
     //      thread = staged pixel (its three channel planes); the next strip's loads are in flight during the MFMAs
@@ -158,8 +162,25 @@ __global__ __launch_bounds__(256) void stem_f16_kernel(const float *__restrict__
                     if (x < W) {
                         orow[(size_t)x * 16 + li] = v;
                         vmax = fmaxf(vmax, fabsf(v));
+                        const float d = v - sh;
+                        ssum[q] += d;
+                        ssq[q] = fmaf(d, d, ssq[q]);
                     }
                 }
+            }
+        }
+    }
+    if (stats) {       // one partial per (image, output row): the layout of the row kernels (conv_small.hip)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int y = ty0 + 2 * wave + q;
+            float s1 = ssum[q], s2 = ssq[q];
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (kq == 0 && y < H) {
+                float *dst = stats + (((size_t)b * H + y) * 16 + li) * 2;
+                dst[0] = s1;
+                dst[1] = s2;
             }
         }
     }
@@ -167,9 +188,10 @@ __global__ __launch_bounds__(256) void stem_f16_kernel(const float *__restrict__
 }
 
 hipError_t launch_stem_f16(const float *img, int B, int H, int W, const float *wpk, const float *scale, const float *shift,
-                           float *out, hipStream_t st, int relu, unsigned *amax_out) {
+                           float *out, hipStream_t st, int relu, unsigned *amax_out, float *stats, const float *stat_shift) {
     const int tiles = (H + SR - 1) / SR;          // one workgroup per band of 8 rows
-    hipLaunchKernelGGL(stem_f16_kernel, dim3(B * tiles), dim3(256), 0, st, img, B, H, W, wpk, scale, shift, out, relu, amax_out);
+    hipLaunchKernelGGL(stem_f16_kernel, dim3(B * tiles), dim3(256), 0, st, img, B, H, W, wpk, scale, shift, out, relu, amax_out, stats,
+                       stat_shift);
     return hipGetLastError();
 }
 
