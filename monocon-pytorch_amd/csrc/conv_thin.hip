@@ -22,6 +22,12 @@
 //     weight-gradient kernels).
 #include "conv_mfma.h"
 
+#ifndef THIN_OCC
+#define THIN_OCC 2
+#endif
+#ifndef THIN_MT_UNROLL
+#define THIN_MT_UNROLL 1
+#endif
 namespace mc {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -37,7 +43,7 @@ constexpr int NI = (ITEMS + 255) / 256;
 }  // namespace
 
 template <int NTN>
-__global__ __launch_bounds__(256) void conv_thin16_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, THIN_OCC) void conv_thin16_kernel(const ConvArgs a) {
     constexpr int CIN = 16;
     __shared__ __attribute__((aligned(16))) unsigned char lds[4 * PLANE];      // [piece][half][row][pixel] x 16 B
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,15 +95,16 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const ConvArgs a) {
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
     float vmax = 0.f;
 
-    // ---- staging plan: item e = (row, pixel, channel quad), quad fastest (4 lanes = the 64 bytes of one pixel)
-    int s_row[NI], s_px[NI], s_dst[NI];
+    // ---- staging plan: item e = (row, pixel, channel quad), quad fastest (4 lanes = the 64 bytes of one pixel).
+    //      s_off: byte offset of the item relative to the tile's first halo pixel; rows outside the image need no test
+    //      (their offsets fall outside the image's buffer descriptor), columns do (they would wrap into the next row)
+    int s_off[NI], s_dst[NI];          // (s_dst < 0: no such item)
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int e = tid + 256 * i;
         const int c4 = e & 3, px = (e >> 2) % IP, row = (e >> 2) / IP;
-        s_row[i] = e < ITEMS ? row : -1000;
-        s_px[i] = px;
-        s_dst[i] = ((c4 >> 1) * PLANE) + (row * IP + px) * 16 + (c4 & 1) * 8;
+        s_off[i] = ((row * a.Win + px) * CIN + c4 * 4) * 4;
+        s_dst[i] = e < ITEMS ? ((c4 >> 1) * PLANE) + (row * IP + px) * 16 + (c4 & 1) * 8 : -1;
     }
 
     const int tiles_per_img = (a.Hout + TR - 1) / TR;
@@ -121,19 +128,25 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const ConvArgs a) {
             for (int nt = 0; nt < NTN; ++nt) ssum[q][nt] = ssq[q][nt] = 0.f;
 
         f32x4 pre[NI];
+        const int band_off = ((oy0 - 1) * a.Win - 1) * CIN * 4;      // (row oy0 - 1, column -1) of this image
         auto fetch = [&](int strip) {
-            const int x0 = strip * TW - 1;
+            const int x0 = strip * TW - 1, so = band_off + strip * TW * CIN * 4;
+            if (strip > 0 && x0 + IP <= a.Win) {          // interior strip: every column is inside the image
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int iy = oy0 - 1 + s_row[i], ix = x0 + s_px[i];
-                const bool ok = iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-                pre[i] = buf_load4(r_x, ok ? ((iy * a.Win + ix) * CIN + ((tid + 256 * i) & 3) * 4) * 4 : BUF_OOB, 0);
+                for (int i = 0; i < NI; ++i) pre[i] = buf_load4(r_x, s_dst[i] >= 0 ? s_off[i] + so : BUF_OOB, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int px = ((s_dst[i] % PLANE) >> 4) % IP;      // (recomputed: not worth 11 registers for 2 strips of 20)
+                    const bool ok = s_dst[i] >= 0 && (unsigned)(x0 + px) < (unsigned)a.Win;
+                    pre[i] = buf_load4(r_x, ok ? s_off[i] + so : BUF_OOB, 0);
+                }
             }
         };
         auto store = [&]() {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                if (256 * (i + 1) > ITEMS && tid + 256 * i >= ITEMS) continue;
+                if (256 * (i + 1) > ITEMS && s_dst[i] < 0) continue;
                 f16x4 h4, l4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_thin16_kernel(const ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int trow = 2 * wave + q;              // output row inside the tile
-#pragma unroll 1
+#pragma unroll THIN_MT_UNROLL
                 for (int mt = 0; mt < TW / 16; ++mt) {
                     const int x0 = sx0 + mt * 16;
                     if (x0 >= a.Wout) break;

@@ -17,6 +17,9 @@
 #include "conv_mfma.h"
 #include "kernels.h"
 
+#ifndef STEM_MT_UNROLL
+#define STEM_MT_UNROLL 1
+#endif
 namespace mc {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void stem_f16_kernel(const float *__restrict__
             const int trow = 2 * wave + q, y = ty0 + trow;
             if (y >= H) continue;
             float *orow = out + ((size_t)b * H + y) * W * 16;
-#pragma unroll 1
+#pragma unroll STEM_MT_UNROLL
             for (int mt = 0; mt < SW / 16; ++mt) {
                 const int x0 = tx0 + mt * 16;
                 if (x0 >= W) break;
