@@ -42,7 +42,10 @@ hipError_t launch_stem(const float *img_nchw, int B, int H, int W, const float *
 // the fp16-pipe kernel; stats (optional): [B][H][16][2] partial sums of (out - stat_shift), (out - stat_shift)^2 per output row
 hipError_t launch_stem_f16(const float *img, int B, int H, int W, const float *wpk, const float *scale, const float *shift,
                            float *out, hipStream_t st, int relu, unsigned *amax_out, float *stats = nullptr,
-                           const float *stat_shift = nullptr);
+                           const float *stat_shift = nullptr, unsigned *img_amax = nullptr);
+// the stem's weight gradient on the fp16 pipe (partials in the layout of stem_wgrad_lds_kernel; the caller reduces them)
+hipError_t launch_stem_wgrad_f16(const float *img, const float *dy, int B, int H, int W, float *partial, int nblocks,
+                                 const unsigned *img_amax, const unsigned *dy_amax, hipStream_t st);
 bool stem_f16_enabled();       // false when compiled out (-DMC_NO_STEM_F16)
 hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out,

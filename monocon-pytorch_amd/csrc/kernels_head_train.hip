@@ -606,8 +606,14 @@ int stem_wgrad_blocks(int B, int H, int W) {
     return (B * ((W + 31) / 32) * ((H + 7) / 8) + STEM_WG_TILES - 1) / STEM_WG_TILES;
 }
 hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
-                             hipStream_t st) {
+                             hipStream_t st, const unsigned *img_amax, const unsigned *dy_amax) {
     const int nb = stem_wgrad_blocks(B, H, W);
+#ifndef MC_NO_STEM_WG_F16
+    if (img_amax && dy_amax && stem_wgrad_use_mfma(W)) {
+        hipError_t e = launch_stem_wgrad_f16(img, dy, B, H, W, partial, nb, img_amax, dy_amax, st);
+        if (e != hipSuccess) return e;
+    } else
+#endif
     if (stem_wgrad_use_mfma(W))
         hipLaunchKernelGGL(stem_wgrad_lds_kernel, dim3(nb), dim3(256), 0, st, img, dy, B, H, W, partial);
     else

@@ -73,6 +73,7 @@ struct TrainState {
     hipEvent_t side_done = nullptr;
     // gradient-map pool (see TB::g_acquire): before main-stream closure `first` writes into a recycled buffer it waits for
     // side-stream closure number `second` (the weight gradient that read the buffer's previous content)
+    unsigned *img_amax = nullptr;      // mode 3: max |image| slot (written by the forward stem, read by its weight gradient)
     std::map<int, int> wait_side;
     std::vector<hipEvent_t> side_fin;
     bool dual = true;
@@ -554,10 +555,12 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         stem.mean = b.alloc(16); stem.rstd = b.alloc(16);
         float *yp = stem.y.p, *zp = ts->nodes[stem.z].t.p, *rm = b.P(stem.bn + ".running_mean");
         unsigned *zmax = ts->nodes[stem.z].t.amax;
+        unsigned *imax = fused_stats ? b.slot() : nullptr;     // max |image|, left by the forward stem for its weight gradient
+        ts->img_amax = imax;
         const float *sw = h->stem_w;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
             if (fused_stats) {
-                HIPCHK(hh, launch_stem_f16(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, nullptr, partial, rm));
+                HIPCHK(hh, launch_stem_f16(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, nullptr, partial, rm, imax));
             } else {
                 HIPCHK(hh, launch_stem(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, hh->prec));
                 HIPCHK(hh, launch_chan_reduce(yp, nullptr, nullptr, rm, B, H * W, 16, 0, 0, partial, 16, st));
@@ -827,8 +830,12 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             Tensor dy = b.bn_backward(r, r.bn);
             float *part = b.alloc((size_t)stem_wgrad_blocks(B, H, W) * 147 * 16), *dw = b.G("backbone.base_layer.0.weight");
             const float *dyp = dy.p;
+            const unsigned *imax = ts->img_amax, *dymax = dy.amax;
             ts->bwd_side.resize(ts->bwd.size(), 0);
-            ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_stem_wgrad(ts->img, dyp, B, H, W, part, dw, st)); return 0; });
+            ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
+                HIPCHK(hh, launch_stem_wgrad(ts->img, dyp, B, H, W, part, dw, st, imax, imax ? dymax : nullptr));
+                return 0;
+            });
             ts->bwd_side.resize(ts->bwd.size(), 1);
             b.g_release(r.z, b.last_side_closure());
         }

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void stem_f16_kernel(const float *__restrict__
                                                        const float *__restrict__ scale, const float *__restrict__ shift,
                                                        float *__restrict__ out, int relu, unsigned *__restrict__ amax_out,
                                                        float *__restrict__ stats /*[B][H][16][2] or null*/,
-                                                       const float *__restrict__ stat_shift) {
+                                                       const float *__restrict__ stat_shift,
+                                                       unsigned *__restrict__ img_amax /*max |image| slot or null*/) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SPIX * 8];     // [piece][row][pixel] x (4 x fp16)
     __shared__ unsigned s_max;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void stem_f16_kernel(const float *__restrict__
         const int ex = f16_scale_exp(s_max);
         const float x_scale = exp2i(ex);
         const float omul = exp2i(-ex) * exp2i(-ew);
+        if (img_amax && tid == 0) amax_commit(img_amax, s_max);      // the weight gradient scales the image by its global maximum
 #pragma unroll
         for (int i = 0; i < SNI; ++i) {
             const int e = tid + 256 * i;
@@ -191,10 +193,179 @@ __global__ __launch_bounds__(256) void stem_f16_kernel(const float *__restrict__
 }
 
 hipError_t launch_stem_f16(const float *img, int B, int H, int W, const float *wpk, const float *scale, const float *shift,
-                           float *out, hipStream_t st, int relu, unsigned *amax_out, float *stats, const float *stat_shift) {
+                           float *out, hipStream_t st, int relu, unsigned *amax_out, float *stats, const float *stat_shift,
+                           unsigned *img_amax) {
     const int tiles = (H + SR - 1) / SR;          // one workgroup per band of 8 rows
     hipLaunchKernelGGL(stem_f16_kernel, dim3(B * tiles), dim3(256), 0, st, img, B, H, W, wpk, scale, shift, out, relu, amax_out, stats,
-                       stat_shift);
+                       stat_shift, img_amax);
+    return hipGetLastError();
+}
+
+
+// ---- the stem's weight gradient on the same pipe.  Structure of stem_wgrad_lds_kernel (kernels_head_train.hip): persistent
+// workgroups walk 4-row x 128-pixel output tiles, the 3 x 10 x 134 image window of a tile goes through LDS, a wave owns one
+// row, D[n][t] = sum over pixels of dY[pixel][n] * img[c(t)][y + r(t) - 3][x + s(t) - 3] over the 147 taps t = (c, r, s).
+// With K = 32 pixels per v_mfma_f32_16x16x32_f16 instead of 4:
+//   * A (dY, NHWC): the 8 consecutive pixels of a lane are 8 dword loads 64 bytes apart (16 lanes = one 64-byte pixel
+//     row each) -- the same number of loads per pixel as before -- scaled and split in registers;
+//   * B (image): a lane's 8 pixels start at x + 8g + s, s = 0..6 the tap's column.  Taps are tiled BY s: the 16 columns
+//     of an MFMA are 16 of the 21 window rows (c, r), all with the same s -- then all seven s-tiles of a lane read the
+//     same 16-pixel span of the same row: two aligned 16-byte LDS reads per piece, and the seven operands are that span
+//     shifted by s elements in registers (nothing for even s, four v_alignbit for odd s; s is a compile-time constant of
+//     the tile).  14 tiles (2 row groups x 7) instead of 10: 40 % more MFMAs, five times fewer LDS bytes.  (gfx950 does
+//     serve unaligned ds_read_b128 -- scratch/ua/ua.hip -- but a first version built on 20 unaligned reads per K-step ran
+//     at half the speed of the fp32 kernel.)
+//   * the image is scaled by its GLOBAL maximum (folded into a slot by the forward stem kernel), dY by its tensor's slot:
+//     partial sums of different tiles then share one scale and accumulate in the MFMA accumulators across tiles.
+// 42 MFMAs of 16 cycles per 32 pixels instead of 80 of 32 cycles.
+namespace {
+constexpr int GW_XT = 128, GW_P = 144, GW_ROWS = 10;          // tile width, staged pixels per window row (134 used), rows
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+}  // namespace
+
+__global__ __launch_bounds__(256) void stem_wgrad_f16_kernel(const float *__restrict__ img, const float *__restrict__ dy, int B,
+                                                             int H, int W, float *__restrict__ partial,
+                                                             const unsigned *__restrict__ img_amax,
+                                                             const unsigned *__restrict__ dy_amax) {
+    constexpr int PLANE_B = 3 * GW_ROWS * GW_P * 2;      // bytes of one piece
+    __shared__ __attribute__((aligned(16))) unsigned char win[2 * PLANE_B];
+    __shared__ float red[14 * 4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int ex = f16_scale_exp(amax_read(img_amax)), ed = f16_scale_exp(amax_read(dy_amax));
+    const float x_scale = exp2i(ex), d_scale = exp2i(ed), omul = exp2i(-ex) * exp2i(-ed);
+    // window row (c, r) of this lane in row group 0 / 1 (21 rows: 16 + 5; the other 11 lanes of group 1 read row 0)
+    int boff[2];
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+        const int cr = grp * 16 + j, c = cr / 7, r = cr - 7 * c;
+        boff[grp] = cr < 21 ? ((c * GW_ROWS + wave + r) * GW_P + 8 * g) * 2 : 0;
+    }
+    f32x4v acc[2][7], accm[2][7];
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+        for (int sft = 0; sft < 7; ++sft) { acc[grp][sft] = f32x4v{0.f, 0.f, 0.f, 0.f}; accm[grp][sft] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    const int va = (8 * g * 16 + j) * 4;            // dY lane offset: pixel 8g of the 32-pixel group, channel j
+    const int tiles_x = (W + GW_XT - 1) / GW_XT, tiles_y = (H + 3) / 4;
+    const int ntiles = B * tiles_y * tiles_x;
+    // staging plan: thread = pairs of horizontally adjacent window pixels (one packed dword per piece); the next tile's
+    // pixels are loaded before the MFMAs of the current one
+    constexpr int NPAIR = 3 * GW_ROWS * (GW_P / 2), NIW = (NPAIR + 255) / 256;
+    int w_c[NIW], w_rr[NIW], w_col[NIW];
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int e = tid + 256 * i, row = e / (GW_P / 2);
+        w_c[i] = e < NPAIR ? row / GW_ROWS : -1;
+        w_rr[i] = row % GW_ROWS;
+        w_col[i] = (e - row * (GW_P / 2)) * 2;
+    }
+    float pv[NIW][2];
+    auto fetch = [&](int tl) {
+        const int b = tl / (tiles_y * tiles_x), rem = tl - b * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * 4, x0 = (rem % tiles_x) * GW_XT;
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            const int gy = y0 - 3 + w_rr[i], gx = x0 - 3 + w_col[i];
+            const bool rok = w_c[i] >= 0 && gy >= 0 && gy < H;
+            const float *src = img + (((size_t)b * 3 + (rok ? w_c[i] : 0)) * H + (rok ? gy : 0)) * W;
+            pv[i][0] = (rok && gx >= 0 && gx < W) ? src[gx] : 0.f;
+            pv[i][1] = (rok && gx + 1 >= 0 && gx + 1 < W) ? src[gx + 1] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int b = tl / (tiles_y * tiles_x), rem = tl - b * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * 4, x0 = (rem % tiles_x) * GW_XT;
+        __syncthreads();                         // the previous tile's reads are done
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            if (w_c[i] < 0) continue;
+            const float s0 = pv[i][0] * x_scale, s1 = pv[i][1] * x_scale;
+            const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 hp = {h0, h1}, lp = {(_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1)};
+            const int off = ((w_c[i] * GW_ROWS + w_rr[i]) * GW_P + w_col[i]) * 2;
+            *reinterpret_cast<f16x2 *>(win + off) = hp;
+            *reinterpret_cast<f16x2 *>(win + PLANE_B + off) = lp;
+        }
+        __syncthreads();
+        if (tl + (int)gridDim.x < ntiles) fetch(tl + gridDim.x);
+        const int y = y0 + wave;
+        const __amdgpu_buffer_rsrc_t r_dy =
+            make_rsrc(dy + ((size_t)b * H + (y < H ? y : 0)) * W * 16, y < H ? (unsigned)(W * 16) * 4u : 0u);
+        float araw[GW_XT / 32][8];      // all four 32-pixel groups of the row up front: the loads of group G + 1.. are in
+                                        // flight under the MFMAs of group G (a first version loaded per group and waited)
+#pragma unroll
+        for (int G = 0; G < GW_XT / 32; ++G)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) araw[G][t] = buf_load1(r_dy, va + t * 64, (x0 + G * 32) * 64);      // beyond the row: zero
+#pragma unroll
+        for (int G = 0; G < GW_XT / 32; ++G) {
+            f16x8 ah, al;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float ds = araw[G][t] * d_scale;
+                const _Float16 hh = (_Float16)ds;
+                ah[t] = hh;
+                al[t] = (_Float16)(ds - (float)hh);
+            }
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                // pixels 8g .. 8g + 15 of the lane's window row, both pieces: w[piece][0..7] dwords of two pixels each
+                unsigned w[2][8];
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const u32x4 lo = *reinterpret_cast<const u32x4 *>(win + z * PLANE_B + boff[grp] + G * 64);
+                    const u32x4 hi = *reinterpret_cast<const u32x4 *>(win + z * PLANE_B + boff[grp] + G * 64 + 16);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { w[z][d] = lo[d]; w[z][4 + d] = hi[d]; }
+                }
+#pragma unroll
+                for (int sft = 0; sft < 7; ++sft) {
+                    u32x4 bz[2];
+#pragma unroll
+                    for (int z = 0; z < 2; ++z)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            bz[z][d] = (sft & 1) ? __builtin_amdgcn_alignbit(w[z][d + sft / 2 + 1], w[z][d + sft / 2], 16) : w[z][d + sft / 2];
+                    const f16x8 bh = __builtin_bit_cast(f16x8, bz[0]), bl = __builtin_bit_cast(f16x8, bz[1]);
+                    accm[grp][sft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, accm[grp][sft], 0, 0, 0);
+                    accm[grp][sft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, accm[grp][sft], 0, 0, 0);
+                    acc[grp][sft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[grp][sft], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // workgroup reduction, wave after wave (fixed order); D: row (out channel n) = 4*(lane>>4) + q, column = window row j
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+                for (int sft = 0; sft < 7; ++sft)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float *dst = &red[(grp * 7 + sft) * 4 + q][lane];
+                        const float v = (accm[grp][sft][q] + acc[grp][sft][q]) * omul;
+                        *dst = wv == 0 ? v : *dst + v;
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 14 * 4 * 64; e += 256) {
+        const int l = e & 63, idx = e >> 6;
+        const int q = idx & 3, tile = idx >> 2, grp = tile / 7, sft = tile - 7 * grp;
+        const int cr = grp * 16 + (l & 15), n = 4 * (l >> 4) + q;
+        if (cr < 21) partial[((size_t)blockIdx.x * 147 + cr * 7 + sft) * 16 + n] = red[idx][l];     // t = c*49 + r*7 + s
+    }
+}
+
+hipError_t launch_stem_wgrad_f16(const float *img, const float *dy, int B, int H, int W, float *partial, int nblocks,
+                                 const unsigned *img_amax, const unsigned *dy_amax, hipStream_t st) {
+    hipLaunchKernelGGL(stem_wgrad_f16_kernel, dim3(nblocks), dim3(256), 0, st, img, dy, B, H, W, partial, img_amax, dy_amax);
     return hipGetLastError();
 }
 
