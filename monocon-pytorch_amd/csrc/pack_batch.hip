@@ -39,8 +39,10 @@ __global__ __launch_bounds__(256) void weight_amax_batch_kernel(const PackJobDes
     }
     const PackJobDesc j = tab[lo];
     if (!j.amax || j.kind != 0) return;
-    // at most WA_BLOCKS workgroups per job take part (the grid is the pack kernel's): one atomic each on the job's word
-    constexpr int WA_BLOCKS = 8;
+    // at most WA_BLOCKS workgroups per job take part (the grid is the pack kernel's): one atomic each on the job's word.
+    // (8 made the 2.4 M weights of a 512 x 512 layer a 1 150-element serial walk per thread: 0.39 ms per step for 78 MB;
+    //  with 64 the pass is bandwidth-bound)
+    constexpr int WA_BLOCKS = 64;
     const int lb = blockIdx.x - j.block_begin, nb = j.nblocks < WA_BLOCKS ? j.nblocks : WA_BLOCKS;
     if (lb >= nb) return;
     const size_t total = (size_t)j.Cout * j.Cin * j.k * j.k;
