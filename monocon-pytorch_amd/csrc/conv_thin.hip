@@ -21,6 +21,7 @@
 //   * the next strip's global loads are issued before the MFMAs of the current one (register prefetch, as in the
 //     weight-gradient kernels).
 #include "conv_mfma.h"
+#include "train.h"
 
 #ifndef THIN_OCC
 #define THIN_OCC 2
@@ -256,6 +257,176 @@ bool conv_thin_ok(const ConvArgs &a, int ks, int stride) {
 hipError_t launch_conv_thin(const ConvArgs &a, hipStream_t st) {
     const int tiles = a.B * ((a.Hout + TR - 1) / TR);
     hipLaunchKernelGGL((conv_thin16_kernel<1>), dim3(tiles < 4096 ? tiles : 4096), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[n][c][r][s] = sum over pixels of dY[pixel][n] * X[pixel + (r - 1, s - 1)][c] of the same 16 -> 16 layer, mode 3, on
+// v_mfma_f32_16x16x32_f16 (K = 32 consecutive pixels of a row).  Replaces wgrad_small_kernel<1, 1> (wgrad_mfma.hip: fp32
+// 16x16x4, at its MFMA roof) when wgrad_thin_ok(); same partial layout [workgroup][tap][n][c] and the same split-K reduce.
+// Structure of stem_wgrad_f16_kernel (stem_f16.hip): persistent workgroups walk 4-row x 128-pixel tiles, a wave owns a row;
+//   * A (dY, NHWC): 8 consecutive pixels of a lane = 8 dword loads 64 bytes apart, scaled and split in registers;
+//   * B (X): the 6 x 130 halo window goes through LDS TRANSPOSED, [piece][channel][row][pixel] fp16 -- a lane (channel c,
+//     pixel octet g) reads the 16-pixel span of window row (row + r) once per piece (two aligned 16-byte reads) and forms
+//     the operands of the three tap columns by register shifts (s = 1: four v_alignbit);
+//   * both tensors are scaled by their global maxima (the slots of the fp16-split mode): one scale for all tiles, the MFMA
+//     accumulators run across a workgroup's tiles.
+namespace {
+constexpr int WT_XT = 128, WT_P = 152, WT_ROWS = 6;       // tile width, staged pixel slots per window row, window rows
+constexpr int WT_PLANE = 16 * WT_ROWS * WT_P * 2;         // bytes of one piece
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+}  // namespace
+
+__global__ __launch_bounds__(256) void wgrad_thin16_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    unsigned char *win = wsm;                                           // [2][16][6][WT_P] fp16
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(wsm + 2 * WT_PLANE);   // [9 * 4][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int ex = f16_scale_exp(amax_read(a.amax_x[0])), ed = f16_scale_exp(amax_read(a.amax_dy));
+    const float x_scale = exp2i(ex), d_scale = exp2i(ed), omul = exp2i(-ex) * exp2i(-ed);
+    const int H = a.Hout, W = a.Wout;
+
+    f32x4v acc[9], accm[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f}; accm[t] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    const int va = (8 * g * 16 + j) * 4;            // dY lane offset: pixel 8g of the 32-pixel group, channel j
+    const int boff = ((j * WT_ROWS + wave) * WT_P + 8 * g) * 2;      // window row (wave + r) adds r * WT_P * 2
+
+    // staging plan: item = (window row, pixel pair, channel quad), quad fastest
+    constexpr int NITEM = WT_ROWS * (WT_P / 2) * 4, NIW = (NITEM + 255) / 256;
+    int w_off[NIW], w_dst[NIW];                    // global byte offset relative to the window origin; LDS byte offset (< 0: none)
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int e = tid + 256 * i, c4 = e & 3, pr = (e >> 2) % (WT_P / 2), row = (e >> 2) / (WT_P / 2);
+        w_off[i] = ((row * a.Win + 2 * pr) * 16 + c4 * 4) * 4;
+        w_dst[i] = e < NITEM ? ((c4 * 4 * WT_ROWS + row) * WT_P + 2 * pr) * 2 : -1;
+    }
+    const int tiles_x = (W + WT_XT - 1) / WT_XT, tiles_y = (H + 3) / 4;
+    const int ntiles = a.B * tiles_y * tiles_x;
+    f32x4 pv[NIW][2];
+    auto fetch = [&](int tl) {
+        const int b = tl / (tiles_y * tiles_x), rem = tl - b * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * 4, x0 = (rem % tiles_x) * WT_XT;
+        const __amdgpu_buffer_rsrc_t r_x = make_rsrc(a.src[0].p + (size_t)b * a.Hin * a.Win * 16, (unsigned)(a.Hin * a.Win * 16) * 4u);
+        const int so = ((y0 - 1) * a.Win + x0 - 1) * 64;        // window origin (row y0 - 1, column x0 - 1); rows outside the
+                                                                 // image fall out of the descriptor, columns are tested
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            const int col = x0 - 1 + ((w_dst[i] >> 1) % WT_P);
+            const bool live = w_dst[i] >= 0;
+            pv[i][0] = buf_load4(r_x, (live && col >= 0 && col < a.Win) ? w_off[i] + so : BUF_OOB, 0);
+            pv[i][1] = buf_load4(r_x, (live && col + 1 >= 0 && col + 1 < a.Win) ? w_off[i] + so + 64 : BUF_OOB, 0);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int b = tl / (tiles_y * tiles_x), rem = tl - b * tiles_y * tiles_x;
+        const int y0 = (rem / tiles_x) * 4, x0 = (rem % tiles_x) * WT_XT;
+        __syncthreads();                         // the previous tile's reads are done
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            if (w_dst[i] < 0) continue;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const float s0 = pv[i][0][ch] * x_scale, s1 = pv[i][1][ch] * x_scale;
+                const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
+                const f16x2 hp = {h0, h1}, lp = {(_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1)};
+                const int off = w_dst[i] + ch * WT_ROWS * WT_P * 2;
+                *reinterpret_cast<f16x2 *>(win + off) = hp;
+                *reinterpret_cast<f16x2 *>(win + WT_PLANE + off) = lp;
+            }
+        }
+        __syncthreads();
+        if (tl + (int)gridDim.x < ntiles) fetch(tl + gridDim.x);
+        const int y = y0 + wave;
+        const __amdgpu_buffer_rsrc_t r_dy =
+            make_rsrc(a.dy + ((size_t)b * H + (y < H ? y : 0)) * W * a.dy_ld, y < H ? (unsigned)(W * a.dy_ld) * 4u : 0u);
+        float araw[WT_XT / 32][8];
+#pragma unroll
+        for (int G = 0; G < WT_XT / 32; ++G)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) araw[G][t] = buf_load1(r_dy, va + t * 64, (x0 + G * 32) * 64);      // beyond the row: zero
+#pragma unroll
+        for (int G = 0; G < WT_XT / 32; ++G) {
+            f16x8 ah, al;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float ds = araw[G][t] * d_scale;
+                const _Float16 hh = (_Float16)ds;
+                ah[t] = hh;
+                al[t] = (_Float16)(ds - (float)hh);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                unsigned w[2][8];
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    const unsigned char *p = win + z * WT_PLANE + boff + r * WT_P * 2 + G * 64;
+                    const u32x4 lo = *reinterpret_cast<const u32x4 *>(p), hi = *reinterpret_cast<const u32x4 *>(p + 16);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) { w[z][d] = lo[d]; w[z][4 + d] = hi[d]; }
+                }
+#pragma unroll
+                for (int sft = 0; sft < 3; ++sft) {
+                    u32x4 bz[2];
+#pragma unroll
+                    for (int z = 0; z < 2; ++z)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                            bz[z][d] = (sft & 1) ? __builtin_amdgcn_alignbit(w[z][d + sft / 2 + 1], w[z][d + sft / 2], 16) : w[z][d + sft / 2];
+                    const f16x8 bh = __builtin_bit_cast(f16x8, bz[0]), bl = __builtin_bit_cast(f16x8, bz[1]);
+                    const int t = r * 3 + sft;
+                    accm[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, accm[t], 0, 0, 0);
+                    accm[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, accm[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // workgroup reduction, wave after wave (fixed order).  D: row (n) = 4 * (lane >> 4) + q, column (c) = lane & 15
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float *dst = &red[t * 4 + q][lane];
+                    const float v = (accm[t][q] + acc[t][q]) * omul;
+                    *dst = wv == 0 ? v : *dst + v;
+                }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 9 * 4 * 64; e += 256) {
+        const int l = e & 63, idx = e >> 6;
+        const int q = idx & 3, t = idx >> 2;
+        const int n = 4 * (l >> 4) + q, c = l & 15;
+        a.partial[(((size_t)blockIdx.x * 9 + t) * 16 + n) * 16 + c] = red[idx][l];
+    }
+}
+
+bool wgrad_thin_ok(const WgradArgs &a, int ks, int stride) {
+#ifdef MC_NO_WGRAD_THIN
+    return false;
+#endif
+    return a.prec == 3 && a.small && ks == 3 && stride == 1 && a.nsrc == 1 && a.Cin == 16 && a.Cout == 16 && a.dy_ld == 16 &&
+           a.amax_x[0] && a.amax_dy && a.Wout % 4 == 0 && a.Hout == a.Hin && a.Wout == a.Win;
+}
+
+hipError_t launch_wgrad_thin(const WgradArgs &a, hipStream_t st) {
+    const size_t lds = 2 * WT_PLANE + 9 * 4 * 64 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_thin16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_thin16_kernel, dim3(a.ksplit), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

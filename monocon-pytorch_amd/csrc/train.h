@@ -187,5 +187,7 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
 bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride);
 hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int stride, int WN, int WC, hipStream_t st);
 int wgrad_bf16_patches(int prec);
+bool wgrad_thin_ok(const WgradArgs &a, int ks, int stride);        // conv_thin.hip: the 16 -> 16 layer on the fp16 pipe (mode 3)
+hipError_t launch_wgrad_thin(const WgradArgs &a, hipStream_t st);
 
 }  // namespace mc

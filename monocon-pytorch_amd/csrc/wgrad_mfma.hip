@@ -427,7 +427,9 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
     prof_last = {2, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks,
                  4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.B * a.Hout * a.Wout * a.Cout + (double)ks * ks * a.Cin * a.Cout)};
     hipError_t e = hipErrorInvalidValue;
-    if (a.small) {
+    if (a.small && wgrad_thin_ok(a, ks, stride)) {
+        e = launch_wgrad_thin(a, st);
+    } else if (a.small) {
         if (stride == 1 && a.Cout == 16) hipLaunchKernelGGL((wgrad_small_kernel<1, 1>), dim3(a.ksplit), dim3(256), 0, st, a);
         else if (stride == 1) hipLaunchKernelGGL((wgrad_small_kernel<1, 2>), dim3(a.ksplit), dim3(256), 0, st, a);
         else if (a.Cout == 16) hipLaunchKernelGGL((wgrad_small_kernel<2, 1>), dim3(a.ksplit), dim3(256), 0, st, a);

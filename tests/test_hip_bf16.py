@@ -254,6 +254,29 @@ def test_thin16_conv_on_the_fp16_pipe(case):
     assert rel_err(got, base) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(2, 16, 128, 1.0, 1.0), (1, 19, 48, 1.0, 1.0), (1, 8, 144, 1e-10, 3e3), (1, 5, 260, 50.0, 1e-6), (3, 4, 8, 1.0, 1.0)],
+                         ids=["one_tile_wide", "ragged", "tiny_x_large_dy", "three_tiles", "smaller_than_a_tile"])
+def test_thin16_wgrad_on_the_fp16_pipe(case):
+    """csrc/conv_thin.hip wgrad_thin16_kernel (mode 3): weight gradient of the 16 -> 16 3x3 layer vs autograd in fp64 at the
+    fp32 kernels' gate (5e-6), and within 2e-6 of the fp32 row kernel it replaces"""
+    from hipmonocon.engine import Engine
+    B, H, W, xmag, dmag = case
+    x = rnd(1500 + H, "x", (B, 16, H, W)) * xmag
+    dy = rnd(1500 + H, "dy", (B, 16, H, W)) * dmag
+    w = torch.zeros(16, 16, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, 1, 1).backward(dy.double())
+    eng = Engine()
+    try:
+        eng.set_precision(3)
+        got = eng.op_conv_wgrad([nhwc(x).cuda()], nhwc(dy).cuda(), 3, 1).cpu()
+        eng.set_precision(0)
+        base = eng.op_conv_wgrad([nhwc(x).cuda()], nhwc(dy).cuda(), 3, 1).cpu()
+    finally:
+        eng.close()
+    assert rel_err(got, w.grad) < 5e-6, rel_err(got, w.grad)
+    assert rel_err(got, base) < 2e-6
+
+
 @pytest.mark.parametrize("case", [(2, 16, 64, 1.0), (1, 33, 65, 1.0), (1, 8, 200, 1e-9), (1, 21, 130, 2e4), (1, 5, 7, 1.0)],
                          ids=["one_tile", "ragged_33x65", "tiny_values_4_tiles", "large_values", "smaller_than_the_halo"])
 def test_stem_on_the_fp16_pipe(case):
