@@ -95,6 +95,16 @@ __global__ __launch_bounds__(256, THIN_OCC) void conv_thin16_kernel(const ConvAr
     const bool do_stats = a.stats != nullptr, has_res = a.res != nullptr;
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
     float vmax = 0.f;
+    // backward-statistics mode (ConvArgs::bm_y, as in conv_epilogue of conv_mfma.h): this launch completes the gradient of a
+    // map; mask it with that map's ReLU and leave (sum d, sum d * y) per output row instead of (sum, sum of squares)
+    const bool bm = a.bm_y != nullptr;
+    const int bm_relu = a.bm_relu;
+    float ma[NTN], mb[NTN];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        ma[nt] = (bm && bm_relu == 2 && nok[nt]) ? a.bm_a[nt * 16 + li] : 0.f;
+        mb[nt] = (bm && bm_relu == 2 && nok[nt]) ? a.bm_b[nt * 16 + li] : 0.f;
+    }
 
     // ---- staging plan: item e = (row, pixel, channel quad), quad fastest (4 lanes = the 64 bytes of one pixel).
     //      s_off: byte offset of the item relative to the tile's first halo pixel; rows outside the image need no test
@@ -178,6 +188,22 @@ __global__ __launch_bounds__(256, THIN_OCC) void conv_thin16_kernel(const ConvAr
                     f32x4v acc[NTN], accm[NTN];
 #pragma unroll
                     for (int nt = 0; nt < NTN; ++nt) { acc[nt] = f32x4v{0.f, 0.f, 0.f, 0.f}; accm[nt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+                    // backward-statistics mode: the y (and z) values of this tile's 64 outputs, requested BEFORE the MFMAs
+                    // (loaded in the epilogue they cost one memory latency per tile: +1 ms per launch, measured)
+                    const bool rok = oy0 + trow < a.Hout;
+                    float ybm[NTN][4], zbm[NTN][4];
+                    if (bm) {
+#pragma unroll
+                        for (int nt = 0; nt < NTN; ++nt) {
+                            const size_t at0 = (((size_t)img * a.Hout + (rok ? oy0 + trow : 0)) * a.Wout + x0 + 4 * kq) * a.Cout + nt * 16 + li;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool ld = rok && nok[nt];
+                                ybm[nt][e] = ld ? a.bm_y[at0 + (size_t)e * a.Cout] : 0.f;
+                                zbm[nt][e] = (ld && bm_relu == 1) ? a.bm_z[at0 + (size_t)e * a.Cout] : 1.f;
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int s = 0; s < 5; ++s) {
                         const int tap = 2 * s + tsel;       // (lane-dependent only through tsel)
@@ -210,7 +236,15 @@ __global__ __launch_bounds__(256, THIN_OCC) void conv_thin16_kernel(const ConvAr
                         for (int e = 0; e < 4; ++e) {
                             float v = ((accm[nt][e] + acc[nt][e]) * omul) * sc[nt] + bi[nt];
                             if (has_res) v += rv[e];
-                            if (do_stats) {
+                            if (bm) {
+                                if (rok && nok[nt]) {
+                                    const float yv = ybm[nt][e];
+                                    const bool on = bm_relu == 0 || (bm_relu == 1 ? zbm[nt][e] > 0.f : fmaf(yv, ma[nt], mb[nt]) > 0.f);
+                                    v = on ? v : 0.f;
+                                    ssum[q][nt] += v;
+                                    ssq[q][nt] = fmaf(v, yv, ssq[q][nt]);
+                                }
+                            } else if (do_stats) {
                                 const float d = v - sh[nt];
                                 ssum[q][nt] += d;
                                 ssq[q][nt] += d * d;

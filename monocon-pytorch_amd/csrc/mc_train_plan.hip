@@ -425,7 +425,8 @@ struct TB {   // train plan builder
         ConvArgs *dp = &ts->dgrads.back();
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(*dp, ks, 1, st)); return 0; });
         sn.ginit = true;
-        sn.last_conv = d.cfg == CFG_SMALL ? nullptr : dp;
+        // (the fp32 row kernel has no backward-statistics epilogue; its fp16-pipe replacement for 16 -> 16 layers has)
+        sn.last_conv = (d.cfg == CFG_SMALL && !conv_thin_ok(d, ks, 1)) ? nullptr : dp;
     }
 
     void emit_wgrad(const std::vector<int> &srcs, const Tensor &dy, int dy_ld, int Cout, int ks, int stride, float *dw) {
@@ -480,7 +481,7 @@ struct TB {   // train plan builder
         if (lc && lc->out == zn.g && lc->Cout == C && lc->out_ld == C && lc->Hout == r.y.H && lc->Wout == r.y.W && !lc->stats) {
             // the gradient of this map was completed by a data-gradient conv: its epilogue masks it and emits the
             // (sum d, sum d*y) partials per 4x8 patch -- no reduction pass, and the affine pass needs no mask
-            const int ppi = ((r.y.W + 7) / 8) * ((r.y.H + 3) / 4), nbp = B * ppi, cstride = lc->CoutP;
+            const int ppi = conv_chunks_per_image(lc->cfg, r.y.H, r.y.W), nbp = B * ppi, cstride = lc->CoutP;   // per 4x8 patch / per row
             float *partial = alloc((size_t)nbp * cstride * 2);
             lc->stats = partial;
             lc->bm_y = yp; lc->bm_z = zp; lc->bm_a = fa; lc->bm_b = fb; lc->bm_relu = relu;
