@@ -263,6 +263,35 @@ def test_query_workspace_predicts_what_the_plans_allocate(golden_sd):
     assert 26e9 < q32 < 34e9, q32      # (45.3 GB before round 3: dY in place over dZ, recycled gradient maps)
 
 
+def test_recycled_gradient_buffers_do_not_change_a_bit(golden_sd, monkeypatch):
+    """round 3: dY in place over dZ + gradient maps from a pool (a buffer last read by the weight-gradient stream is waited for
+    before its next first write).  Same kernels, other addresses: losses and every gradient must be bit-identical to the plan
+    with one private buffer per map (MONOCON_HIP_GRAD_POOL=0), also with immediate recycling (..._COOL=0, the tightest
+    cross-stream coupling), over several steps; and the pooled plan must be the smaller one."""
+    batch = to_cuda(synth.make_batch(GOLDEN_SEED + 41, 3, 96, 160))
+
+    def run(pool, cool):
+        monkeypatch.setenv("MONOCON_HIP_GRAD_POOL", pool)
+        monkeypatch.setenv("MONOCON_HIP_GRAD_POOL_COOL", cool)
+        m = build(golden_sd)
+        outs = []
+        for _ in range(3):
+            for p in m.parameters():
+                p.grad = None
+            _, loss = m(batch)
+            sum(loss.values()).backward()
+            torch.cuda.synchronize()
+            outs.append((torch.stack([v.detach() for v in loss.values()]).clone(),
+                         torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).clone()))
+        return outs, m._rt.engine.workspace_bytes()
+    private, ws_private = run("0", "0")
+    for cool in ("0", "2"):
+        pooled, ws_pooled = run("1", cool)
+        for (la, ga), (lb, gb) in zip(private, pooled):
+            assert torch.equal(la, lb) and torch.equal(ga, gb), cool
+        assert ws_pooled < ws_private
+
+
 # ------------------------------------------------------------------------------------- guards
 def test_backward_of_a_stale_forward_raises(golden_sd):
     from hipmonocon.lib import MonoconHipError
