@@ -71,6 +71,12 @@ def parse():
                     help="precision mode of the headline value: all three keep fp32 values and meet the fp32 parity tolerances")
     ap.add_argument("--realistic-steps", type=int, default=6,
                     help="steps of the realistic_loop leg (fresh labels + H2D of uint8 frames + loss.item() per step); 0 = skip")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: if the handle cannot build its own RCCL communicator, fall back to torch.distributed's all_reduce "
+                         "(also RCCL) instead of failing; the line then says path = torch")
+    ap.add_argument("--full-json", default=None,
+                    help="where the verbose report (every leg with its prose notes) goes; default gpurun_out/bench_full.json when "
+                         "that directory exists, else bench_full.json beside this file.  stdout carries ONE compact line")
     ap.add_argument("--no-extra-modes", action="store_true",
                     help="skip the fp32_emulated / mixed_precision legs (profiles/collect.sh: keeps the kernel trace on the headline path)")
     return ap.parse_args()
@@ -163,9 +169,9 @@ def cpu_baseline(sd, height, width, budget_s):
         m2, n2 = timed(lambda: O.forward(sd, img2), budget_s / 4)
         legs["eval_forward_b2"] = {"images_per_sec": round(2 / m2, 3), "s_per_run": round(m2, 3), "runs": n2}
         img32 = img2.repeat(16, 1, 1, 1)
-        m32, n32 = timed(lambda: O.forward(sd, img32), 0.0, min_runs=1, max_runs=1, warm=False)   # ~12 s: one run, no warm-up
+        m32, n32 = timed(lambda: O.forward(sd, img32), 0.0, min_runs=3, max_runs=3, warm=True)   # warm-up 1, median of 3
         legs["eval_forward_b32"] = {"images_per_sec": round(32 / m32, 3), "s_per_run": round(m32, 3), "runs": n32,
-                                    "note": "single un-warmed run (the B=2 leg just exercised the same kernels)"}
+                                    "note": "1 warm-up + median of 3"}
         K, DB = 100, 64
         d = {k: torch.from_numpy(v) for k, v in synth.make_decode_inputs(77, DB, height // 4, width // 4, topk=K).items()}
         P2 = np.stack([synth.KITTI_P2] * DB)
@@ -173,6 +179,30 @@ def cpu_baseline(sd, height, width, budget_s):
         legs["decode_b64_k100"] = {"images_per_sec": round(DB / md, 1), "ms_per_batch": round(md * 1e3, 2), "runs": nd}
     out["legs"] = legs
     return out
+
+
+def input_feed_capacity(train_img_per_s_per_gpu, seconds=4.0):
+    """SURVEY 8f-4, one measurement: how fast ONE DataLoader worker produces samples on this host -- PNG decode (PIL) +
+    label file + calibration + filter rules + Normalize / Pad / ToTensor on the mini KITTI tree of tests/golden (real
+    375x1242 frames) -- against what the GPUs consume.  Deterministic transforms only (the random train augmentations
+    are host-side numpy work on top, not part of SURVEY 8's path)."""
+    mini = os.path.join(REPO, "tests", "golden", "kitti_mini")
+    if not os.path.isdir(mini):
+        return None
+    from dataset.monocon_dataset import MonoConDataset
+    ds = MonoConDataset(mini, "val")
+    ds[0]
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        ds[n % len(ds)]
+        n += 1
+    per_worker = n / (time.perf_counter() - t0)
+    need = lambda g: int(np.ceil(g * train_img_per_s_per_gpu / per_worker))       # noqa: E731
+    return {"per_worker_img_per_s": round(per_worker, 1), "samples": n,
+            "workers_needed_1gpu": need(1), "workers_needed_8gpu": need(8),
+            "host_logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
+            "note": "one process: PIL decode of a 375x1242 PNG + labels + Normalize/Pad/ToTensor (float32 CHW out); the "
+                    "mc_preprocess path (uint8 HWC to the device, normalise on the GPU) leaves only decode + labels on the host"}
 
 
 _T0 = time.perf_counter()
@@ -211,6 +241,73 @@ def _traffic(family):
         return None, None, {}
 
 
+def _num(d, *path, nd=3):
+    for k in path:
+        if not isinstance(d, dict) or k not in d or d[k] is None:
+            return None
+        d = d[k]
+    return round(d, nd) if isinstance(d, float) else d
+
+
+def compact_line(out, full_path):
+    """the contract keys + one short numeric block per BASELINE config / precision leg (no prose)"""
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "world_size", "collective_backend", "steps", "warmup", "ms_per_step",
+                             "higher_is_better", "scaling", "vs_baseline", "data") if k in out}
+    c["dtype"] = "f32 (%s)" % out["config"]["precision_mode"]
+    c["config"] = {"workload": "train step B=%d/GPU 3x384x1280 (configs[2] shape, fp32 values, mode %s)"
+                               % (out["config"]["global_batch"] // max(out["n_gpus"], 1), out["config"]["precision_mode"]),
+                   "global_batch": out["config"]["global_batch"], "parallelism": out["config"]["parallelism"],
+                   "precision_mode": out["config"]["precision_mode"]}
+    r = out.get("roofline") or {}
+    c["roofline"] = {"bound": r.get("bound"), "kernel": "mc::conv_bf16_kernel" if "bf16" in str(r.get("kernel")) else str(r.get("kernel"))[:40],
+                     "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": "TFLOP/s", "frac": r.get("frac"),
+                     "traffic": r.get("traffic"), "traffic_unit": "MB/launch (PMC)",
+                     "alg_mb_per_launch": r.get("algorithmic_mb_per_launch"), "avg_launch_ms": r.get("avg_launch_ms"),
+                     "mfma_per_mac": 3 if out["config"]["precision_mode"] == "f16x2" else (6 if out["config"]["precision_mode"] == "bf16x3" else 1),
+                     "alg_tflops_fp32eq": r.get("algorithmic_tflops_fp32_equivalent"),
+                     "mfma_busy": _num(r, "pmc", "mfma_busy"), "clock_ghz": _num(r, "pmc", "clock_ghz"),
+                     "conv_ms": r.get("conv_ms_per_step"), "wgrad_ms": _num(r, "wgrad", "ms_per_step"), "wgrad_frac": _num(r, "wgrad", "frac", nd=4),
+                     "other_ms": r.get("other_ms_per_step")}
+    c["workspace_gb"] = out.get("workspace_gb")
+    f = out.get("forward_only")
+    if f:      # BASELINE configs[1]
+        c["forward_only"] = {"img_s": f["images_per_sec"], "ms": f["ms_per_step"], "conv_ms": _num(f, "roofline", "conv_ms"),
+                             "other_ms": _num(f, "roofline", "other_ms"), "mfma_frac": _num(f, "roofline", "frac", nd=4),
+                             "hbm_frac": f.get("whole_forward_frac_of_hbm_peak"), "hbm_frac_max_attainable": f.get("max_attainable_hbm_frac")}
+    modes = {}
+    for key, tag in (("native_fp32", "fp32"), ("fp32_emulated_bf16x3", "bf16x3"), ("fp32_emulated_f16x2", "f16x2"), ("mixed_precision", "bf16")):
+        b = out.get(key)
+        if b:
+            modes[tag] = {"train_img_s": _num(b, "train", "images_per_sec"), "train_ms": _num(b, "train", "ms_per_step"),
+                          "fwd_img_s": _num(b, "forward", "images_per_sec"), "fwd_ms": _num(b, "forward", "ms_per_step"),
+                          "conv_frac": _num(b, "train", "roofline", "frac", nd=4), "fwd_hbm_frac": _num(b, "forward", "whole_forward_frac_of_hbm_peak", nd=4)}
+    if modes:
+        c["modes"] = modes
+    if out.get("realistic_loop"):
+        c["realistic_loop"] = {"img_s": out["realistic_loop"]["images_per_sec"], "ms": out["realistic_loop"]["ms_per_step"]}
+    if out.get("input_feed"):
+        c["input_feed"] = {k: v for k, v in out["input_feed"].items() if k != "note"}
+    if out.get("decode_only"):     # BASELINE configs[4]
+        c["decode_only"] = {"img_s": out["decode_only"]["images_per_sec"], "ms_per_batch": out["decode_only"]["ms_per_batch"], "batch": 64, "topk": 100}
+    if out.get("kitti_eval_overlaps"):
+        c["kitti_eval_overlaps"] = {k: out["kitti_eval_overlaps"][k] for k in ("bev_ms", "box3d_ms")}
+    if out.get("power_ceiling"):
+        c["power_ceiling"] = out["power_ceiling"]
+    for k in ("comm_world", "n_collectives", "comm_path", "per_rank_ms_per_step", "per_rank_exposed_allreduce_ms"):
+        if k in out:
+            c[k] = out[k]
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "sample": "oracle train step B=2 3x384x1280 fp32, median of runs in %.0f s" % 12,
+                             "cpu": cb.get("cpu"),
+                             "eval_fwd_b2_img_s": _num(cb, "legs", "eval_forward_b2", "images_per_sec"),
+                             "eval_fwd_b32_img_s": _num(cb, "legs", "eval_forward_b32", "images_per_sec"),
+                             "decode_b64_img_s": _num(cb, "legs", "decode_b64_k100", "images_per_sec")}
+    c["full_report"] = os.path.relpath(full_path, REPO) if full_path else None
+    return c
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,9 +338,9 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # a measurement must not die on the communicator: if the handle cannot build its own RCCL communicator on this
-        # node, fall back to torch.distributed's all-reduce (also RCCL) -- `multi_gpu.comm` in the JSON says which ran
-        os.environ.setdefault("MONOCON_HIP_DP_FALLBACK", "1")
+        # the exchange path is part of what is measured: without --allow-fallback a communicator the handle cannot build
+        # is a hard error on every rank (non-zero exit), not a silent switch to torch.distributed's all_reduce
+        os.environ["MONOCON_HIP_DP_FALLBACK"] = "1" if args.allow_fallback else "0"
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -566,14 +663,38 @@ def main():
             out["realistic_loop"] = real
         if dist_on:
             out["multi_gpu"] = {k: head[k] for k in ("per_rank_ms_per_step", "per_rank_exposed_allreduce_ms", "comm") if k in head}
+            comm = head.get("comm") or {}
+            out["comm_world"] = comm.get("world", 0)                         # ranks in the handle's own RCCL communicator (0: none)
+            out["n_collectives"] = comm.get("collectives_per_exchange", 1 if "path" in comm else None)
+            out["comm_path"] = "rccl (handle-owned communicator, overlapped buckets)" if comm.get("world") else "torch"
+            out["per_rank_ms_per_step"] = head.get("per_rank_ms_per_step")
+            out["per_rank_exposed_allreduce_ms"] = head.get("per_rank_exposed_allreduce_ms")
         if dec is not None:
             out["decode_only"] = dec
             out["kitti_eval_overlaps"] = evl
         if not args.no_cpu_baseline:
             _phase("CPU baseline (oracle: train step B=2, eval forward B=2 / B=32, decode B=64)")
             out["cpu_baseline"] = cpu_baseline(sd, H, W, args.cpu_seconds)
+        if real is not None:
+            _phase("input feed capacity (one DataLoader worker on the mini KITTI tree)")
+            try:
+                out["input_feed"] = input_feed_capacity(rep["images_per_sec"] / world)
+            except Exception as e:      # noqa: BLE001  (a host-side side figure must not kill the measurement)
+                out["input_feed"] = {"error": str(e)[:200]}
         _phase("done")
-        print(json.dumps(out), flush=True)
+        # ---- the verbose report (every leg, with its prose) goes to a file and to stderr; stdout carries ONE compact,
+        #      numbers-only line so that every BASELINE config survives a log tail
+        full_path = args.full_json
+        if full_path is None:
+            d = os.path.join(REPO, "gpurun_out")
+            full_path = os.path.join(d if os.path.isdir(d) else REPO, "bench_full.json")
+        try:
+            with open(full_path, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            full_path = None
+        print("[bench full report] " + json.dumps(out), file=sys.stderr, flush=True)
+        print(json.dumps(compact_line(out, full_path)), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

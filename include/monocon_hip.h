@@ -204,6 +204,17 @@ int mc_comm_info(mc_handle *h, int *rank, int *world, int *overlap, int *n_colle
                  char *lib_path, int lib_path_len);
 int mc_comm_exposed_ms(mc_handle *h, float *ms);
 int mc_allreduce_grads(mc_handle *h, void *stream);
+/* Start-up of a data-parallel job (no reference counterpart: README.MD:11,15).  The workgroup shape of every
+ * convolution is chosen by timing when a plan is built; ranks that tune concurrently can pick different shapes (results
+ * stay bit-identical, step times do not).  So rank 0 builds its plan first -- mc_build_train_plan builds and tunes the
+ * train plan of a shape without running a kernel of the step or a collective -- exports the table (mc_tune_export: ints,
+ * per entry [key length, key..., shape id]; buf == NULL returns the size in *n_ints), and every other rank imports it
+ * (mc_tune_import, returns the number of entries or -1) before it builds its own plan.
+ * mc_comm_init runs ncclCommInitRank under a watchdog (MONOCON_HIP_COMM_TIMEOUT_S, default 60): if not every rank
+ * arrives, the call fails with a message naming this rank instead of hanging. */
+int mc_build_train_plan(mc_handle *h, int B, int H, int W);
+int mc_tune_export(mc_handle *h, int *buf, int cap, int *n_ints);
+int mc_tune_import(mc_handle *h, const int *buf, int n_ints);
 
 /* ---- optimizer ---------------------------------------------------------------------------
  * Replaces clip_grad_norm_(max_norm, L2) + torch.optim.AdamW.step (engine/monocon_engine.py:94-102;
@@ -289,7 +300,8 @@ int mc_box3d_overlap(mc_handle *h, const double *boxes, const double *query_boxe
  * boxes were concatenated, eval.py:347-422): overlaps is the part's (sum dt_nums, sum gt_nums) matrix, gt_datas
  * (sum gt, 5) = bbox + alpha, dt_datas (sum dt, 6) = bbox + alpha + score, dontcares (sum dc, 4), ignore flags as
  * produced by clean_data (eval.py:35-87).  mode 0: scores of the true positives without false-positive accounting,
- * appended to scores_out (capacity sum gt_nums) -- the first pass of eval_class (eval.py:490-505); mode 1:
+ * appended to scores_out (capacity sum gt_nums) -- the first pass of eval_class (eval.py:490-505) -- and, when pr is
+ * not NULL, pr[0..3] += that pass's own (tp, 0, fn, 0); mode 1:
  * fused_compute_statistics (eval.py:297-344), pr[n_thresholds][4] += (tp, fp, fn, similarity).  Returns 0, or -1 on a
  * bad argument. */
 int mc_kitti_image_overlap(const double *boxes, long long N, const double *query_boxes, long long K, int criterion,

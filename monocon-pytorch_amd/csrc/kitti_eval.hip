@@ -361,7 +361,8 @@ int mc_kitti_image_overlap(const double *boxes, long long N, const double *query
 // One "part" (a run of consecutive frames whose boxes were concatenated): for every frame the block
 // overlaps[dt0 : dt0 + dt_nums[f], gt0 : gt0 + gt_nums[f]] of the part's (sum dt, sum gt) matrix.
 //   mode 0: scores of the true positives at threshold 0 without false-positive accounting (the first pass of eval_class,
-//           eval.py:490-505) appended to scores_out (capacity = sum gt) -> *n_scores
+//           eval.py:490-505) appended to scores_out (capacity = sum gt) -> *n_scores; pr (optional, [4]) += that pass's own
+//           (tp, 0, fn, 0)
 //   mode 1: tp / fp / fn / similarity accumulated into pr[n_thresholds][4] for every score threshold (eval.py:297-344)
 int mc_kitti_statistics_part(int mode, const double *overlaps, long long n_frames, const long long *gt_nums,
                              const long long *dt_nums, const long long *dc_nums, const double *gt_datas,
@@ -383,7 +384,11 @@ int mc_kitti_statistics_part(int mode, const double *overlaps, long long n_frame
         const double *dc = dontcares ? dontcares + c0 * 4 : nullptr;
         const long long *ig = ignored_gts ? ignored_gts + g0 : nullptr, *id = ignored_dets ? ignored_dets + d0 : nullptr;
         if (mode == 0) {
-            image_statistics(ov, tot_gt, gd, ng, dd, nd, ig, id, dc, nc, metric, min_overlap, 0.0, false, false, &scores);
+            const StatOut o = image_statistics(ov, tot_gt, gd, ng, dd, nd, ig, id, dc, nc, metric, min_overlap, 0.0, false, false, &scores);
+            if (pr) {      // optional: the pass's own (tp, fp = 0, fn) -- a valid GT matched to an ignored detection is NEITHER
+                pr[0] += (double)o.tp; pr[1] += (double)o.fp; pr[2] += (double)o.fn;
+                if (o.similarity != -1.0) pr[3] += o.similarity;
+            }
         } else {
             for (long long t = 0; t < n_thresholds; ++t) {
                 const StatOut o = image_statistics(ov, tot_gt, gd, ng, dd, nd, ig, id, dc, nc, metric, min_overlap,

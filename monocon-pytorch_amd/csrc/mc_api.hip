@@ -1118,6 +1118,43 @@ int mc_set_conv_cfg(mc_handle *h, int cfg) {
     return 0;
 }
 
+// The autotuned workgroup shapes as a flat int table: per entry [key length, key..., shape id].  Data-parallel ranks exchange
+// it (rank 0 tunes, the others import before they build their plans) so that every replica runs the SAME tilings: the
+// timing-based choice can differ between ranks that tune concurrently -- results would stay bit-identical (the shapes
+// do not change the arithmetic), the step times would not.
+int mc_tune_export(mc_handle *h, int *buf, int cap, int *n_ints) {
+    if (!h || !n_ints) return -1;
+    int n = 0;
+    for (auto &kv : h->tuned) n += 2 + (int)kv.first.size();
+    *n_ints = n;
+    if (!buf) return 0;                       // size query
+    if (cap < n) return fail(h, "mc_tune_export: buffer of %d ints, %d needed", cap, n);
+    int o = 0;
+    for (auto &kv : h->tuned) {
+        buf[o++] = (int)kv.first.size();
+        for (int v : kv.first) buf[o++] = v;
+        buf[o++] = kv.second;
+    }
+    return 0;
+}
+
+int mc_tune_import(mc_handle *h, const int *buf, int n_ints) {
+    if (!h || (!buf && n_ints > 0)) return -1;
+    int o = 0, added = 0;
+    while (o < n_ints) {
+        const int kl = buf[o++];
+        if (kl < 10 || kl > 16 || o + kl + 1 > n_ints) return fail(h, "mc_tune_import: malformed table at int %d", o - 1);
+        std::vector<int> key(buf + o, buf + o + kl);
+        o += kl;
+        const int cfg = buf[o++];
+        if (cfg != CFG_SMALL && (cfg <= 0 || (cfg & 15) >= CFG_COUNT || (cfg & ~(15 | CFG_WS))))
+            return fail(h, "mc_tune_import: unknown shape id %d", cfg);
+        h->tuned[key] = cfg;
+        ++added;
+    }
+    return added;
+}
+
 int mc_set_precision(mc_handle *h, int mode) {
     if (!h) return -1;
     if (mode < 0 || mode > 3)

@@ -19,7 +19,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "mc_internal.h"
 
@@ -229,8 +234,33 @@ int mc_comm_init(mc_handle *h, int rank, int world, const void *id128) {
     c->rank = rank; c->world = world;
     UniqueId id;
     std::memcpy(&id, id128, sizeof id);
-    const int rc = g_rccl.comm_init_rank(&c->comm, world, id, rank);
-    if (rc) return fail(h, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_err(rc));
+    // ncclCommInitRank blocks until ALL ranks have joined: a rank that died on its way here (or never got the id) would
+    // leave the others waiting forever, with nothing on the screen.  The call therefore runs on a helper thread under a
+    // watchdog (MONOCON_HIP_COMM_TIMEOUT_S, default 60 s): on expiry this rank reports who it is and fails -- the
+    // binding then raises / falls back on every rank together.  (The helper stays blocked inside RCCL; it holds no
+    // reference to the handle.)
+    struct Pending { std::mutex m; std::condition_variable cv; bool done = false; int rc = 0; Comm comm = nullptr; };
+    auto pend = std::make_shared<Pending>();
+    const int device = h->device;
+    const CommInitRankFn init_fn = g_rccl.comm_init_rank;
+    std::thread([pend, device, init_fn, world, id, rank] {
+        (void)hipSetDevice(device);
+        Comm cm = nullptr;
+        const int r = init_fn(&cm, world, id, rank);
+        std::lock_guard<std::mutex> lk(pend->m);
+        pend->rc = r; pend->comm = cm; pend->done = true;
+        pend->cv.notify_all();
+    }).detach();
+    double timeout_s = 60.0;
+    if (const char *e = std::getenv("MONOCON_HIP_COMM_TIMEOUT_S")) timeout_s = std::atof(e) > 0 ? std::atof(e) : timeout_s;
+    {
+        std::unique_lock<std::mutex> lk(pend->m);
+        if (!pend->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return pend->done; }))
+            return fail(h, "mc_comm_init: rank %d of %d still waits in ncclCommInitRank after %.0f s -- not every rank reached it "
+                           "(device %d; MONOCON_HIP_COMM_TIMEOUT_S changes the limit)", rank, world, timeout_s, device);
+        c->comm = pend->comm;
+        if (pend->rc) return fail(h, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_err(pend->rc));
+    }
     HIPCHK(h, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&c->ready2, hipEventDisableTiming));

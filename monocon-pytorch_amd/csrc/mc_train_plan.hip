@@ -874,6 +874,35 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
 // ====================================================================================== C ABI
 extern "C" {
 
+// the train plan of this shape (built -- and its convolution shapes autotuned -- on first use)
+static TrainState *ensure_train_plan(mc_handle *h, int B, int H, int W, bool head_only) {
+    TrainState *ts = h->train;
+    if (!ts || ts->B != B || ts->H != H || ts->W != W || ts->bind_gen != h->bind_gen || ts->head_only != head_only) {
+        if (ts && h->train_free) h->train_free(ts);
+        h->train = nullptr;
+        h->tgt_arena = h->dp_arena = nullptr;
+        h->train_bytes = 0;
+        h->tgt_arena_bytes = h->dp_arena_bytes = 0;
+        ts = build_train(h, B, H, W, head_only);
+        if (!ts) return nullptr;
+        h->train = ts;
+        h->train_bytes = ts->bytes;
+        h->train_free = train_free;
+    }
+    return ts;
+}
+
+// Build (and autotune) the train plan of a shape WITHOUT running it: no kernel of the step, no collective.  Data-parallel
+// start-up: rank 0 calls this, exports its tune table (mc_tune_export), the other ranks import it and build theirs.
+int mc_build_train_plan(mc_handle *h, int B, int H, int W) {
+    if (!h) return -1;
+    if (B < 2 || B > 64) return fail(h, "mc_build_train_plan: batch %d (2..64 per GPU)", B);
+    if (H < 32 || W < 32 || (H % 32) || (W % 32)) return fail(h, "mc_build_train_plan: H, W must be multiples of 32");
+    if (h->packed_groups != 7) return fail(h, "mc_build_train_plan: bind all parameters and call mc_pack_params first");
+    HIPCHK(h, hipSetDevice(h->device));
+    return ensure_train_plan(h, B, H, W, false) ? 0 : -1;
+}
+
 static int forward_train_impl(mc_handle *h, const float *img, const mc_labels *labels, int B, int H, int W, int max_objs,
                               float *const preds[MC_NUM_PREDS], float *losses, void *stream, bool head_only) {
     if (!h) return -1;
@@ -886,19 +915,8 @@ static int forward_train_impl(mc_handle *h, const float *img, const mc_labels *l
         return fail(h, "%s: bind all %sparameters and call mc_pack_params first", fn, head_only ? "head. " : "");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    TrainState *ts = h->train;
-    if (!ts || ts->B != B || ts->H != H || ts->W != W || ts->bind_gen != h->bind_gen || ts->head_only != head_only) {
-        if (ts && h->train_free) h->train_free(ts);
-        h->train = nullptr;
-        h->tgt_arena = h->dp_arena = nullptr;
-        h->train_bytes = 0;
-        h->tgt_arena_bytes = h->dp_arena_bytes = 0;
-        ts = build_train(h, B, H, W, head_only);
-        if (!ts) return -1;
-        h->train = ts;
-        h->train_bytes = ts->bytes;
-        h->train_free = train_free;
-    }
+    TrainState *ts = ensure_train_plan(h, B, H, W, head_only);
+    if (!ts) return -1;
     ts->img = img; ts->feat_ext = img; ts->labels = *labels; ts->losses = losses; ts->pad_h = H; ts->pad_w = W; ts->max_objs = max_objs;
     for (int i = 0; i < MC_NUM_PREDS; ++i) {
         if (!preds[i]) return fail(h, "%s: preds[%d] is NULL", fn, i);

@@ -103,6 +103,11 @@ class MonoConDataset(BaseKITTIMono3DDataset):
         if transforms is None:          # as the reference: augmentations for 'train' only (monocon_dataset.py:58-63)
             transforms = default_train_transforms(aug_rng) if split == 'train' else default_transforms()
         self.transforms = Compose(transforms)
+        # One Generator serves every random transform.  A DataLoader with num_workers > 0 COPIES it into each forked
+        # worker, which would then all draw the same augmentation sequence (the engine's worker_init_fn only
+        # reseeds numpy's global state): the first __getitem__ inside a worker re-seeds the shared object in place from
+        # (its current stream, worker id, the worker's torch seed).
+        self._aug_rng, self._aug_rng_worker = aug_rng, None
         cfg = dict(DEFAULT_FILTER_CONFIG)
         if filter_configs is not None:
             unknown = [k for k in filter_configs if k not in DEFAULT_FILTER_CONFIG]
@@ -149,7 +154,17 @@ class MonoConDataset(BaseKITTIMono3DDataset):
             L['mask'][row] = True
         return L
 
+    def _reseed_in_worker(self):
+        info = torch.utils.data.get_worker_info()
+        if self._aug_rng is None or info is None or self._aug_rng_worker == info.id:
+            return
+        base = int(self._aug_rng.bit_generator.random_raw())          # same in every copy: the parent's stream position
+        ss = np.random.SeedSequence([base, info.id, int(info.seed) % (2 ** 63)])
+        self._aug_rng.bit_generator.state = type(self._aug_rng.bit_generator)(ss).state
+        self._aug_rng_worker = info.id
+
     def __getitem__(self, idx: int) -> Dict[str, Any]:
+        self._reseed_in_worker()
         image, metas = self.load_image(idx)
         out = {'img': image, 'img_metas': metas, 'calib': self.load_calib(idx)}
         if self.label_files:

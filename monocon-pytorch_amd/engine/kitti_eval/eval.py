@@ -171,6 +171,8 @@ def _statistics_part(mode, overlaps, gt_nums, dt_nums, dc_nums, gt_datas, dt_dat
     n_scores = C.c_longlong(0)
     if mode == 1:
         assert pr is not None and pr.dtype == np.float64 and pr.flags.c_contiguous and pr.shape == (len(thr), 4)
+    elif pr is not None:
+        assert pr.dtype == np.float64 and pr.flags.c_contiguous and pr.size >= 4
     rc = _lib.load().mc_kitti_statistics_part(
         int(mode), _dp(overlaps), len(gt_nums), _llp(gt_nums), _llp(dt_nums), _llp(dc_nums), _dp(gt_datas), _dp(dt_datas),
         _dp(dontcares), _llp(ignored_gts), _llp(ignored_dets), int(metric), float(min_overlap), _dp(thr), len(thr),
@@ -189,10 +191,12 @@ def compute_statistics_jit(overlaps, gt_datas, dt_datas, ignored_gt, ignored_det
     args = (overlaps, one(len(gt_datas)), one(len(dt_datas)), one(len(dc_bboxes)), gt_datas, dt_datas, dc_bboxes,
             ignored_gt, ignored_det, metric, min_overlap)
     if not compute_fp:
-        s = _statistics_part(0, *args)
-        # (without false-positive accounting the reference reports tp and fn only)
-        fn = int(((np.asarray(ignored_gt) == 0).sum()) - len(s))
-        return len(s), 0, max(fn, 0), 0, s
+        # (without false-positive accounting the reference reports tp and fn only.  fn comes from the native pass itself:
+        #  a valid ground truth matched to a detection with ignored_det == 1 is neither tp nor fn, eval.py:228-247 --
+        #  "valid ground truths minus tp" over-counted such frames)
+        pr0 = np.zeros((1, 4))
+        s = _statistics_part(0, *args, pr=pr0)
+        return int(pr0[0, 0]), 0, int(pr0[0, 2]), 0, s
     pr = np.zeros((1, 4))
     _statistics_part(1, *args, thresholds=[thresh], compute_aos=compute_aos, pr=pr)
     return int(pr[0, 0]), int(pr[0, 1]), int(pr[0, 2]), pr[0, 3], np.zeros(0)

@@ -127,23 +127,39 @@ def ensure_engine_comm(engine, force=False):
         return False
     if not force and dp_backend() != "rccl":
         return False
-    try:
-        if world > 1:
-            import torch.distributed as dist
-            dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
-            t = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                t.copy_(torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(t, src=0)
-            uid = bytes(t.cpu().numpy().tobytes())
+    # every rank issues the SAME collective sequence whether or not something failed locally: broadcast of a status byte
+    # + the 128-byte id, then one vote.  (A rank 0 that cannot create the id -- librccl not loadable, the case
+    # MONOCON_HIP_DP_FALLBACK exists for -- still broadcasts, with status 0, instead of skipping to the vote while the
+    # other ranks sit in the broadcast.)
+    ok, err = True, None
+    uid = None
+    if world > 1:
+        import torch.distributed as dist
+        dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                raw = engine.comm_unique_id()
+                t[0] = 1
+                t[1:].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            except Exception as e:      # noqa: BLE001
+                ok, err = False, e
+        dist.broadcast(t, src=0)
+        host = t.cpu()
+        if int(host[0]) != 1:
+            ok, err = False, err or RuntimeError("rank 0 could not create the RCCL unique id")
         else:
-            uid = engine.comm_unique_id()
-        engine.comm_init(rank, world, uid)
-    except Exception as e:      # noqa: BLE001
-        ok = False
-        err = e
+            uid = bytes(host[1:].numpy().tobytes())
     else:
-        ok, err = True, None
+        try:
+            uid = engine.comm_unique_id()
+        except Exception as e:          # noqa: BLE001
+            ok, err = False, e
+    if ok:
+        try:
+            engine.comm_init(rank, world, uid)      # collective inside RCCL, under the library's watchdog (names the rank on expiry)
+        except Exception as e:          # noqa: BLE001
+            ok, err = False, e
     if world > 1 and not all_ranks_ok(ok, engine.device):
         ok = False
     if not ok:
@@ -156,6 +172,36 @@ def ensure_engine_comm(engine, force=False):
             return False
         raise RuntimeError("could not build the handle's RCCL communicator: %s" % (err,))
     return True
+
+
+def share_tune_table(engine, B, H, W, src=0):
+    """Identical convolution tilings on every rank: rank ``src`` builds (and autotunes) its train plan for this shape
+    -- no kernel of the step, no collective -- and broadcasts the table of chosen workgroup shapes; the other ranks adopt
+    it before they build their own plans.  (Concurrent timing-based tuning can pick different shapes per rank: results
+    would stay bit-identical, step times would not.)  Returns the number of table entries; 0 outside a distributed run."""
+    if not is_distributed():
+        return 0
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    table, ok = [], True
+    if rank == src:
+        try:
+            engine.build_train_plan(B, H, W)
+            table = engine.tune_export()
+        except Exception:               # noqa: BLE001  (the other ranks wait in the broadcast: report through the header)
+            ok, table = False, []
+    head = torch.tensor([len(table) if ok else -1], dtype=torch.int64, device=dev)
+    dist.broadcast(head, src=src)
+    n = int(head.item())
+    if n < 0:
+        raise RuntimeError("rank %d could not build / autotune its train plan" % src)
+    body = torch.tensor(table, dtype=torch.int32, device=dev) if rank == src else torch.zeros(n, dtype=torch.int32, device=dev)
+    if n:
+        dist.broadcast(body, src=src)
+    if rank != src and n:
+        engine.tune_import(body.cpu().tolist())
+    return n
 
 
 def all_ranks_ok_many(flags, device=None):

@@ -395,6 +395,28 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(self.h, self.lib.mc_allreduce_grads(self.h, _stream()), "mc_allreduce_grads")
 
+    # ---- data-parallel start-up: identical convolution tilings on every rank
+    def build_train_plan(self, B, H, W):
+        """build (and autotune) the train plan of a shape without running it -- no kernel of the step, no collective"""
+        with torch.cuda.device(self.device):
+            _lib.check(self.h, self.lib.mc_build_train_plan(self.h, int(B), int(H), int(W)), "mc_build_train_plan")
+
+    def tune_export(self):
+        """the autotuned workgroup shapes as a list of ints ([key length, key..., shape id] per entry)"""
+        n = C.c_int(0)
+        _lib.check(self.h, self.lib.mc_tune_export(self.h, None, 0, C.byref(n)), "mc_tune_export")
+        buf = (C.c_int * max(n.value, 1))()
+        _lib.check(self.h, self.lib.mc_tune_export(self.h, buf, n.value, C.byref(n)), "mc_tune_export")
+        return list(buf[:n.value])
+
+    def tune_import(self, table):
+        """adopt another rank's table; returns the number of entries"""
+        buf = (C.c_int * max(len(table), 1))(*[int(v) for v in table])
+        rc = self.lib.mc_tune_import(self.h, buf, len(table))
+        if rc < 0:
+            _lib.check(self.h, rc, "mc_tune_import")
+        return rc
+
     def set_conv_cfg(self, cfg):
         """force a workgroup shape of the fused conv (tuning / tests); 0 = automatic."""
         _lib.check(self.h, self.lib.mc_set_conv_cfg(self.h, int(cfg)), "mc_set_conv_cfg")

@@ -18,6 +18,7 @@ EXPORTS = (
     "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_query_workspace", "mc_forward_cost",
     "mc_preprocess", "mc_profile_forward", "mc_profile_train", "mc_set_precision", "mc_set_conv_cfg", "mc_bench_conv", "mc_bench_mfma_peak",
     "mc_comm_unique_id", "mc_comm_init", "mc_comm_destroy", "mc_comm_set_overlap", "mc_comm_info", "mc_comm_exposed_ms", "mc_allreduce_grads",
+    "mc_build_train_plan", "mc_tune_export", "mc_tune_import",
     "mc_rotate_iou_eval", "mc_box3d_overlap", "mc_kitti_image_overlap", "mc_kitti_statistics_part",
 )
 
@@ -111,6 +112,9 @@ def load():
     lib.mc_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_ulonglong), C.c_char_p, i]
     lib.mc_comm_exposed_ms.argtypes = [vp, fp]
     lib.mc_allreduce_grads.argtypes = [vp, vp]
+    lib.mc_build_train_plan.argtypes = [vp, i, i, i]
+    lib.mc_tune_export.argtypes = [vp, C.POINTER(i), i, C.POINTER(i)]
+    lib.mc_tune_import.argtypes = [vp, C.POINTER(i), i]
     ll, dp, llp = C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_longlong)
     lib.mc_rotate_iou_eval.argtypes = [vp, vp, vp, ll, ll, i, vp, vp]
     lib.mc_box3d_overlap.argtypes = [vp, vp, vp, ll, ll, i, vp, vp]

@@ -149,11 +149,12 @@ def _require_objects(detector, label, pad_hw, num_classes=3):
     mask = label["mask"]
     seen = getattr(detector, "_mask_validated", None)
     cached = seen is not None and seen[0]() is mask and seen[1] == mask._version
-    if _dist.is_distributed():
-        # every rank must take the same branch: a rank that skipped the validation while another one runs its
-        # collective would leave the latter hanging.  One MIN all-reduce decides -- all skip, or all validate.
-        cached = _dist.all_ranks_ok(cached, mask.device)
     if cached:
+        # No collective here: a per-step vote on "is everybody's mask cached" was a host sync on every step of
+        # the data-parallel path -- the very sync the cache exists to avoid -- ahead of the overlapped gradient exchange.
+        # The contract instead: the ranks of an SPMD loop either all re-use their label tensors (a resident batch stepped
+        # repeatedly) or all feed fresh ones (a DataLoader); fresh labels are validated below, with ONE collective that
+        # makes every rank raise together.
         return
     H, W = pad_hw
     fh, fw = H // 4, W // 4
@@ -190,8 +191,13 @@ def forward_train(detector, data_dict):
         if p.grad is not None and p.grad.data_ptr() == tb.grads[n].data_ptr():
             p.grad = p.grad.clone()
     eng = detector._rt.get(tb.state(detector))
-    if not eng.comm_world and _dist.is_distributed():
-        _dist.ensure_engine_comm(eng)                         # 'rccl' backend: the handle exchanges the gradients itself
+    if _dist.is_distributed():
+        shape = tuple(img.shape)
+        if getattr(eng, "_tune_shared_for", None) != shape:   # first step of this shape: rank 0 tunes, everyone adopts
+            _dist.share_tune_table(eng, shape[0], shape[2], shape[3])
+            eng._tune_shared_for = shape
+        if not eng.comm_world:
+            _dist.ensure_engine_comm(eng)                     # 'rccl' backend: the handle exchanges the gradients itself
     params = [p for _, p in tb.named]
     out = _HipTrainStep.apply(detector, tb, eng, img.contiguous(), label, detector.head.max_objs, *params)
     losses, preds = out[:10], out[10:]

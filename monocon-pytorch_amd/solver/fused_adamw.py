@@ -52,13 +52,26 @@ class AdamW(Optimizer):
         self._bound_sig = None
         self._step_cache = None
 
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._bound_sig = None
+        self._step_cache = None
+
+    def zero_state(self):
+        """forget the moments and step counts (a fresh optimizer over the same parameters)"""
+        self.state.clear()
+        self._bound_sig = None
+        self._step_cache = None
+
     def _common_step(self, plist):
         """The bias-correction step lives in ``state[p]['step']`` only (so it survives state_dict round trips);
         the fused kernel applies one step number to all tensors, as they always share it in this train loop.  Reading
         it back is one ``int()`` per tensor -- a host sync each if a resumed checkpoint left the step tensors on the
         device -- so it is read once (after construction / load_state_dict / a change of the parameter list) and
         tracked on the host from then on."""
-        key = len(plist)
+        # keyed on the IDENTITY of the stepped tensors and of their step objects (ADVICE r3: the length alone let a changed
+        # parameter set of equal size, a reset state or a user-edited state[p]['step'] reuse a stale host copy)
+        key = tuple((id(p), id(self.state[p].get('step'))) for p in plist)
         if self._step_cache is not None and self._step_cache[0] == key:
             return self._step_cache[1]
         steps = {int(self.state[p]['step']) for p in plist}
@@ -112,9 +125,9 @@ class AdamW(Optimizer):
             return loss
         eng = self._bind(plist)
         step = self._common_step(plist) + 1
-        self._step_cache = (len(plist), step)
         for p in plist:
-            self.state[p]['step'] += 1
+            self.state[p]['step'] += 1          # in place: the tensors' identities (the cache key) survive
+        self._step_cache = (tuple((id(p), id(self.state[p]['step'])) for p in plist), step)
         if self.last_grad_norm is None:
             self.last_grad_norm = torch.zeros(1, dtype=torch.float32, device=plist[0].device)
         beta1, beta2 = group['betas']

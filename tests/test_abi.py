@@ -59,3 +59,28 @@ def test_bench_cli_contract_without_a_gpu():
         assert flag in r.stdout, flag
     src = open(os.path.join(REPO, "bench.py")).read()
     assert 'choices=("f16x2", "bf16x3", "fp32")' in src and '"--gpus", type=int, default=1' in src
+
+
+def test_bench_compact_line_carries_every_baseline_config():
+    """the ONE stdout line must stay small enough to survive a log tail and still hold the numbers of every
+    BASELINE config (train step = configs[2] shape, forward_only = configs[1], decode_only = configs[4], the per-mode
+    legs, the roofline and cpu_baseline objects).  Exercised on a committed verbose report of an earlier round."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(REPO, "profiles", "r3h_bench.json")))
+    line = bench.compact_line(full, os.path.join(REPO, "gpurun_out", "bench_full.json"))
+    text = json.dumps(line)
+    assert len(text) < 4096, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "forward_only", "decode_only", "modes"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["roofline"]["frac"] == full["roofline"]["frac"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert line["forward_only"]["img_s"] == full["forward_only"]["images_per_sec"]
+    assert set(line["modes"]) == {"fp32", "bf16x3", "bf16"} and line["modes"]["fp32"]["train_ms"] == full["native_fp32"]["train"]["ms_per_step"]
+    assert line["decode_only"]["img_s"] == full["decode_only"]["images_per_sec"]
+    assert all(not isinstance(v, str) or len(v) < 120 for v in line["roofline"].values())

@@ -106,3 +106,140 @@ def test_replicas_start_identical_and_fail_together():
     assert n0 == n1 == 9 and nbt0 == nbt1 == 0
     assert s0 == s1 == 4242
     assert f0 is False and f1 is False and t0 is True and t1 is True
+
+
+# ----------------------------------------------------------------------------- world 8 (the node the driver benches on)
+class _FakeEngine:
+    """stands in for hipmonocon.engine.Engine in the start-up protocol tests (no GPU here): records what the protocol
+    asks of it"""
+
+    def __init__(self, rank, fail_uid=False, fail_init_on=()):
+        self.rank, self.device = rank, torch.device("cpu")
+        self.comm_world = 0
+        self.fail_uid, self.fail_init_on = fail_uid, set(fail_init_on)
+        self.built, self.imported, self.inited = [], None, None
+        self._table = [10, 32, 96, 320, 3, 1, 64, 64, 1, 6, 64, 4,  11, 32, 48, 160, 1, 1, 128, 128, 2, 6, 128, 128, 1]
+
+    def comm_unique_id(self):
+        if self.fail_uid:
+            raise RuntimeError("librccl.so not found")
+        return bytes((7 * i + 3) % 251 for i in range(128))
+
+    def comm_init(self, rank, world, uid):
+        if rank in self.fail_init_on:
+            raise RuntimeError("mc_comm_init: rank %d of %d still waits in ncclCommInitRank" % (rank, world))
+        self.inited = (rank, world, uid)
+        self.comm_world = world
+
+    def comm_destroy(self):
+        self.comm_world = 0
+
+    def build_train_plan(self, B, H, W):
+        self.built.append((B, H, W))
+
+    def tune_export(self):
+        return list(self._table)
+
+    def tune_import(self, table):
+        self.imported = list(table)
+        return 2
+
+
+def _world8_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MONOCON_HIP_DP="rccl")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hipmonocon import dist as hdist
+    res = {}
+    # (1) rank-0 state broadcast over 8 ranks
+    torch.manual_seed(2000 + rank)
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8))
+    m[1].num_batches_tracked += rank
+    hdist.sync_module_state(m)
+    res["checksum"] = hdist.state_checksum(m)
+    # (2) the bucket schedule: four dense buckets of the flat gradient buffer, exchanged in backward order, each
+    #     averaged over the ranks -- the same partition csrc/mc_comm.hip makes (mc_grad_bucket_of), on gloo
+    spec = [("head.a", (64, 9)), ("neck.b", (33,)), ("backbone.level5.c", (128, 5)), ("backbone.level4.d", (77,)),
+            ("backbone.level2.e", (16, 3)), ("backbone.base_layer.f", (5,))]
+    fg = FlatGrads([(n, torch.empty(s)) for n, s in spec], torch.device("cpu"))
+    for n, s in spec:
+        fg.views[n].copy_(torch.from_numpy(synth.normalish(300 + rank, n, s).astype(np.float32)))
+
+    def bucket_of(name):
+        if name.startswith(("head.", "neck.")):
+            return 0
+        if name.startswith("backbone.level5"):
+            return 1
+        if name.startswith("backbone.level4"):
+            return 2
+        return 3
+    order = []
+    for b in range(4):
+        names = [n for n, _ in spec if bucket_of(n) == b]
+        lo = min(fg.views[n].data_ptr() for n in names)
+        hi = max(fg.views[n].data_ptr() + fg.views[n].numel() * 4 for n in names)
+        i0, i1 = (lo - fg.flat.data_ptr()) // 4, (hi - fg.flat.data_ptr()) // 4
+        seg = fg.flat[i0:i1]                               # a dense range: ONE collective per bucket
+        dist.all_reduce(seg, op=dist.ReduceOp.SUM)
+        seg.mul_(1.0 / world)
+        order.append((b, int(i0), int(i1)))
+    res["buckets"] = order
+    res["grads"] = {n: fg.views[n].clone() for n, _ in spec}
+    # (3) tune table: rank 0 builds + exports, everyone else imports the same ints
+    eng = _FakeEngine(rank)
+    res["n_tune"] = hdist.share_tune_table(eng, 32, 384, 1280)
+    res["built"], res["imported"] = eng.built, eng.imported
+    # (4) communicator start-up: every rank adopts rank 0's id ...
+    assert hdist.ensure_engine_comm(eng) is True
+    res["inited"] = eng.inited
+    # (5) ... and when rank 0 cannot create the id (ADVICE r3: it used to skip the broadcast and hang the others), or
+    #     one rank's init times out, ALL ranks fall back together
+    os.environ["MONOCON_HIP_DP_FALLBACK"] = "1"
+    e2 = _FakeEngine(rank, fail_uid=(rank == 0))
+    res["fallback_uid"] = hdist.ensure_engine_comm(e2)
+    os.environ["MONOCON_HIP_DP"] = "rccl"
+    e3 = _FakeEngine(rank, fail_init_on={5})
+    res["fallback_init"] = (hdist.ensure_engine_comm(e3), e3.comm_world)
+    os.environ["MONOCON_HIP_DP"] = "rccl"
+    os.environ["MONOCON_HIP_DP_FALLBACK"] = "0"
+    e4 = _FakeEngine(rank, fail_init_on={3})
+    try:
+        hdist.ensure_engine_comm(e4)
+        res["hard"] = "no error"
+    except RuntimeError as e:
+        res["hard"] = str(e)[:40]
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_start_up_protocol_and_bucket_schedule():
+    """the first real 8-GPU run is a single shot.  Eight ranks over gloo: rank-0 state broadcast, the
+    four-bucket exchange == the mean of the per-rank gradients, one tune table on every rank, the communicator id on
+    every rank, and a failure on ONE rank (id creation on rank 0, init time-out on rank 5 / 3) turning into the SAME
+    outcome on all eight -- fallback when allowed, an exception when not -- instead of a hang."""
+    world, port = 8, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_world8_worker, args=(world, port, out), nprocs=world, join=True)
+    r0 = out[0]
+    spec = [("head.a", (64, 9)), ("neck.b", (33,)), ("backbone.level5.c", (128, 5)), ("backbone.level4.d", (77,)),
+            ("backbone.level2.e", (16, 3)), ("backbone.base_layer.f", (5,))]
+    for r in range(world):
+        o = out[r]
+        assert o["checksum"] == r0["checksum"]
+        assert o["buckets"] == r0["buckets"] and [b for b, _, _ in o["buckets"]] == [0, 1, 2, 3]
+        for n, s in spec:
+            expect = sum(torch.from_numpy(synth.normalish(300 + q, n, s).astype(np.float32)) for q in range(world)) / world
+            assert torch.allclose(o["grads"][n], expect, atol=1e-6), (r, n)
+            assert torch.equal(o["grads"][n], r0["grads"][n])
+        assert o["n_tune"] == 25
+        assert (o["built"] == [(32, 384, 1280)]) == (r == 0) and (o["imported"] is None) == (r == 0)
+        if r:
+            assert o["imported"] == _FakeEngine(0).tune_export()
+        assert o["inited"] == (r, world, _FakeEngine(0).comm_unique_id())
+        assert o["fallback_uid"] is False
+        assert o["fallback_init"] == (False, 0)
+        assert o["hard"].startswith("could not build the handle's RCCL")
+    # bucket ranges are disjoint and cover the buffer in order
+    rng = r0["buckets"]
+    assert all(rng[i][2] <= rng[i + 1][1] for i in range(3))

@@ -349,3 +349,17 @@ def test_dataset_evaluate_scores_the_labels_against_themselves():
                 assert res[key % (name, dn)] == pytest.approx(want), (key % (name, dn), n)
     assert res["img_bbox/KITTI/Car_3D_AP40_moderate_strict"] > 0
     assert not any(k.startswith("img_bbox2d") and "_3D_" in k for k in res)
+
+
+def test_single_frame_helper_fn_with_an_ignored_detection():
+    """a valid ground truth whose best match is a detection with ignored_det == 1 is neither a true positive
+    nor a false negative (engine/kitti_eval/eval.py:228-247 of the reference); "valid ground truths minus tp" counted it
+    as fn.  Two valid GTs: one matched by a scored, non-ignored detection, one only by an ignored detection."""
+    from engine.kitti_eval import eval as E
+    gd = np.array([[0, 0, 10, 10, 0.0], [20, 0, 30, 10, 0.0]])
+    dd = np.array([[0, 0, 10, 10, 0.0, 0.9], [20, 0, 30, 10, 0.0, 0.8]])
+    ov = KO.image_overlap(dd[:, :4], gd[:, :4])
+    ig, idt = np.array([0, 0]), np.array([0, 1])
+    tp, fp, fn, sim, scores = E.compute_statistics_jit(ov, gd, dd, ig, idt, np.zeros((0, 4)), 0, 0.5)
+    want = KO.statistics(ov, gd, dd, [0, 0], [0, 1], np.zeros((0, 4)), 0, 0.5, 0.0, False)
+    assert (tp, fn) == (1, 0) == (want[0], want[2]) and list(scores) == [0.9]
