@@ -112,8 +112,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_p16_kernel(const ConvArg
     __syncthreads();
 
     // ---- DMA plan.  Halo tile: piece j = wave + NW * i covers flat slots [64 j, 64 j + 64) of
-    //      [octet][piece][patch pair][halo row][24 slots]; lane l of it fetches pixel (iy, ix) of patch 2 * pair + (slot >= IW)
-    int a_pix[NA_W], a_sub[NA_W];     // pixel index inside the image (-1: zero fill), byte offset of (octet, piece) inside a chunk
+    //      [octet][piece][patch pair][halo row][24 slots]; lane l of it fetches pixel (iy, ix) of patch 2 * pair + (slot >= IW).
+    //      Kept per piece: the pixel's index inside the image (-1: zero fill); the byte offset follows from the source's
+    //      channel count at every source switch (branch-free: this runs between chunks with ~200 registers live).
+    int a_pix[NA_W], a_voff[NA_W];
 #pragma unroll
     for (int i = 0; i < NA_W; ++i) {
         const int f = 64 * (wave + NW * i) + lane;
@@ -130,8 +132,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_p16_kernel(const ConvArg
             pix = y * a.Win + x;
         }
         a_pix[i] = ok ? pix : -1;
-        a_sub[i] = (plane >> 1) * 32 + (plane & 1) * 16;
     }
+    auto lane_offsets = [&](int cs) {
+#pragma unroll
+        for (int i = 0; i < NA_W; ++i) {
+            const int plane = (64 * (wave + NW * i) + lane) / C::PLANE_SLOTS;
+            const int off = a_pix[i] * cs * 4 + (plane >> 1) * 32 + (plane & 1) * 16;
+            a_voff[i] = a_pix[i] >= 0 ? off : BUF_OOB;
+        }
+    };
     // weight slice of one (tap, chunk): flat slot f -> [octet][piece][BNT columns] x 16 bytes
     const int w_plane = NTAP * a.Cin * a.CoutP * 2;            // bytes of one piece plane of the panel
     const int Cin8 = a.Cin >> 3;
@@ -162,18 +171,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_p16_kernel(const ConvArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[tm][tn][r] = 0.f; accm[tm][tn][r] = 0.f; }
 
-    const EpiCoef<WTN> coef = conv_epi_coef<WN, WTN, BM>(a, n0, wn, li);
+    // the epilogue's per-column coefficients: fetched before the K loop (their latency hides behind it) where the registers
+    // allow it; the 2x2-tile waves -- 248 of 256 registers without them -- fetch them after the loop instead
+    constexpr bool COEF_EARLY = WTM * WTN < 4;
+    EpiCoef<WTN> coef;
+    if (COEF_EARLY) coef = conv_epi_coef<WN, WTN, BM>(a, n0, wn, li);
 
     // ---- walk over the virtual concat, 16 channels per chunk.  Two cursors: (si_n, c0_n) runs LAC chunks ahead (the tile
     //      DMA), (si_c, c0_c) is the chunk whose MFMAs run.
     const int nch = a.Cin >> 4;
     int si_n = 0, c0_n = 0, Cs_n = a.src[0].C;
     __amdgpu_buffer_rsrc_t r_in = make_rsrc(a.src[0].p + (size_t)img * a.Hin * a.Win * Cs_n, (unsigned)(a.Hin * a.Win * Cs_n) * 4u);
-    int a_voff[NA_W];
-    auto lane_offsets = [&](int cs) {
-#pragma unroll
-        for (int i = 0; i < NA_W; ++i) a_voff[i] = a_pix[i] >= 0 ? a_pix[i] * cs * 4 + a_sub[i] : BUF_OOB;
-    };
     lane_offsets(Cs_n);
     auto advance_next = [&]() {        // stays on the last chunk at the end (a harmless re-load into a free buffer)
         int s2 = si_n, c2 = c0_n + 16;
@@ -251,7 +259,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_p16_kernel(const ConvArg
         int ab_dma = ab + LAC; if (ab_dma >= NABUF) ab_dma -= NABUF;
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
-            constexpr int dummy = 0; (void)dummy;
             const int cur = (PAR + t) & 1;
             int slot_t = bs + t; slot_t = slot_t >= 3 ? slot_t - 3 : slot_t; slot_t = slot_t >= 3 ? slot_t - 3 : slot_t;   // (bs + t) % 3, t <= 8
             slot_t = slot_t >= 3 ? slot_t - 3 : slot_t;
@@ -265,7 +272,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_p16_kernel(const ConvArg
                 for (int q = 0; q < AQ; ++q)
                     if (t * AQ + q < NA_W) dma_a(t * AQ + q, ab_dma);
             }
-            if (t == NA_STEPS - 1) advance_next();
             if (t + 1 < NTAP) load_frags(fa[cur ^ 1], fb[cur ^ 1], ab, t + 1, slot_n);
             else load_frags(fa[cur ^ 1], fb[cur ^ 1], ab_next, 0, slot_n);
             __builtin_amdgcn_sched_barrier(0);
@@ -292,6 +298,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_p16_kernel(const ConvArg
         }
         ab = ab_next;
         bs = (bs + NTAP) % 3;
+        advance_next();     // (at the chunk boundary: control flow inside the unrolled steps costs the register allocator dearly)
     };
     constexpr int PAR1 = NTAP & 1;            // odd tap counts: the second chunk of a pair starts on the other register set
     for (int ch = 0; ch < nch; ch += 2) {
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_p16_kernel(const ConvArg
         for (int tn = 0; tn < WTN; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] += accm[tm][tn][r];
+    if (!COEF_EARLY) coef = conv_epi_coef<WN, WTN, BM>(a, n0, wn, li);
     const float omul = exp2i(-e_cur) * exp2i(-f16_scale_exp(*a.amax_w));
     conv_epilogue<WM, WN, WTM, WTN, BNT, BM>(a, acc, pinfo, chunk * PB, img, n0, wm, wn, g, li, coef, omul);
 }
@@ -345,7 +353,6 @@ static hipError_t launch_p16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved)
 template <int KS>
 static hipError_t launch_p16_shape(const ConvArgs &a, hipStream_t st, ConvArgs *resolved) {
     switch (a.cfg & 15) {
-        case CFG_128x128: return launch_p16_one<KS, 2, 2, 2, 2>(a, st, resolved);
         case CFG_128x64: return launch_p16_one<KS, 2, 2, 2, 1>(a, st, resolved);
         case CFG_128x64m: return launch_p16_one<KS, 4, 1, 1, 2>(a, st, resolved);
         case CFG_64x128: return launch_p16_one<KS, 1, 4, 2, 1>(a, st, resolved);
@@ -354,18 +361,19 @@ static hipError_t launch_p16_shape(const ConvArgs &a, hipStream_t st, ConvArgs *
     }
 }
 
-// eligible: mode 4, stride 1, every source stored as P16 (a multiple of 16 channels each), piece-plane weights
+// eligible: the fp16-split arithmetic (prec 3), stride 1, every source stored as P16 (a multiple of 16 channels each), piece-plane weights
 bool conv_p16_ok(const ConvArgs &a, int ks, int stride) {
-    if (a.prec != 4 || !a.wpk16 || !a.amax_w || stride != 1) return false;
+    if (a.prec != 3 || !a.wpk16 || !a.amax_w || stride != 1) return false;
     if (!(ks == 3 || ks == 1 || ks == 12 || ks == 21 || ks == 22)) return false;
     if (a.Hin != a.Hout || a.Win != a.Wout) return false;
     for (int i = 0; i < a.nsrc; ++i)
         if (!a.pexp[i] || a.src[i].C % 16) return false;
     return true;
 }
-bool conv_p16_cfg_ok(int cfg, int CoutP) {
+bool conv_p16_cfg_ok(int cfg, int CoutP, int ks) {
+    (void)ks;      // (the 2x2-tile shape CFG_128x128 is not built: with the full epilogue it spills at 256 registers)
     switch (cfg & 15) {
-        case CFG_128x128: case CFG_128x64: case CFG_128x64m: case CFG_64x128: case CFG_64x64: break;
+        case CFG_128x64: case CFG_128x64m: case CFG_64x128: case CFG_64x64: break;
         default: return false;
     }
     return !(cfg & ~15) && CoutP % conv_shape(cfg).BNT() == 0;
