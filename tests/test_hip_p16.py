@@ -77,3 +77,67 @@ def test_conv_p16(eng4, case, cfg):
     got = out.cpu().permute(0, 3, 1, 2)
     assert got.shape == ref.shape
     assert rel_err(got, ref) < TOL, rel_err(got, ref)
+
+
+DGRAD_CASES = [
+    # (name, B, H, W, CinTotal, c_off, Cs, Cout, k, stride)
+    ("dg_s1_64_64", 2, 16, 24, 64, 0, 64, 64, 3, 1),
+    ("dg_s1_cat_slice", 1, 12, 16, 192, 64, 128, 128, 3, 1),
+    ("dg_k1_root", 1, 12, 16, 448, 256, 64, 128, 1, 1),
+    ("dg_s2_64_128", 2, 16, 32, 64, 0, 64, 128, 3, 2),          # the four output-parity windows 1x1 / 1x2 / 2x1 / 2x2
+    ("dg_s2_256_512_tiny", 1, 8, 8, 256, 0, 256, 512, 3, 2),
+    ("dg_head_576_64", 1, 8, 16, 64, 0, 64, 576, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+def test_conv_dgrad_p16(eng4, case):
+    """data gradients in mode 4: dY stored as P16, the transposed / flipped panels as before; stride-2 layers exercise
+    the 1x2 / 2x1 / 2x2 window builds of the DMA-staged kernel (few taps per chunk: the deeper tile ring)."""
+    name, B, H, W, cin_total, c_off, cs, cout, k, stride = case
+    seed = 800 + DGRAD_CASES.index(case)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    w = rnd(seed, "w", (cout, cin_total, k, k), (2.0 / (k * k * cin_total)) ** 0.5)
+    dy = rnd(seed, "dy", (B, cout, Ho, Wo))
+    x = torch.zeros(B, cin_total, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w.double(), None, stride, k // 2).backward(dy.double())
+    ref = x.grad[:, c_off:c_off + cs]
+    dev = eng4.device
+    got = eng4.op_conv_dgrad(nhwc(dy).to(dev), w.to(dev), (H, W), c_off, cs, stride)
+    assert rel_err(got.cpu().permute(0, 3, 1, 2), ref) < TOL
+    base = rnd(seed, "acc", (B, cs, H, W))
+    acc = nhwc(base).to(dev).clone()
+    eng4.op_conv_dgrad(nhwc(dy).to(dev), w.to(dev), (H, W), c_off, cs, stride, accumulate_into=acc)
+    assert rel_err(acc.cpu().permute(0, 3, 1, 2), ref + base.double()) < TOL
+
+
+WGRAD_CASES = [
+    # (name, B, H, W, [Cin...], Cout, k, stride)
+    ("wg_s1_64_64", 2, 16, 24, [64], 64, 3, 1),
+    ("wg_s1_128_128", 1, 12, 40, [128], 128, 3, 1),
+    ("wg_s1_cat_64_64", 2, 8, 16, [64, 64], 64, 3, 1),
+    ("wg_s1_odd", 1, 6, 10, [64], 64, 3, 1),
+    ("wg_s2_64_128", 2, 24, 48, [64], 128, 3, 2),
+    ("wg_s2_256_512", 1, 8, 8, [256], 512, 3, 2),
+    ("wg_k1_root4", 1, 12, 16, [128, 128, 64, 128], 128, 1, 1),
+    ("wg_head_64_576", 1, 8, 16, [64], 576, 3, 1),
+]
+
+
+@pytest.mark.parametrize("operands", ["xd", "x", "d"])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_wgrad_p16(eng4, case, operands, monkeypatch):
+    """weight gradients with X and / or dY stored as P16 (the train plan mixes them: level-1 activations and the head's
+    hidden-map gradient stay fp32): the staging only transposes the stored pieces"""
+    name, B, H, W, cins, cout, k, stride = case
+    monkeypatch.setenv("MONOCON_HIP_P16_OPERANDS", operands)
+    seed = 900 + WGRAD_CASES.index(case)
+    xs = [rnd(seed, "x%d" % i, (B, c, H, W)) * (3.0 ** i) for i, c in enumerate(cins)]
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    dy = rnd(seed, "dy", (B, cout, Ho, Wo)) * 1e-3
+    w = torch.zeros(cout, sum(cins), k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(torch.cat(xs, 1).double(), w, None, stride, k // 2).backward(dy.double())
+    dev = eng4.device
+    got = eng4.op_conv_wgrad([nhwc(x).to(dev) for x in xs], nhwc(dy).to(dev), k, stride).cpu()
+    assert got.shape == w.grad.shape
+    assert rel_err(got, w.grad) < TOL, rel_err(got, w.grad)
