@@ -73,7 +73,10 @@ struct ConvCfgB16 {
     static constexpr size_t LDS_BYTES = TILE_BYTES + PB * 16;
 };
 
-template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
+// P16S (mode 4, SPL == 2, the stride-2 layers): the sources are stored as P16 (p16.h) -- the staging copies the two pieces
+// (two 8-byte loads per pixel and channel quad) instead of scaling / splitting fp32 values; one source, its exponent
+// from ConvArgs::pexp[0]
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false, bool P16S = false>
 __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kernel(const ConvArgs a) {
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
     typedef typename Piece<SPL>::T pc_t;
@@ -122,8 +125,9 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     float a_scale = 1.f, omul = 1.f;
     if constexpr (SPL == 2) {
         unsigned am = 0u;
-        for (int i = 0; i < a.nsrc; ++i) { const unsigned v = amax_read(a.amax_in[i]); am = v > am ? v : am; }
-        const int ea = f16_scale_exp(am), ew = f16_scale_exp(*a.amax_w);
+        if constexpr (!P16S)
+            for (int i = 0; i < a.nsrc; ++i) { const unsigned v = amax_read(a.amax_in[i]); am = v > am ? v : am; }
+        const int ea = P16S ? *a.pexp[0] : f16_scale_exp(am), ew = f16_scale_exp(*a.amax_w);
         a_scale = exp2i(ea);
         omul = exp2i(-ea) * exp2i(-ew);
     }
@@ -220,14 +224,34 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
             const int y = pinfo[p * 4 + 1] * S - PAD + iy;
             const int x = pinfo[p * 4 + 2] * S - PAD + ix;
             const bool ok = e < TOTAL && pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
-            voff[i] = ok ? ((y * a.Win + x) * cs + c4 * 4) * 4 : BUF_OOB;
+            voff[i] = ok ? (P16S ? (y * a.Win + x) * cs * 4 + (c4 >> 1) * 32 + (c4 & 1) * 8 : ((y * a.Win + x) * cs + c4 * 4) * 4) : BUF_OOB;
             sdst[i] = PLANAR ? (c4 >> 1) * CPL + (p >> 1) * PPB + (iy * RS + ix + IW * (p & 1)) * 16 + (c4 & 1) * 8
                              : (int)(stage_dst - lds_raw) + i * (NT / C4) * ROWB;
+        }
+    };
+    auto stage_load = [&](__amdgpu_buffer_rsrc_t r, int vo, int so) -> f32x4 {
+        if constexpr (P16S) {
+            typedef int i32x2_l __attribute__((ext_vector_type(2)));
+            const i32x2_l h = __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0);
+            const i32x2_l l = __builtin_amdgcn_raw_buffer_load_b64(r, vo == BUF_OOB ? BUF_OOB : vo + 16, so, 0);
+            i32x4 w;
+            w[0] = h[0]; w[1] = h[1]; w[2] = l[0]; w[3] = l[1];
+            return __builtin_bit_cast(f32x4, w);
+        } else {
+            return buf_load4(r, vo, so);
         }
     };
     auto stage_one = [&](const f32x4 &v, int i) {       // split one float4 into its pieces and write them to the LDS planes
         if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL)) {
             pc4 q[SPL];
+            if constexpr (P16S) {      // v = (hi pieces of the quad, lo pieces of the quad), 8 + 8 bytes
+                typedef int i32x2_l __attribute__((ext_vector_type(2)));
+                const i32x4 w = __builtin_bit_cast(i32x4, v);
+                i32x2_l h2, l2;
+                h2[0] = w[0]; h2[1] = w[1]; l2[0] = w[2]; l2[1] = w[3];
+                q[0] = __builtin_bit_cast(pc4, h2);
+                q[SPL - 1] = __builtin_bit_cast(pc4, l2);
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float r = SPL == 2 ? v[j] * a_scale : v[j];
@@ -236,6 +260,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                     q[pz][j] = (pc_t)r;
                     r -= (float)q[pz][j];
                 }
+            }
             }
 #pragma unroll
             for (int pz = 0; pz < SPL; ++pz) *reinterpret_cast<pc4 *>(lds_raw + sdst[i] + pz * PLANE) = q[pz];
@@ -251,7 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     lane_offsets(Cs);
     if (PF) {
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) pv[i] = buf_load4(r_in, voff[i], 0);
+        for (int i = 0; i < NIT; ++i) pv[i] = stage_load(r_in, voff[i], 0);
     }
     for (bool first = true;; first = false) {
         [[maybe_unused]] unsigned long long tp_a = TP_NOW();
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                 f32x4 v[UB];
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
-                    if (i0 + u < NIT) v[u] = buf_load4(r_in, voff[i0 + u], c0 * 4);
+                    if (i0 + u < NIT) v[u] = stage_load(r_in, voff[i0 + u], c0 * 4);
 #pragma unroll
                 for (int u = 0; u < UB; ++u) stage_one(v[u], i0 + u);
             }
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
         }
         if (PF && more) {
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) pv[i] = buf_load4(r_in, voff[i], nc0 * 4);
+            for (int i = 0; i < NIT; ++i) pv[i] = stage_load(r_in, voff[i], nc0 * 4);
         }
         {
             const int kc_next = (kc + CK < a.Cin) ? kc + CK : kc;
@@ -433,9 +458,14 @@ hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal,
 }
 
 // ---- dispatch
-template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false, bool P16S = false>
 static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
+    if constexpr (S == 2 && SPL == 2 && !P16S) {
+        if (a.pexp[0]) return a.nsrc == 1 ? launch_b16_one<KS, S, WM, WN, WTM, WTN, SPL, BM, true>(a, st, resolved) : hipErrorInvalidValue;
+    } else if constexpr (!P16S) {
+        if (a.pexp[0]) return hipErrorInvalidValue;
+    }
     if constexpr (!BM && S == 1 && (KS == 3 || KS == 1)) {      // backward-statistics epilogue: own instantiation
         if (a.bm_y) return launch_b16_one<KS, S, WM, WN, WTM, WTN, SPL, true>(a, st, resolved);
     } else if constexpr (!BM) {
@@ -448,7 +478,7 @@ static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved)
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
     static bool attr_set = false;
-    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL, BM>;
+    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL, BM, P16S>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
@@ -477,7 +507,7 @@ bool conv_bf16_ok(const ConvArgs &a, int ks, int stride) {
     if (a.prec == 3) {       // the fp16 split needs the maxima of every operand tensor
         if (!a.amax_w) return false;
         for (int i = 0; i < a.nsrc; ++i)
-            if (!a.amax_in[i]) return false;
+            if (!a.amax_in[i] && !a.pexp[i]) return false;
     }
     for (int i = 0; i < a.nsrc; ++i)
         if (a.src[i].C % 32) return false;

@@ -126,7 +126,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
         if (np16) {
             if (np16 != a.nsrc) return hipErrorInvalidValue;
             if (conv_p16_ok(a, ks, stride)) {
-                if (!conv_p16_cfg_ok(a.cfg, a.CoutP, ks)) a.cfg = a.CoutP % 128 == 0 ? CFG_64x128 : CFG_128x64m;
+                if (!conv_p16_cfg_ok(a.cfg, a.CoutP, ks)) a.cfg = a.CoutP % 128 == 0 ? CFG_64x128 : (a.CoutP % 64 == 0 ? CFG_128x64m : CFG_128x32);
                 return launch_conv_p16(a, ks, stride, st, resolved);
             }
             // (stride-2 3x3 layers: the register-staged kernel, whose staging then copies the pieces instead of making them)

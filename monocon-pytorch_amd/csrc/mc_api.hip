@@ -315,7 +315,7 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
         bool all16 = a_in.nsrc > 0;
         for (int i = 0; i < a_in.nsrc; ++i) all16 = all16 && a_in.pexp[i];
         if (all16 && conv_p16_ok(a_in, ks, stride) && !conv_p16_cfg_ok(heuristic, a_in.CoutP, ks))
-            heuristic = a_in.CoutP % 128 == 0 ? CFG_64x128 : CFG_128x64m;
+            heuristic = a_in.CoutP % 128 == 0 ? CFG_64x128 : (a_in.CoutP % 64 == 0 ? CFG_128x64m : CFG_128x32);
     }
     if (!h->autotune) return heuristic;
     const bool b16 = a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride);
@@ -923,6 +923,9 @@ int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[],
             a.src[i].p = p16buf[i].as<float>();
             a.pexp[i] = p16exp.as<int>() + i;
         }
+        // (shapes neither P16 kernel takes -- 16-channel layers, stride 2 with a source that is no multiple of 32 -- stay fp32)
+        if (!(conv_p16_ok(a, ksize, stride) || (stride == 2 && nsrc == 1 && conv_bf16_ok(a, ksize, stride))))
+            for (int i = 0; i < nsrc; ++i) { a.src[i].p = src[i]; a.pexp[i] = nullptr; }
     }
     a.scale = scale; a.bias = bias; a.res = residual; a.res_ld = Cout;
     a.out = out; a.out_ld = Cout; a.out_coff = 0; a.relu = relu;

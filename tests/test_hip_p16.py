@@ -46,14 +46,14 @@ CASES = [
     ("big_scale", 1, 8, 16, [64], [3e5], 64, 3, False, False),
     ("tiny_scale", 1, 8, 16, [64], [1e-20], 64, 3, False, False),
 ]
-SHAPES = {4: "128x64", 5: "128x64m", 7: "64x128", 8: "64x64"}
+SHAPES = {4: "128x64", 5: "128x64m", 6: "128x32", 7: "64x128", 8: "64x64"}
 
 
 @pytest.mark.parametrize("cfg", sorted(SHAPES), ids=[SHAPES[k] for k in sorted(SHAPES)])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_p16(eng4, case, cfg):
     name, B, H, W, cins, scales, cout, k, use_res, relu = case
-    if cout % {4: 64, 5: 64, 7: 128, 8: 64}[cfg]:
+    if cout % {4: 64, 5: 64, 6: 32, 7: 128, 8: 64}[cfg]:
         pytest.skip("tile does not divide the column count")
     seed = 700 + CASES.index(case)
     xs = [rnd(seed, "x%d" % i, (B, c, H, W)) * s for i, (c, s) in enumerate(zip(cins, scales))]
@@ -141,3 +141,67 @@ def test_conv_wgrad_p16(eng4, case, operands, monkeypatch):
     got = eng4.op_conv_wgrad([nhwc(x).to(dev) for x in xs], nhwc(dy).to(dev), k, stride).cpu()
     assert got.shape == w.grad.shape
     assert rel_err(got, w.grad) < TOL, rel_err(got, w.grad)
+
+
+S2_CASES = [("s2_64_128", 2, 16, 32, 64, 128), ("s2_128_256", 1, 24, 16, 128, 256), ("s2_256_512", 1, 8, 8, 256, 512)]
+
+
+@pytest.mark.parametrize("case", S2_CASES, ids=[c[0] for c in S2_CASES])
+def test_conv_stride2_from_p16(eng4, case):
+    """the three stride-2 3x3 layers with >= 64 input channels: the register-staged kernel copying stored pieces"""
+    name, B, H, W, cin, cout = case
+    seed = 950 + S2_CASES.index(case)
+    x = rnd(seed, "x", (B, cin, H, W)) * 7.0
+    w = rnd(seed, "w", (cout, cin, 3, 3), (2.0 / (9 * cin)) ** 0.5)
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, 2, 1))
+    dev = eng4.device
+    out = eng4.op_conv([nhwc(x).to(dev)], w.to(dev), 2, None, None, None, True)
+    assert rel_err(out.cpu().permute(0, 3, 1, 2), ref) < TOL
+
+
+@pytest.mark.parametrize("cfg", sorted(SHAPES), ids=[SHAPES[k] for k in sorted(SHAPES)])
+def test_conv_p16_under_load(eng4, cfg):
+    """a launch that fills the chip several times over (B = 8 at 96x320: 7680 patches): the DMA pipeline's waits are
+    counted, not drained -- a wrong count shows as rare wrong tiles only when the memory system is busy"""
+    B, H, W, cin, cout = 8, 96, 320, 64, 64 if cfg != 7 else 128
+    x = rnd(990, "x", (B, cin, H, W))
+    w = rnd(990, "w", (cout, cin, 3, 3), (2.0 / (9 * cin)) ** 0.5)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    dev = eng4.device
+    eng4.set_conv_cfg(cfg)
+    try:
+        outs = [eng4.op_conv([nhwc(x).to(dev)], w.to(dev), 1, None, None, None, False).cpu() for _ in range(3)]
+    finally:
+        eng4.set_conv_cfg(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_err(outs[0].permute(0, 3, 1, 2), ref) < TOL
+
+
+def test_mode4_train_step_tracks_mode3():
+    """EXPERIMENTAL mode 4 inside the train plan (P16 activations / BatchNorm-input gradients of >= 64 channels, the
+    DMA-staged convolution for every stride-1 layer that reads them): one small train step against mode 3 on the same
+    batch -- losses to 1e-4 (the fp32 budget), every gradient finite, flat gradient within 2 % (two fp32-grade paths on a
+    B=2 train-mode-BN fixture).  Mode 4 is NOT the headline and not part of the full-size parity suite: with
+    the weight gradients on their second stream its backward is not bit-reproducible run to run."""
+    import os
+    from conftest import GOLDEN_SEED
+    from model import MonoConDetector
+    stats = np.load(os.path.join(os.path.dirname(__file__), "golden", "bn_calib_seed7.npz"))
+    sd = synth.make_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
+    b = synth.make_batch(GOLDEN_SEED + 9, 2, 96, 320)
+    batch = {"img": b["img"].cuda(), "label": {k: v.cuda() for k, v in b["label"].items()}, "img_metas": b["img_metas"]}
+    out = {}
+    for mode in ("f16x2", "f16x2p"):
+        m = MonoConDetector(34, pretrained_backbone=False)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train().set_precision(mode)
+        _, loss = m(batch)
+        sum(loss.values()).backward()
+        torch.cuda.synchronize()
+        g = torch.cat([p.grad.flatten().double() for p in m.parameters() if p.grad is not None])
+        assert bool(torch.isfinite(g).all())
+        out[mode] = ({k: float(v.detach()) for k, v in loss.items()}, g)
+    for k, v in out["f16x2"][0].items():
+        assert abs(out["f16x2p"][0][k] - v) <= 1e-4 * abs(v) + 1e-6, (k, v, out["f16x2p"][0][k])
+    e = float((out["f16x2"][1] - out["f16x2p"][1]).norm() / out["f16x2"][1].norm())
+    assert e < 2e-2, e
