@@ -17,7 +17,7 @@ import torch
 from config.cfgnode import CfgNode
 from hipmonocon import dist as hdist
 from utils.decorators import decorator_timer
-from utils.engine_utils import count_trainable_params, export_cfg, load_cfg, tprint
+from utils.engine_utils import count_trainable_params, export_cfg, load_cfg, load_checkpoint_file, tprint
 
 try:
     from torch.utils.tensorboard import SummaryWriter
@@ -160,7 +160,7 @@ class BaseEngine:
             tprint("Checkpoint is saved to '%s'." % path)
 
     def load_checkpoint(self, ckpt_file: str, verbose: bool = False) -> None:
-        d = torch.load(ckpt_file, map_location='cpu', weights_only=False)
+        d = load_checkpoint_file(ckpt_file)       # (tolerant of the reference's pickled dataset / transform objects)
         for k, v in d['engine_attrs'].items():
             if k not in ('world', 'rank', 'local_rank'):
                 setattr(self, k, v)

@@ -59,7 +59,8 @@ class MonoConDetector(nn.Module):
 
     def load_checkpoint(self, ckpt_file: str):
         # the reference pickles whole engine objects; torch >= 2.6 needs weights_only=False for those
-        model_dict = torch.load(ckpt_file, map_location='cpu', weights_only=False)['state_dict']['model']
+        from utils.engine_utils import load_checkpoint_file
+        model_dict = load_checkpoint_file(ckpt_file)['state_dict']['model']
         self.load_state_dict(model_dict)
 
     def _extract_feat_from_data_dict(self, data_dict: Dict[str, Any]) -> torch.Tensor:

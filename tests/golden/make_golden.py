@@ -507,12 +507,84 @@ def dataset_pins():
 
 
 
+def ref_checkpoint(sd_stats):
+    """A checkpoint in the reference's own layout (engine/base_engine.py:155-189) WITHOUT its 235 MB of tensors.
+
+    Real reference objects produce it: MonoConDetector (parameters = the seed-7 synthetic state dict), torch.optim.AdamW
+    and the reference's CyclicScheduler as MonoconEngine.build_solver makes them (engine/monocon_engine.py:35-55), two
+    optimizer + scheduler steps on seeded synthetic gradients.  The two optimizer steps run with the group's lr forced to
+    0 for the duration of step() (restored before scheduler.step()): the moments and step counts become realistic while
+    the parameters stay BIT-identical to the synthetic state dict -- so a loader test can (a) rebuild every tensor from
+    the seed and (b) expect the eval forward of the loaded model to equal fwd_small_eval.npz.
+    What is stored: the nested dict exactly as torch.save would get it, every tensor replaced by {"__t__": i} with its
+    shape / dtype / fp64 sum / strided samples in the .npz.  engine_attrs: the attributes BaseEngine.__init__ sets that
+    survive its filter (base_engine.py:171-174 -- the missing comma there also lets `test_dataset` through: a pickled
+    MonoConDataset, which cannot be constructed here (transforms import cv2); the loader test adds a stand-in object of
+    that class path and one of an unknown class path instead)."""
+    sd = synth.make_state_dict(SEED, bn_stats=sd_stats)
+    m = ref_model(sd, train=True)
+    opt = optim.AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99))
+    sch = CyclicScheduler(opt, total_steps=1000)
+    betas_used, lrs = [], []
+    for step in range(2):
+        for n, p in m.named_parameters():
+            if n in netspec.DEAD_PARAMS:
+                p.grad = None
+            else:
+                p.grad = torch.from_numpy(synth.normalish(9000 + step, n, tuple(p.shape), 0.0, 1e-3).astype(np.float32))
+        g = opt.param_groups[0]
+        betas_used.append(g["betas"][0]); lrs.append(g["lr"])
+        keep = g["lr"]
+        g["lr"] = 0.0
+        opt.step()
+        g["lr"] = keep
+        sch.step()
+    for k, v in m.state_dict().items():            # parameters untouched (lr 0), buffers untouched (no forward ran)
+        assert torch.equal(v, sd[k].to(v.dtype).reshape(v.shape)), k
+    engine_dict = {
+        "engine_attrs": {"version": "v1.0.3", "description": "MonoCon Default Configuration", "epochs": 3, "target_epochs": 200,
+                         "global_iters": 931, "log_period": 5, "val_period": 0, "root": "./exps/ref", "writer_dir": "./exps/ref/tf_logs",
+                         "weight_dir": "./exps/ref/checkpoints", "epoch_times": [101.5, 99.25], "entire_losses": [12.5, 11.75]},
+        "state_dict": {"model": m.state_dict(), "optimizer": opt.state_dict(), "scheduler": sch.state_dict()},
+    }
+    tensors = []
+
+    def strip(o):
+        if torch.is_tensor(o):
+            tensors.append(o)
+            return {"__t__": len(tensors) - 1}
+        if isinstance(o, dict):
+            return {"__dict__": [[strip_key(k), strip(v)] for k, v in o.items()]}       # order + non-string keys survive JSON
+        if isinstance(o, (list, tuple)):
+            return {"__%s__" % type(o).__name__: [strip(v) for v in o]}
+        if isinstance(o, (int, float, str, bool)) or o is None:
+            return o
+        raise TypeError("unexpected %r in the checkpoint" % type(o))
+
+    def strip_key(k):
+        return {"__int__": k} if isinstance(k, int) else k
+
+    skeleton = strip(engine_dict)
+    out = {"skeleton": np.frombuffer(json.dumps(skeleton).encode(), dtype=np.uint8), "n_tensors": len(tensors),
+           "betas1": np.asarray(betas_used), "lrs": np.asarray(lrs), "meta": json.dumps(META)}
+    for i, t in enumerate(tensors):
+        out["t%d.shape" % i] = np.asarray(t.shape, dtype=np.int64)
+        out["t%d.dtype" % i] = str(t.dtype)
+        out["t%d.sum" % i] = float(t.double().sum())
+        flat = t.reshape(-1)
+        out["t%d.samples" % i] = flat[::max(1, flat.numel() // 16)][:16].double().numpy() if flat.numel() else np.zeros(0)
+    save("ref_checkpoint.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
         dataset_pins()
     elif len(sys.argv) > 1 and sys.argv[1] == "train_full":
         _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
         train_full(sd_stats=_stats)
+    elif len(sys.argv) > 1 and sys.argv[1] == "ref_checkpoint":
+        _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
+        ref_checkpoint(sd_stats=_stats)
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
         cond_train(sd_stats=_stats)
