@@ -10,6 +10,7 @@ namespace mc {
 hipError_t launch_pack_conv_w(const float *w_oihw, int Cout, int Cin, int ks, float *dst, int CinTotal,
                               int CoutP, int n_off, int c_off, hipStream_t st);
 hipError_t launch_zero(float *p, size_t n, hipStream_t st);
+hipError_t launch_noise_fill(float *p, size_t n, unsigned seed, hipStream_t st);   // autotuning aid (kernels_misc.hip)
 // eval-mode BN fold: scale = g*rsqrt(rv+eps), shift = b - rm*scale (g/b may be null => 1/0)
 hipError_t launch_fold_bn(const float *g, const float *b, const float *rm, const float *rv, float eps,
                           int C, float *scale, float *shift, hipStream_t st);

@@ -248,6 +248,25 @@ hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const flo
     return hipGetLastError();
 }
 
+// Plan-build aid: ReLU-shaped pseudo-random fill (half zeros, the rest uniform in (0, 4)) of a buffer the autotuner is
+// about to time kernels on.  A freshly allocated plan buffer is all zeros, and on this part a kernel that multiplies zeros
+// clocks 20-40 % higher than the same kernel on real activations (DVFS, profiles/r4_mfma_f16_power_ceiling.txt): shapes
+// were being ranked in a regime the step never runs in.
+__global__ void noise_fill_kernel(float *__restrict__ p, size_t n, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = (h & 1u) ? 0.f : (float)(h >> 8) * (4.0f / 16777216.0f);
+    }
+}
+hipError_t launch_noise_fill(float *p, size_t n, unsigned seed, hipStream_t st) {
+    size_t g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(noise_fill_kernel, dim3((unsigned)g), dim3(256), 0, st, p, n, seed);
+    return hipGetLastError();
+}
+
 // max |x| of a dense tensor -> *slot (bit pattern of a non-negative float; see amax_update): the operand-scale input of
 // the fp16-split mode for tensors that come from outside the plans' own producers
 __global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, size_t n, unsigned *__restrict__ slot, int single) {

@@ -170,6 +170,16 @@ struct TB {   // train plan builder
         p = static_cast<float *>(q);
         return p;
     }
+    // activation / gradient maps the autotuner times kernels on: optionally ReLU-shaped noise instead of zeros (see
+    // launch_noise_fill).  MEASURED (round 4, one session, B=32): 56.52 / 56.56 ms per step tuned on zeros, 56.51 / 56.62
+    // tuned on noise -- the ranking of the shapes does not depend on it; off by default (MONOCON_HIP_TUNE_NOISE=1).
+    bool tune_noise = [] { const char *e = std::getenv("MONOCON_HIP_TUNE_NOISE"); return e && std::atoi(e) != 0; }();
+    float *alloc_map(size_t n) {
+        float *p = alloc(n);
+        if (p && !h->dry_alloc && h->autotune && tune_noise && n >= 4096)
+            (void)launch_noise_fill(p, n, (unsigned)ts->bufs.size() * 7919u, nullptr);
+        return p;
+    }
     // ---- gradient maps.  The backward closures are BUILT in the order they run, so the life of a map's gradient is known
     // while building: it starts at its first writer (a data-gradient conv, a pooling / deconv backward, the residual
     // share of an affine pass) and ends with the layer that produced the map (whose affine pass turns dZ into dY in
@@ -200,7 +210,7 @@ struct TB {   // train plan builder
             }
             n.g = b.p;
         } else {
-            n.g = alloc(ne);
+            n.g = alloc_map(ne);
         }
         return n.g;
     }
@@ -218,7 +228,7 @@ struct TB {   // train plan builder
     int node(int B, int H, int W, int C, bool needs_grad = true, bool allow16 = true) {
         TNode n;
         n.t.B = B; n.t.H = H; n.t.W = W; n.t.C = C;
-        n.t.p = alloc(n.t.numel());
+        n.t.p = alloc_map(n.t.numel());
         n.t.amax = slot();
         if (allow16 && is16(C)) n.t.pexp = eslot();
         n.needs_grad = needs_grad;
