@@ -540,6 +540,12 @@ struct TB {   // train plan builder
         }
         const double n = (double)B * rows;
         ConvArgs *lc = zn.last_conv;
+        // MONOCON_HIP_BM_EPILOGUE: 0 = never take over the reductions in the data gradient's epilogue (always the reduction
+        // pass), N > 1 = only for maps of at most N pixels per image
+        {
+            static const int bm_mode = [] { const char *e = std::getenv("MONOCON_HIP_BM_EPILOGUE"); return e ? std::atoi(e) : 1; }();
+            if (bm_mode == 0 || (bm_mode > 1 && r.y.H * r.y.W > bm_mode)) lc = nullptr;
+        }
         if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
             fprintf(stderr, "[plan] bn_backward %-40s %4d ch %4dx%-4d relu %d res %d last-writer-conv %d\n", bn.c_str(), C, r.y.H,
                     r.y.W, relu, r.res >= 0, lc != nullptr);
