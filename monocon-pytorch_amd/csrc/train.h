@@ -190,6 +190,7 @@ struct WgradArgs {
     int small;                // 1: 16-input-channel layer on the LDS-free 16x16x4 kernel (ksplit = workgroups)
     int prec;                 // 1: bf16 MFMA operands, 2: 3-way bf16 split, 3: 2-way fp16 split -- where wgrad_bf16_ok() (wgrad_bf16.hip)
     int pb;                   // 32-pixel patches per staged group (2, or 1 for the split kernels)
+    int pipe;                 // != 0: the software-pipelined fp16-split kernel (wgrad_pipe.hip) with this tile; ksplit = slices
     const unsigned *amax_x[4], *amax_dy;   // prec 3: max |x| (bit patterns) of every source and of dY (see ConvArgs::amax_in)
     const int *pexp_x[4], *pexp_dy;        // mode 4: non-null = that operand is stored as P16 with this exponent (p16.h)
 };
@@ -199,6 +200,9 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
 bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride);
 hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int stride, int WN, int WC, hipStream_t st);
 int wgrad_bf16_patches(int prec);
+int wgrad_pipe_tile(const WgradArgs &a, int ks, int stride);      // wgrad_pipe.hip: 0 = not eligible
+void wgrad_pipe_plan(WgradArgs &a, int tile);
+hipError_t launch_wgrad_pipe(const WgradArgs &a, int ks, hipStream_t st);
 bool wgrad_thin_ok(const WgradArgs &a, int ks, int stride);        // conv_thin.hip: the 16 -> 16 layer on the fp16 pipe (mode 3)
 hipError_t launch_wgrad_thin(const WgradArgs &a, hipStream_t st);
 

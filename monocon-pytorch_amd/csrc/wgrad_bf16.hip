@@ -95,6 +95,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+#ifdef MC_EXP_PHASE_DELAY
+__device__ int g_phase_delay = 0, g_phase_mode = 0;
+__device__ unsigned *g_lds_dbg = nullptr;
+#endif
 template <int KS, int S, int WN, int WC, int SPL, bool X16 = false, bool D16 = false>
 // X16 / D16 (mode 4, SPL == 2): that operand is stored as P16 (p16.h) -- already scaled and split by its producer, so its
 // staging only transposes (two 8-byte loads per pixel and channel quad, a bit-field merge per packed pixel pair)
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
     for (int i = 0; i < NID; ++i) {
         const int e = tid + NT * i, item = (e / NC4) % 16;
         const int my = item / 4, mx = (item % 4) * 2;
-        d_mx[i] = (dn_ok && e < DP) ? mx : -DEAD;
+        d_mx[i] = (dn_ok && e < DP) ? mx : DEAD;
         d_stat[i] = D16 ? (my * a.Wout + mx) * a.dy_ld * 4 + p16_quad_off((n0 >> 2) + dn4)
                         : ((my * a.Wout + mx) * a.dy_ld + n0 + dn4 * 4) * 4;
         d_dst[i] = (dn4 * 4) * DCH + lds_skew(dn4 * 4) + my * 16 + mx * 2;
@@ -211,17 +215,22 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
         const int oy = prow * 4, ox = valid ? (pp - prow * a.ppr) * 8 : DEAD;
         const int xb = (oy * S * a.Win + ox * S) * Cs * 4;
         const int db = (oy * a.Wout + ox) * a.dy_ld * 4;
+        // (one UNSIGNED compare per pixel: with `xx >= 0 && xx < W` hipcc branches on the shared half of the two conditions
+        //  and, since both arms load into the same registers, puts s_waitcnt vmcnt(0) between them -- a full memory latency
+        //  in front of the MFMAs of every group.  Dead items carry a column far outside either way.)
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
             const int xx = ox * S + x_ix[i];
-            xv[slot][p][i][0] = ld_quad<X16>(r_x, (xx >= 0 && xx < a.Win) ? xb + x_stat[i] : BUF_OOB);
-            xv[slot][p][i][1] = ld_quad<X16>(r_x, (xx + XSTEP >= 0 && xx + XSTEP < a.Win) ? xb + x_stat[i] + XSTEP * Cs * 4 : BUF_OOB);
+            const bool in0 = (unsigned)xx < (unsigned)a.Win, in1 = (unsigned)(xx + XSTEP) < (unsigned)a.Win;
+            xv[slot][p][i][0] = ld_quad<X16>(r_x, in0 ? xb + x_stat[i] : BUF_OOB);
+            xv[slot][p][i][1] = ld_quad<X16>(r_x, in1 ? xb + x_stat[i] + XSTEP * Cs * 4 : BUF_OOB);
         }
 #pragma unroll
         for (int i = 0; i < NID; ++i) {
             const int xx = ox + d_mx[i];
-            dv[slot][p][i][0] = ld_quad<D16>(r_d, (xx >= 0 && xx < a.Wout) ? db + d_stat[i] : BUF_OOB);
-            dv[slot][p][i][1] = ld_quad<D16>(r_d, (xx >= 0 && xx + 1 < a.Wout) ? db + d_stat[i] + a.dy_ld * 4 : BUF_OOB);
+            const bool in0 = (unsigned)xx < (unsigned)a.Wout, in1 = (unsigned)(xx + 1) < (unsigned)a.Wout;
+            dv[slot][p][i][0] = ld_quad<D16>(r_d, in0 ? db + d_stat[i] : BUF_OOB);
+            dv[slot][p][i][1] = ld_quad<D16>(r_d, in1 ? db + d_stat[i] + a.dy_ld * 4 : BUF_OOB);
         }
     };
     // piece q of (a, b): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (mode 2), packed pixel pair per channel
@@ -272,6 +281,16 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
     const unsigned char *a_base = dyt + (wn * 32 + lc) * DCH + lds_skew(wn * 32 + lc) + g * 16;
     const unsigned char *b_base = xt + (wc * 32 + lc) * XCH + lds_skew(wc * 32 + lc) + g * S * XROW;
 
+#ifdef MC_EXP_PHASE_DELAY
+    // experiment: the second workgroup of a CU (LDS base != 0) starts late, so that its staging phases fall into the other
+    // workgroup's MFMA phases instead of coinciding with its staging phases
+    {
+        const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);   // HW_REG_LDS_ALLOC, all 32 bits
+        if (g_lds_dbg && threadIdx.x == 0) g_lds_dbg[blockIdx.x] = la;
+        if (g_phase_mode == 0 ? (la & 0xfff) != 0 : blockIdx.x >= gridDim.x / 2)
+            for (int i = 0; i < g_phase_delay; ++i) __builtin_amdgcn_s_sleep(8);      // 512 cycles each
+    }
+#endif
 #pragma unroll
     for (int d = 0; d < PD; ++d)
         if (g_begin + d < g_end) {
@@ -287,6 +306,14 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
 #ifndef MC_EXP_NO_STORE
 #pragma unroll
         for (int p = 0; p < PB; ++p) store(p, d);
+#else
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {      // the loads stay (and are waited for), the split + LDS writes go
+#pragma unroll
+            for (int i = 0; i < NIX; ++i) asm volatile("" ::"v"(xv[d][p][i][0]), "v"(xv[d][p][i][1]));
+#pragma unroll
+            for (int i = 0; i < NID; ++i) asm volatile("" ::"v"(dv[d][p][i][0]), "v"(dv[d][p][i][1]));
+        }
 #endif
         __syncthreads();
 #ifndef MC_EXP_NO_FETCH

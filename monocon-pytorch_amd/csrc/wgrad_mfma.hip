@@ -399,6 +399,7 @@ static bool wgrad_sources_ok(const WgradArgs &a) {
 
 void wgrad_plan(WgradArgs &a, int ks, int stride) {
     a.small = 0;
+    a.pipe = 0;
     if (wgrad_is_small(a, ks, stride)) {
         a.small = 1;
         const int rows = a.B * a.Hout;
@@ -407,6 +408,7 @@ void wgrad_plan(WgradArgs &a, int ks, int stride) {
         a.ppr = a.ppi = a.groups_per_img = 0;
         return;
     }
+    if (const int tile = wgrad_pipe_tile(a, ks, stride)) { wgrad_pipe_plan(a, tile); return; }
     int WN, WC;
     wgrad_shape(a, &WN, &WC);
     a.n_tiles = (a.Cout + 32 * WN - 1) / (32 * WN);
@@ -432,7 +434,9 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
         for (int i = 0; i < a.nsrc; ++i) any16 = any16 || a.pexp_x[i];
         if (any16 && (a.small || !(a.prec == 3 && wgrad_bf16_ok(a, ks, stride)))) return hipErrorInvalidValue;
     }
-    if (a.small && wgrad_thin_ok(a, ks, stride)) {
+    if (a.pipe) {
+        e = launch_wgrad_pipe(a, ks, st);
+    } else if (a.small && wgrad_thin_ok(a, ks, stride)) {
         e = launch_wgrad_thin(a, st);
     } else if (a.small) {
         if (stride == 1 && a.Cout == 16) hipLaunchKernelGGL((wgrad_small_kernel<1, 1>), dim3(a.ksplit), dim3(256), 0, st, a);

@@ -152,6 +152,9 @@ WG_CASES = [
     ("b16wg_k1_root4", 1, 12, 16, [128, 128, 64, 128], 128, 1),
     ("b16wg_k1_32_64", 2, 8, 8, [32], 64, 1),
     ("b16wg_256_256_12x24", 2, 12, 24, [256], 256, 3),
+    ("b16wg_128_64", 1, 8, 16, [128], 64, 3),
+    ("b16wg_odd_64_128", 1, 6, 10, [64], 128, 3),
+    ("b16wg_cat_64_64_128", 1, 10, 20, [64, 64], 128, 3),
 ]
 
 
@@ -330,6 +333,35 @@ def test_wgrad_split_emulation_is_fp32_accurate(eng_split, case):
     dev = eng_split.device
     got = eng_split.op_conv_wgrad([nhwc(x).to(dev) for x in xs], nhwc(dy).to(dev), k, 1).cpu()
     assert rel_err(got, w.grad) < 5e-6
+
+
+@pytest.mark.parametrize("blocks", [1, 2, 3, 7])
+@pytest.mark.parametrize("case", [c for c in WG_CASES if c[6] == 3 and sum(c[4]) % 64 == 0 and c[5] in (64, 128, 256)],
+                         ids=lambda c: c[0].replace("b16wg", "pipe"))
+def test_wgrad_pipeline_long_pixel_loops(case, blocks, monkeypatch):
+    """mode 3, stride 1, 3x3: the software-pipelined kernel (wgrad_pipe.hip) with so few workgroups that each one walks many
+    pixel groups (odd and even counts, the two tile buffers and register sets in steady state), against autograd in fp64
+    and against the two-barrier kernel it replaces."""
+    from hipmonocon.engine import Engine
+    name, B, H, W, cins, cout, k = case
+    seed = 990 + WG_CASES.index(case)
+    xs = [rnd(seed, "x%d" % i, (B, c, H, W)) for i, c in enumerate(cins)]
+    dy = rnd(seed, "dy", (B, cout, H, W))
+    w = torch.zeros(cout, sum(cins), k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(torch.cat(xs, 1).double(), w, None, 1, 1).backward(dy.double())
+    eng = Engine()
+    try:
+        eng.set_precision(3)
+        monkeypatch.setenv("MONOCON_HIP_WGRAD_PIPE_BLOCKS", str(blocks))
+        monkeypatch.setenv("MONOCON_HIP_WGRAD_PIPE", "2")          # every tile, the opt-in 64 x 64 one included
+        got = eng.op_conv_wgrad([nhwc(x).cuda() for x in xs], nhwc(dy).cuda(), k, 1).cpu()
+        monkeypatch.setenv("MONOCON_HIP_WGRAD_PIPE", "0")
+        old = eng.op_conv_wgrad([nhwc(x).cuda() for x in xs], nhwc(dy).cuda(), k, 1).cpu()
+        eng.set_precision(0)
+    finally:
+        eng.close()
+    assert rel_err(got, w.grad) < 5e-6
+    assert rel_err(got, old) < 2e-6
 
 
 @pytest.mark.parametrize("mode,tol", [(1, 2e-2), (2, 5e-6), (3, 5e-6)], ids=["bf16", "split", "f16x2"])
