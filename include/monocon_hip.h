@@ -335,7 +335,11 @@ int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], dou
  * partial products per multiply accumulated in fp32; as close to the fp64 reference as the fp32 MFMA path (same
  * parity tolerances), ~2.7x its matrix rate.  3: fp32 EMULATED on the fp16 pipe -- every operand tensor scaled by the
  * power of two its max |x| dictates, split into two fp16 pieces, three partial products per multiply; same parity
- * tolerances, half the matrix work of mode 2.  Re-pack (mc_pack_params) before the next forward. */
+ * tolerances, half the matrix work of mode 2.  4 (round 4, EXPERIMENTAL): the arithmetic of mode 3 with the >= 64-channel
+ * activations / BatchNorm-input gradients of the train plan stored pre-split ("P16", csrc/p16.h: the two fp16 pieces of
+ * x * 2^e per element, one producer-chosen exponent per tensor) and both MFMA operands DMA-staged into LDS
+ * (csrc/conv_p16.hip); forward equal to mode 3 to 1e-5, slower in the step, not a bench leg.
+ * Re-pack (mc_pack_params) before the next forward. */
 int mc_set_precision(mc_handle *h, int mode);
 /* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
  * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel, 32 = the LDS-free

@@ -199,7 +199,10 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
     // raw fp32 data of the pixel groups in flight; PD = how many groups ahead the loads run.  Two ahead (24 more registers)
     // was tried in round 3 on a Little's-law argument (2 workgroups per CU x 23 KB in flight): A/B in one session 59.5 ms
     // (PD 1) vs 60.1 ms (PD 2) per step -- slower; it stays at one.
-    constexpr int PD = 1;
+#ifndef MC_WG16_PD
+#define MC_WG16_PD 1
+#endif
+    constexpr int PD = MC_WG16_PD;
     f32x4 xv[PD][PB][NIX][2], dv[PD][PB][NID][2];
     auto fetch = [&](int gi, int p, int slot) {
         // (wave-uniform by construction; the integer division runs on the vector ALU, so say so -- otherwise every
