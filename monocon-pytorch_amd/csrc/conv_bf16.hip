@@ -106,6 +106,17 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     const int img = mchunk / a.chunks, chunk = mchunk % a.chunks;
     const int n0 = nt * BNT;
 
+    // SPL == 2: the max-|x| words of the input tensor(s) are REQUESTED first thing and reduced only when the first staged
+    // tile is about to be converted (below, behind the weight / coefficient / staging loads): read where the scale is
+    // declared, every workgroup started with one exposed memory round trip per source of the virtual concat -- a short-K
+    // layer (64 channels: 3.6 us of matrix work per workgroup) has nothing to hide it behind.
+    unsigned am_raw[4] = {0u, 0u, 0u, 0u};
+    if constexpr (SPL == 2 && !P16S) {
+        const int al = lane < AMAX_SUB ? lane * AMAX_STRIDE : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) am_raw[i] = a.amax_in[i < a.nsrc ? i : 0][al];      // (extra copies of source 0: harmless)
+    }
+
     if (tid < PB) {
         const int pp = chunk * PB + tid;
         const int valid = pp < a.ppi;
@@ -121,16 +132,27 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     // main accumulator takes exactly as many additions as the fp32 MFMA path (its round-off, not the exactness of the
     // products, is what limits the emulation) and the minor sum's round-off is 2^-8 smaller; folded in once at the end.
     // SPL == 2: operand scale 2^e_a (activations; one scale for all sources of a virtual concat: the largest maximum
-    // decides) and the exact inverse of both scales for the epilogue
+    // decides) and the exact inverse of both scales for the epilogue -- set by operand_scales() below
     float a_scale = 1.f, omul = 1.f;
-    if constexpr (SPL == 2) {
-        unsigned am = 0u;
-        if constexpr (!P16S)
-            for (int i = 0; i < a.nsrc; ++i) { const unsigned v = amax_read(a.amax_in[i]); am = v > am ? v : am; }
-        const int ea = P16S ? *a.pexp[0] : f16_scale_exp(am), ew = f16_scale_exp(*a.amax_w);
-        a_scale = exp2i(ea);
-        omul = exp2i(-ea) * exp2i(-ew);
-    }
+    auto operand_scales = [&] {
+        if constexpr (SPL == 2) {
+            int ea;
+            if constexpr (P16S) {
+                ea = *a.pexp[0];
+            } else {
+                unsigned v = am_raw[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i) v = am_raw[i] > v ? am_raw[i] : v;
+                v = lane < AMAX_SUB ? v : 0u;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
+                ea = f16_scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)v));
+            }
+            const int ew = f16_scale_exp(*a.amax_w);
+            a_scale = exp2i(ea);
+            omul = exp2i(-ea) * exp2i(-ew);
+        }
+    };
     constexpr int NACC = SPL >= 2 ? 2 : 1;
     f32x16 acc[WTM][WTN], accm[NACC == 2 ? WTM : 1][NACC == 2 ? WTN : 1];
 #pragma unroll
@@ -223,8 +245,11 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
             const int iy = pix / IW, ix = pix % IW;
             const int y = pinfo[p * 4 + 1] * S - PAD + iy;
             const int x = pinfo[p * 4 + 2] * S - PAD + ix;
-            const bool ok = e < TOTAL && pinfo[p * 4 + 3] && y >= 0 && y < a.Hin && x >= 0 && x < a.Win;
-            voff[i] = ok ? (P16S ? (y * a.Win + x) * cs * 4 + (c4 >> 1) * 32 + (c4 & 1) * 8 : ((y * a.Win + x) * cs + c4 * 4) * 4) : BUF_OOB;
+            // (bitwise, unsigned: `a && b && ...` becomes a chain of branches, each with its own LDS round trip for pinfo)
+            const bool ok = (e < TOTAL) & (pinfo[p * 4 + 3] != 0) & ((unsigned)y < (unsigned)a.Hin) & ((unsigned)x < (unsigned)a.Win);
+            int off = P16S ? (y * a.Win + x) * cs * 4 + (c4 >> 1) * 32 + (c4 & 1) * 8 : ((y * a.Win + x) * cs + c4 * 4) * 4;
+            asm volatile("" : "+v"(off));      // computed for every lane, then selected: no branch around the multiplies
+            voff[i] = ok ? off : BUF_OOB;
             sdst[i] = PLANAR ? (c4 >> 1) * CPL + (p >> 1) * PPB + (iy * RS + ix + IW * (p & 1)) * 16 + (c4 & 1) * 8
                              : (int)(stage_dst - lds_raw) + i * (NT / C4) * ROWB;
         }
@@ -278,6 +303,8 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #pragma unroll
         for (int i = 0; i < NIT; ++i) pv[i] = stage_load(r_in, voff[i], 0);
     }
+    __builtin_amdgcn_sched_barrier(0);      // (the reduction must not be scheduled back up in front of the staging loads)
+    operand_scales();
     for (bool first = true;; first = false) {
         [[maybe_unused]] unsigned long long tp_a = TP_NOW();
         if (!first) __syncthreads();
