@@ -152,37 +152,54 @@ hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, c
 // 96x320 maps.  Walking them channel by channel (one workgroup per channel, 8 bytes out of every Cstride*8) uses a
 // sliver of each cache line; this pre-pass reads whole rows (thread = channel, consecutive 8-byte pairs) and folds
 // FOLD_ROWS of them into one row of doubles, which the finalise kernels then finish.  Fixed order throughout.
-constexpr int FOLD_ROWS = 128, FOLD_MIN_NB = 2048;
+// (round 4: 64 rows per workgroup, thread = (row group, channel PAIR) with 16-byte loads, eight rows in flight -- the
+//  128-row version walked its rows four 8-byte loads at a time from 60 workgroups: 38 us per launch for 8 MB, 28 launches
+//  a step)
+constexpr int FOLD_ROWS = 64, FOLD_MIN_NB = 2048;
 __global__ __launch_bounds__(256) void partial_fold_kernel(const float *__restrict__ partial, int nb, int Cstride, int C,
                                                            double *__restrict__ out /*[blocks][C][2]*/) {
-    __shared__ double red[256][2];
+    __shared__ double red[256][4];
     const int r0 = blockIdx.x * FOLD_ROWS, r1 = min(nb, r0 + FOLD_ROWS);
-    const int CG = C < 256 ? C : 256, RG = 256 / CG;          // thread = (row group, channel)
+    const int C2 = C >> 1, S4 = Cstride >> 1;                 // channel pairs; float4s per row (C and Cstride are even)
+    const int CG = C2 < 256 ? C2 : 256, RG = 256 / CG;        // thread = (row group, channel pair)
     const int cl = threadIdx.x % CG, rg = threadIdx.x / CG;
-    for (int c0 = 0; c0 < C; c0 += CG) {
-        const int c = c0 + cl;
-        double s1 = 0, s2 = 0;
-        if (rg < RG && c < C) {
-            const float2 *p = reinterpret_cast<const float2 *>(partial) + (size_t)(r0 + rg) * Cstride + c;
-            const size_t step = (size_t)RG * Cstride;
+    const f32x4 *base = reinterpret_cast<const f32x4 *>(partial);
+    for (int c0 = 0; c0 < C2; c0 += CG) {
+        const int cp = c0 + cl;
+        double s[4] = {0, 0, 0, 0};
+        if (rg < RG && cp < C2) {
+            const f32x4 *p = base + (size_t)(r0 + rg) * S4 + cp;
+            const size_t step = (size_t)RG * S4;
             int r = r0 + rg;
-            for (; r + 3 * RG < r1; r += 4 * RG, p += 4 * step) {
-                const float2 v0 = p[0], v1 = p[step], v2 = p[2 * step], v3 = p[3 * step];
-                s1 += v0.x; s2 += v0.y; s1 += v1.x; s2 += v1.y; s1 += v2.x; s2 += v2.y; s1 += v3.x; s2 += v3.y;
+            for (; r + 7 * RG < r1; r += 8 * RG, p += 8 * step) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[u * step];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[j] += v[u][j];
             }
-            for (; r < r1; r += RG, p += step) { const float2 v = *p; s1 += v.x; s2 += v.y; }
+            for (; r < r1; r += RG, p += step) {
+                const f32x4 v = *p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += v[j];
+            }
         }
-        red[threadIdx.x][0] = s1; red[threadIdx.x][1] = s2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
         __syncthreads();
-        if (rg == 0 && c < C) {
-            for (int g = 1; g < RG; ++g) { s1 += red[g * CG + cl][0]; s2 += red[g * CG + cl][1]; }
-            out[((size_t)blockIdx.x * C + c) * 2] = s1;
-            out[((size_t)blockIdx.x * C + c) * 2 + 1] = s2;
+        if (rg == 0 && cp < C2) {
+            for (int g = 1; g < RG; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += red[g * CG + cl][j];
+            double *o = out + ((size_t)blockIdx.x * C + 2 * cp) * 2;
+            o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
         }
         __syncthreads();
     }
 }
-size_t partial_fold_doubles(int nb, int C) { return nb >= FOLD_MIN_NB ? (size_t)((nb + FOLD_ROWS - 1) / FOLD_ROWS) * C * 2 : 0; }
+size_t partial_fold_doubles(int nb, int C) { return (nb >= FOLD_MIN_NB && C % 2 == 0) ? (size_t)((nb + FOLD_ROWS - 1) / FOLD_ROWS) * C * 2 : 0; }
 
 // ------------------------------------------------------------------ BatchNorm (train) finalise
 // partial: [nb][Cstride][2] sums of (y - shift), (y - shift)^2 over n = nb * rows values per channel.
