@@ -1130,6 +1130,18 @@ static int backward_impl(mc_handle *h, TrainState *ts, const float *grad_losses,
             HIPCHK(h, hipStreamWaitEvent(ts->side, ts->side_ev[k], 0));
             if (ts->bwd[i](h, ts->side)) return -1;
             if (k < ts->side_fin.size() && ts->side_fin[k]) HIPCHK(h, hipEventRecord(ts->side_fin[k], ts->side));
+            {   // debugging aid: MONOCON_HIP_SIDE_SYNC=lo:hi makes the main stream wait for side closures lo <= k < hi
+                static const std::pair<int, int> rng = [] {
+                    const char *e = std::getenv("MONOCON_HIP_SIDE_SYNC");
+                    int lo = 0, hi = 0;
+                    if (e && std::sscanf(e, "%d:%d", &lo, &hi) != 2) lo = hi = 0;
+                    return std::make_pair(lo, hi);
+                }();
+                if ((int)k >= rng.first && (int)k < rng.second) {
+                    HIPCHK(h, hipEventRecord(ts->side_done, ts->side));
+                    HIPCHK(h, hipStreamWaitEvent(st, ts->side_done, 0));
+                }
+            }
             ++k;
             used_side = true;
         } else {
