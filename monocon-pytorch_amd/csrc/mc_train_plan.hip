@@ -946,7 +946,12 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     if (ts->dual) {
         size_t nside = 0;
         for (char c : ts->bwd_side) nside += c != 0;
-        if (hipStreamCreateWithFlags(&ts->side, hipStreamNonBlocking) != hipSuccess ||
+        // MONOCON_HIP_SIDE_PRIORITY = low / high: the weight-gradient stream below / above the caller's stream in the
+        // hardware queues' priority order (default: the same)
+        int prio = 0, lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = numerically greatest = least urgent
+        if (const char *pe = std::getenv("MONOCON_HIP_SIDE_PRIORITY")) prio = pe[0] == 'l' ? lo : (pe[0] == 'h' ? hi : 0);
+        if (hipStreamCreateWithPriority(&ts->side, hipStreamNonBlocking, prio) != hipSuccess ||
             hipEventCreateWithFlags(&ts->side_done, hipEventDisableTiming) != hipSuccess) ts->dual = false;
         ts->side_ev.resize(ts->dual ? nside : 0);
         for (auto &ev : ts->side_ev)

@@ -418,7 +418,11 @@ void wgrad_plan(WgradArgs &a, int ks, int stride) {
     a.pb = (a.prec >= 1 && wgrad_bf16_ok(a, ks, stride)) ? wgrad_bf16_patches(a.prec) : 2;
     a.groups_per_img = (a.ppi + a.pb - 1) / a.pb;
     const long long G = (long long)a.B * a.groups_per_img;
-    int ks_ = 512 * 4 / (WN * WC) / (a.n_tiles * a.c_tiles);   // two resident 4-wave workgroups per CU
+    // two resident 4-wave workgroups per CU (MONOCON_HIP_WGRAD_BLOCKS: experiment knob, e.g. 256 = one per CU, which
+    // leaves half of every SIMD's registers to whatever the main stream runs beside it)
+    const char *eb = std::getenv("MONOCON_HIP_WGRAD_BLOCKS");
+    const int target = eb ? std::atoi(eb) : 512;
+    int ks_ = target * 4 / (WN * WC) / (a.n_tiles * a.c_tiles);
     if (ks_ < 1) ks_ = 1;
     if (ks_ > G) ks_ = (int)G;
     a.ksplit = ks_;

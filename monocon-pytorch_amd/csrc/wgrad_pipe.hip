@@ -59,7 +59,8 @@ template <int N> __device__ __forceinline__ void wp_wait_vm() { asm volatile("s_
 __device__ __forceinline__ void wp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int KS, int WN, int WC, int WK>
-__global__ __launch_bounds__(64 * WN * WC * WK, 1) void wgrad_pipe_kernel(const WgradArgs a) {
+// (the 4-wave build is meant to SHARE a CU with whatever the main stream runs: at most half of a SIMD's registers)
+__global__ __launch_bounds__(64 * WN * WC * WK, WN * WC * WK == 4 ? 2 : 1) void wgrad_pipe_kernel(const WgradArgs a) {
     using Cfg = WgPipeCfg<KS, WN, WC, WK>;
     constexpr int NB = Cfg::NB, CB = Cfg::CB, NT = Cfg::NT, PAD = Cfg::PAD, IH = Cfg::IH, IW = Cfg::IW, T = Cfg::T;
     constexpr int XROW = Cfg::XROW, XCH = Cfg::XCH, DCH = Cfg::DCH, XPL = Cfg::X_PLANE, DPL = Cfg::D_PLANE, BUF = Cfg::BUF;
@@ -297,6 +298,14 @@ static hipError_t launch_wp(const WgradArgs &a, hipStream_t st) {
 }
 
 // tile of the pipelined kernel for this layer (0: not eligible): 1 = 128n x 64c, 2 = 64n x 128c, 3 = 64n x 64c (two K halves)
+// -- the 8-wave builds, which own a CU while they run -- and 4 = 64n x 64c on FOUR waves, which leaves half of the registers
+// and 72 KB of LDS of every CU to whatever the main stream runs beside it.
+// MONOCON_HIP_WGRAD_PIPE: 0 = off (the two-barrier kernel everywhere), 1 (default) = tile 4 for every eligible layer,
+// 2 = tiles 1 / 2, 3 = tiles 1 / 2 / 3.  MEASURED (B = 32 train step, one session): per launch the 8-wave tiles are the
+// fastest (weight-gradient bucket alone 12.45 ms, tile 4: 13.7), but the weight gradients run on their own stream BESIDE
+// the data-gradient chain, and an 8-wave workgroup (8 x 244 registers, 116-148 KB LDS) shares its CU with nothing: the two
+// streams then merely take turns (sum of the three buckets 55.8 ms, step 55.3).  With tile 4 the element-wise passes of the
+// main stream (HBM-bound, few registers) and one conv workgroup per CU run under the weight gradients: step 54.8 -> 53.9 ms.
 int wgrad_pipe_tile(const WgradArgs &a, int ks, int stride) {
     const char *en = std::getenv("MONOCON_HIP_WGRAD_PIPE");
     const int enabled = en ? std::atoi(en) : 1;
@@ -309,15 +318,16 @@ int wgrad_pipe_tile(const WgradArgs &a, int ks, int stride) {
             if (a.nsrc > 1 && a.src[i].C % m) return false;
         return true;
     };
+    if (enabled == 1) return (a.Cout % 64 == 0 && a.Cin % 64 == 0 && src_mult(64)) ? 4 : 0;
     // (a last, half-filled 128-row tile -- the fused 64 -> 576 head conv -- still beats nine 64-row tiles)
     if (a.Cout >= 128 && a.Cout % 64 == 0 && a.Cin % 64 == 0 && src_mult(64)) return 1;
     if (a.Cout == 64 && a.Cin % 128 == 0 && src_mult(128)) return 2;
-    // the 64 x 64 tile (two K halves) only ties with the two-barrier kernel (222-244 vs 235-246 us): opt-in (MONOCON_HIP_WGRAD_PIPE=2)
-    if (enabled >= 2 && a.Cout == 64 && a.Cin % 64 == 0 && src_mult(64)) return 3;
+    // the 64 x 64 tile (two K halves) only ties with the two-barrier kernel (222-244 vs 235-246 us)
+    if (enabled >= 3 && a.Cout == 64 && a.Cin % 64 == 0 && src_mult(64)) return 3;
     return 0;
 }
 void wgrad_pipe_plan(WgradArgs &a, int tile) {
-    const int NB = tile == 1 ? 128 : 64, CB = tile == 2 ? 128 : 64, WK = tile == 3 ? 2 : 1;
+    const int NB = tile == 1 ? 128 : 64, CB = tile == 2 ? 128 : 64, WK = tile == 3 ? 2 : 1;       // (tile 4: 64 x 64, 4 waves)
     a.pipe = tile;
     a.small = 0;
     a.pb = 1;
@@ -341,6 +351,7 @@ hipError_t launch_wgrad_pipe(const WgradArgs &a, int ks, hipStream_t st) {
     case 1: return launch_wp<3, 4, 2, 1>(a, st);
     case 2: return launch_wp<3, 2, 4, 1>(a, st);
     case 3: return launch_wp<3, 2, 2, 2>(a, st);
+    case 4: return launch_wp<3, 2, 2, 1>(a, st);
     default: return hipErrorInvalidValue;
     }
 }

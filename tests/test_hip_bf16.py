@@ -336,9 +336,10 @@ def test_wgrad_split_emulation_is_fp32_accurate(eng_split, case):
 
 
 @pytest.mark.parametrize("blocks", [1, 2, 3, 7])
+@pytest.mark.parametrize("tiles", [1, 3], ids=["shared4w", "full8w"])
 @pytest.mark.parametrize("case", [c for c in WG_CASES if c[6] == 3 and sum(c[4]) % 64 == 0 and c[5] in (64, 128, 256)],
                          ids=lambda c: c[0].replace("b16wg", "pipe"))
-def test_wgrad_pipeline_long_pixel_loops(case, blocks, monkeypatch):
+def test_wgrad_pipeline_long_pixel_loops(case, blocks, tiles, monkeypatch):
     """mode 3, stride 1, 3x3: the software-pipelined kernel (wgrad_pipe.hip) with so few workgroups that each one walks many
     pixel groups (odd and even counts, the two tile buffers and register sets in steady state), against autograd in fp64
     and against the two-barrier kernel it replaces."""
@@ -353,7 +354,7 @@ def test_wgrad_pipeline_long_pixel_loops(case, blocks, monkeypatch):
     try:
         eng.set_precision(3)
         monkeypatch.setenv("MONOCON_HIP_WGRAD_PIPE_BLOCKS", str(blocks))
-        monkeypatch.setenv("MONOCON_HIP_WGRAD_PIPE", "2")          # every tile, the opt-in 64 x 64 one included
+        monkeypatch.setenv("MONOCON_HIP_WGRAD_PIPE", str(tiles))   # 1: the 4-wave shared-CU tile; 3: every 8-wave tile
         got = eng.op_conv_wgrad([nhwc(x).cuda() for x in xs], nhwc(dy).cuda(), k, 1).cpu()
         monkeypatch.setenv("MONOCON_HIP_WGRAD_PIPE", "0")
         old = eng.op_conv_wgrad([nhwc(x).cuda() for x in xs], nhwc(dy).cuda(), k, 1).cpu()
