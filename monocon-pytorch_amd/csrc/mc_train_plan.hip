@@ -836,7 +836,12 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
                 return 0;
             });
         }
+        // the fused 64 -> 576 weight gradient (2 ms at B = 32, the longest launch of the backward) and the scatter of its
+        // result go to the weight-gradient stream like every other layer's: dx is a private buffer, nothing writes it again
+        // in this step (round 4: it used to run on the caller's stream, in front of the whole neck / backbone backward)
+        ts->bwd_side.resize(ts->bwd.size(), 0);
         b.emit_wgrad({feat}, dxT, CP, CP, 3, 1, dw3);
+        const size_t head_wgrad_first = ts->bwd_side.size();
         std::vector<float *> g3w, g3b;
         for (int hd = 0; hd < NUM_HEADS; ++hd) {
             g3w.push_back(b.G(std::string("head.") + HN[hd] + ".0.weight"));
@@ -848,6 +853,8 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
                 ts->ok = false;
         }
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_copy_batch(g3cb, st)); return 0; });
+        (void)head_wgrad_first;
+        ts->bwd_side.resize(ts->bwd.size(), 1);
         // dense OIHW (576,64,3,3) copy of the nine head convs for the dgrad panel
         std::vector<const float *> w3;
         for (int hd = 0; hd < NUM_HEADS; ++hd) w3.push_back(b.P(std::string("head.") + HN[hd] + ".0.weight"));
