@@ -45,8 +45,11 @@ hipError_t launch_stem_f16(const float *img, int B, int H, int W, const float *w
                            float *out, hipStream_t st, int relu, unsigned *amax_out, float *stats = nullptr,
                            const float *stat_shift = nullptr, unsigned *img_amax = nullptr);
 // the stem's weight gradient on the fp16 pipe (partials in the layout of stem_wgrad_lds_kernel; the caller reduces them)
+// (y != null: `dy` is the MASKED gradient d of the stem's activation map and dY = P d + Q y + R is formed on the fly from the
+//  BatchNorm-backward coefficients coef[16][4]; dy_amax = max |d|, y_amax = max |y|)
 hipError_t launch_stem_wgrad_f16(const float *img, const float *dy, int B, int H, int W, float *partial, int nblocks,
-                                 const unsigned *img_amax, const unsigned *dy_amax, hipStream_t st);
+                                 const unsigned *img_amax, const unsigned *dy_amax, hipStream_t st, const float *y = nullptr,
+                                 const float *coef = nullptr, const unsigned *y_amax = nullptr);
 bool stem_f16_enabled();       // false when compiled out (-DMC_NO_STEM_F16)
 hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out,

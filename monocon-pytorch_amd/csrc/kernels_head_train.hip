@@ -606,11 +606,16 @@ int stem_wgrad_blocks(int B, int H, int W) {
     return (B * ((W + 31) / 32) * ((H + 7) / 8) + STEM_WG_TILES - 1) / STEM_WG_TILES;
 }
 hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
-                             hipStream_t st, const unsigned *img_amax, const unsigned *dy_amax) {
+                             hipStream_t st, const unsigned *img_amax, const unsigned *dy_amax, const float *y, const float *coef,
+                             const unsigned *y_amax) {
     const int nb = stem_wgrad_blocks(B, H, W);
+    if (y && !(img_amax && dy_amax && stem_wgrad_use_mfma(W))) return hipErrorInvalidValue;   // the fused form: fp16-pipe kernel only
+#ifdef MC_NO_STEM_WG_F16
+    if (y) return hipErrorInvalidValue;
+#endif
 #ifndef MC_NO_STEM_WG_F16
     if (img_amax && dy_amax && stem_wgrad_use_mfma(W)) {
-        hipError_t e = launch_stem_wgrad_f16(img, dy, B, H, W, partial, nb, img_amax, dy_amax, st);
+        hipError_t e = launch_stem_wgrad_f16(img, dy, B, H, W, partial, nb, img_amax, dy_amax, st, y, coef, y_amax);
         if (e != hipSuccess) return e;
     } else
 #endif

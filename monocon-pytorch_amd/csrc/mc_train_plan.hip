@@ -131,6 +131,10 @@ struct TB {   // train plan builder
     void *last_panel16 = nullptr;   // bf16 twin of the panel the last pack_job() made
 
     static constexpr int AMAX_SLOTS = 1024, EXP_SLOTS = 1024;
+    // bn_backward(): the caller consumes (d, y, coef) itself -- no element-wise dY pass (the stem, whose dY is read by its
+    // weight gradient only); honoured on the backward-statistics-epilogue path, reported back in did_skip_affine
+    bool want_skip_affine = false, did_skip_affine = false;
+    float *skip_coef = nullptr;
     // mode 4: which tensors are stored as P16 -- activations and BatchNorm-input gradients of >= 64 channels (the 16- and
     // 32-channel maps of the stem / level0 / level1 keep fp32 and their own kernels)
     bool is16(int C) const { return h->p16 && h->prec == 3 && C >= 64 && C % 8 == 0; }
@@ -561,6 +565,17 @@ struct TB {   // train plan builder
             lc->bm_y = yp; lc->bm_z = zp; lc->bm_a = fa; lc->bm_b = fb; lc->bm_relu = relu;
             if (dslot) lc->amax_out = dslot;
             double *fold = fold_scratch(nbp, C);
+            if (want_skip_affine && !dyexp && !gres) {
+                // the epilogue also leaves max |d| (for the consumer's operand scale); only the coefficients are computed here
+                lc->amax_out = dymax;
+                ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
+                    HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, cstride, n, C, gamma, mean, rstd, dg, db, coef, st, fold));
+                    return 0;
+                });
+                did_skip_affine = true;
+                skip_coef = coef;
+                return dy;        // .p = the masked gradient d, .amax = max |d|
+            }
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, cstride, n, C, gamma, mean, rstd, dg, db, coef, st, fold));
                 if (dyexp)
@@ -642,10 +657,12 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         unsigned *zmax = ts->nodes[stem.z].t.amax;
         unsigned *imax = fused_stats ? b.slot() : nullptr;     // max |image|, left by the forward stem for its weight gradient
         ts->img_amax = imax;
+        unsigned *ymax = fused_stats ? b.slot() : nullptr;     // max |raw stem output|: operand-scale bound of the fused weight gradient
+        stem.y.amax = ymax;
         const float *sw = h->stem_w;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
             if (fused_stats) {
-                HIPCHK(hh, launch_stem_f16(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, nullptr, partial, rm, imax));
+                HIPCHK(hh, launch_stem_f16(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, ymax, partial, rm, imax));
             } else {
                 HIPCHK(hh, launch_stem(ts->img, B, H, W, sw, ones16, zeros16, yp, st, 0, hh->prec));
                 HIPCHK(hh, launch_chan_reduce(yp, nullptr, nullptr, rm, B, H * W, 16, 0, 0, partial, 16, st));
@@ -925,13 +942,20 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             b.g_release(r.z, b.last_side_closure());     // dZ / dY of this layer: last read by its weight gradient
         } else if (r.kind == REC_STEM) {
             if (!ts->nodes[r.z].ginit) continue;
+            // mode 3: the stem's dY has ONE reader, its weight gradient -- which forms it on the fly from (d, y, coefficients)
+            // instead of reading what an element-wise pass wrote (MONOCON_HIP_STEM_FUSE=0: the separate pass)
+            static const bool stem_fuse = [] { const char *e = std::getenv("MONOCON_HIP_STEM_FUSE"); return !e || std::atoi(e) != 0; }();
+            b.want_skip_affine = stem_fuse && h->prec == 3 && !h->p16 && ts->img_amax && r.y.amax && W % 4 == 0 && W >= 16;
+            b.did_skip_affine = false;
             Tensor dy = b.bn_backward(r, r.bn);
+            b.want_skip_affine = false;
+            const bool fused = b.did_skip_affine;
             float *part = b.alloc((size_t)stem_wgrad_blocks(B, H, W) * 147 * 16), *dw = b.G("backbone.base_layer.0.weight");
-            const float *dyp = dy.p;
-            const unsigned *imax = ts->img_amax, *dymax = dy.amax;
+            const float *dyp = dy.p, *yfp = fused ? r.y.p : nullptr, *cfp = fused ? b.skip_coef : nullptr;
+            const unsigned *imax = ts->img_amax, *dymax = dy.amax, *yfmax = fused ? r.y.amax : nullptr;
             ts->bwd_side.resize(ts->bwd.size(), 0);
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_stem_wgrad(ts->img, dyp, B, H, W, part, dw, st, imax, imax ? dymax : nullptr));
+                HIPCHK(hh, launch_stem_wgrad(ts->img, dyp, B, H, W, part, dw, st, imax, imax ? dymax : nullptr, yfp, cfp, yfmax));
                 return 0;
             });
             ts->bwd_side.resize(ts->bwd.size(), 1);

@@ -223,17 +223,41 @@ constexpr int GW_XT = 128, GW_P = 144, GW_ROWS = 10;          // tile width, sta
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
+// FUSED (round 4): dY is not read but formed on the fly, dY = P_c d + Q_c y + R_c, from the masked gradient d of the stem's
+// activation map (left by the backward-statistics epilogue of level0's data gradient), the raw stem output y and the
+// BatchNorm-backward coefficients -- the stem's dY has no other reader (no data gradient flows into the image), so its
+// element-wise pass (3 GB of traffic, 0.77 ms, the LAST launch of the caller's stream in a backward) does not exist any more.
+// Same fma chain as affine_bwd_kernel, i.e. the same fp32 dY; the operand scale comes from the sound bound
+// max|P| max|d| + max|Q| max|y| + max|R| (slots `dy_amax` = max |d| and `y_amax`) instead of the exact maximum of dY.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void stem_wgrad_f16_kernel(const float *__restrict__ img, const float *__restrict__ dy, int B,
                                                              int H, int W, float *__restrict__ partial,
                                                              const unsigned *__restrict__ img_amax,
-                                                             const unsigned *__restrict__ dy_amax) {
+                                                             const unsigned *__restrict__ dy_amax,
+                                                             const float *__restrict__ ybn, const float *__restrict__ coef,
+                                                             const unsigned *__restrict__ y_amax) {
     constexpr int PLANE_B = 3 * GW_ROWS * GW_P * 2;      // bytes of one piece
     __shared__ __attribute__((aligned(16))) unsigned char win[2 * PLANE_B];
     __shared__ float red[14 * 4][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int ex = f16_scale_exp(amax_read(img_amax)), ed = f16_scale_exp(amax_read(dy_amax));
+    float cP = 0.f, cQ = 0.f, cR = 0.f;            // FUSED: coefficients of this lane's channel j
+    int ed;
+    if constexpr (FUSED) {
+        const f32x4v cf = reinterpret_cast<const f32x4v *>(coef)[j];
+        cP = cf[0]; cQ = cf[1]; cR = cf[2];
+        float mP = fabsf(cP), mQ = fabsf(cQ), mR = fabsf(cR);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {          // over the 16 channels (every 16-lane group holds all of them)
+            mP = fmaxf(mP, __shfl_xor(mP, o)); mQ = fmaxf(mQ, __shfl_xor(mQ, o)); mR = fmaxf(mR, __shfl_xor(mR, o));
+        }
+        const float bound = mP * __builtin_bit_cast(float, amax_read(dy_amax)) + mQ * __builtin_bit_cast(float, amax_read(y_amax)) + mR;
+        ed = f16_scale_exp(__builtin_bit_cast(unsigned, bound));
+    } else {
+        ed = f16_scale_exp(amax_read(dy_amax));
+    }
+    const int ex = f16_scale_exp(amax_read(img_amax));
     const float x_scale = exp2i(ex), d_scale = exp2i(ed), omul = exp2i(-ex) * exp2i(-ed);
     // window row (c, r) of this lane in row group 0 / 1 (21 rows: 16 + 5; the other 11 lanes of group 1 read row 0)
     int boff[2];
@@ -301,6 +325,23 @@ __global__ __launch_bounds__(256) void stem_wgrad_f16_kernel(const float *__rest
         for (int G = 0; G < GW_XT / 32; ++G)
 #pragma unroll
             for (int t = 0; t < 8; ++t) araw[G][t] = buf_load1(r_dy, va + t * 64, (x0 + G * 32) * 64);      // beyond the row: zero
+        if constexpr (FUSED) {
+            const __amdgpu_buffer_rsrc_t r_y =
+                make_rsrc(ybn + ((size_t)b * H + (y < H ? y : 0)) * W * 16, y < H ? (unsigned)(W * 16) * 4u : 0u);
+            float yraw[GW_XT / 32][8];
+#pragma unroll
+            for (int G = 0; G < GW_XT / 32; ++G)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) yraw[G][t] = buf_load1(r_y, va + t * 64, (x0 + G * 32) * 64);
+            // (pixels beyond the row / rows beyond the image: d = y = 0 gives R, not 0 -- mask them)
+#pragma unroll
+            for (int G = 0; G < GW_XT / 32; ++G)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const bool in = y < H && x0 + G * 32 + 8 * g + t < W;
+                    araw[G][t] = in ? fmaf(cP, araw[G][t], fmaf(cQ, yraw[G][t], cR)) : 0.f;
+                }
+        }
 #pragma unroll
         for (int G = 0; G < GW_XT / 32; ++G) {
             f16x8 ah, al;
@@ -364,8 +405,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_f16_kernel(const float *__rest
 }
 
 hipError_t launch_stem_wgrad_f16(const float *img, const float *dy, int B, int H, int W, float *partial, int nblocks,
-                                 const unsigned *img_amax, const unsigned *dy_amax, hipStream_t st) {
-    hipLaunchKernelGGL(stem_wgrad_f16_kernel, dim3(nblocks), dim3(256), 0, st, img, dy, B, H, W, partial, img_amax, dy_amax);
+                                 const unsigned *img_amax, const unsigned *dy_amax, hipStream_t st, const float *y,
+                                 const float *coef, const unsigned *y_amax) {
+    if (y) {        // dy = the masked gradient d of the stem's activation map; dY is formed on the fly
+        if (!coef || !y_amax) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(stem_wgrad_f16_kernel<true>, dim3(nblocks), dim3(256), 0, st, img, dy, B, H, W, partial, img_amax, dy_amax, y,
+                           coef, y_amax);
+    } else {
+        hipLaunchKernelGGL(stem_wgrad_f16_kernel<false>, dim3(nblocks), dim3(256), 0, st, img, dy, B, H, W, partial, img_amax, dy_amax,
+                           nullptr, nullptr, nullptr);
+    }
     return hipGetLastError();
 }
 

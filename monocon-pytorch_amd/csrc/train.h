@@ -175,8 +175,10 @@ hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const floa
 hipError_t launch_splitk_reduce(const float *partial, int ksplit, int T, int Cout, int Cin, float *dw, hipStream_t st);
 int stem_wgrad_blocks(int B, int H, int W);
 // img_amax / dy_amax (mode 3): max-|x| slots of the image and of dY -> the fp16-pipe kernel (stem_f16.hip)
+// (fused form, mode 3 only: y / coef / y_amax non-null -- see launch_stem_wgrad_f16)
 hipError_t launch_stem_wgrad(const float *img, const float *dy, int B, int H, int W, float *partial, float *dw,
-                             hipStream_t st, const unsigned *img_amax = nullptr, const unsigned *dy_amax = nullptr);
+                             hipStream_t st, const unsigned *img_amax = nullptr, const unsigned *dy_amax = nullptr,
+                             const float *y = nullptr, const float *coef = nullptr, const unsigned *y_amax = nullptr);
 
 // ---- conv weight gradient (wgrad_mfma.hip)
 struct WgradArgs {
