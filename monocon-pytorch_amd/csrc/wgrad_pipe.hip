@@ -55,7 +55,6 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float s, unsigned
     lo = l;
 }
 
-template <int N> __device__ __forceinline__ void wp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int KS, int WN, int WC, int WK>
@@ -98,7 +97,6 @@ __global__ __launch_bounds__(64 * WN * WC * WK, WN * WC * WK == 4 ? 2 : 1) void 
     //      pair, channel quad), channel quad fastest
     constexpr int XC4 = CB / 4, XPAIRS = IW / 2, XP = IH * XPAIRS * XC4, NIX = (XP + NT - 1) / NT;
     constexpr int NC4 = NB / 4, DP = 4 * 4 * NC4, NID = (DP + NT - 1) / NT;
-    constexpr int NL = 2 * (NIX + NID);                       // buffer loads per thread and group
     static_assert(NT % XC4 == 0 && NT % NC4 == 0 && IW % 2 == 0, "static channel quad per thread");
     constexpr int DEAD = -(1 << 24);
     const int xc4 = tid % XC4, dn4 = tid % NC4;
@@ -255,7 +253,7 @@ __global__ __launch_bounds__(64 * WN * WC * WK, WN * WC * WK == 4 ? 2 : 1) void 
     // ---- prologue: groups g_begin (-> buffer 0) and g_begin + 1 (-> register set 1)
     if (g_begin < g_end) {
         fetch(g_begin, WpInt<0>{});
-        fetch(min(g_begin + 1, g_end - 1), WpInt<1>{});
+        fetch(min(g_begin + 1, g_end - 1), WpInt<1>{});      // (the compiler's own vmcnt before the conversion leaves these in flight)
 #pragma unroll
         for (int i = 0; i < NIX; ++i) store_x(lds_raw, WpInt<0>{}, i);
 #pragma unroll
