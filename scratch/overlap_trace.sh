@@ -8,3 +8,4 @@ PREC=f16x2 python $ROOT/scratch/train_prof.py > $OUT/plain.log 2>&1
 rm -rf $OUT/trace
 PREC=f16x2 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python $ROOT/scratch/train_prof.py > $OUT/trace.log 2>&1
 python $ROOT/scratch/overlap_report.py $(find $OUT/trace -name t_kernel_trace.csv | head -1) | tee $OUT/report.txt
+python $ROOT/scratch/stream_exclusive.py $(find $OUT/trace -name t_kernel_trace.csv | head -1) | tee -a $OUT/report.txt
