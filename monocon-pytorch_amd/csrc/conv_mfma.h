@@ -688,7 +688,9 @@ enum ConvCfgId {
     CFG_64x64 = 8,      // 2x2 waves, 1x1 tiles :  64 px x  64 ch
     CFG_COUNT = 9,
     CFG_WS = 16,        // flag: wave-specialised kernel (producer wave + double-buffered LDS)
-    CFG_SMALL = 32      // LDS-free 16x16x4 kernel for 16/32-channel 3x3 layers (conv_small.hip)
+    CFG_SMALL = 32,     // LDS-free 16x16x4 kernel for 16/32-channel 3x3 layers (conv_small.hip)
+    CFG_WRES = 64       // flag: weight-resident persistent kernel (conv_wres.hip) where the launch is eligible; the shape
+                        // bits name the tiling every other launch with this id takes (results are bit-identical)
 };
 inline ConvShape conv_shape(int cfg) {
     switch (cfg & 15) {
@@ -741,6 +743,8 @@ hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal,
 // fp16-split mode from outside the plans' own producers (op-level entry points, stage-level forwards)
 // (single_word: a weight slot -- one word; otherwise a tensor slot of AMAX_WORDS words)
 hipError_t launch_absmax(const float *x, size_t n, unsigned *slot, hipStream_t st, bool single_word = false);
+bool conv_wres_ok(const ConvArgs &a, int ks, int stride);             // conv_wres.hip: mode 3, 3x3 stride 1, one 64-channel source
+hipError_t launch_conv_wres(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved);
 bool conv_p16_ok(const ConvArgs &a, int ks, int stride);              // conv_p16.hip: mode 4, stride 1, every source P16
 bool conv_p16_cfg_ok(int cfg, int CoutP, int ks);
 hipError_t launch_conv_p16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved);

@@ -132,6 +132,10 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
             // (stride-2 3x3 layers: the register-staged kernel, whose staging then copies the pieces instead of making them)
         }
     }
+    if (a.cfg & CFG_WRES) {
+        if (conv_wres_ok(a, ks, stride)) return launch_conv_wres(a, ks, stride, st, resolved);
+        a.cfg &= ~CFG_WRES;
+    }
     if (a.prec >= 1 && conv_bf16_ok(a, ks, stride)) return launch_conv_bf16(a, ks, stride, st, resolved);
     if (ks == 3 && stride == 1) {
         return ck == 32 ? launch_shape<3, 1, 32>(a, st, resolved) : launch_shape<3, 1, 16>(a, st, resolved);

@@ -1,0 +1,292 @@
+// Round 5: the 64-channel 3x3 convolutions of precision mode 3 (f16x2) as a WEIGHT-RESIDENT, persistent kernel.
+//
+// Which launches (reference shapes): the 64 -> 64 BasicBlock convs of level2 at 1/4 resolution (model/backbone/dla.py:12-51),
+// every 64-column slice of the fused 64 -> 576 head conv (model/dense_heads/monocon_heads.py:114-131) and the per-source
+// 64 -> 64 data gradients of those layers and of the ida_2 nodes (model/backbone/dla_neck.py:94-106) -- K = 9 x 64 = 576,
+// N = 64 per workgroup.  In conv_bf16_kernel these were the laggards of the conv bucket (profiles/r4e_pmc.txt: 0.22-0.26
+// of the fp16 MFMA peak, `SQ_VALU_MFMA_BUSY` 0.43): a 128-pixel workgroup lives for ~3.5 us of matrix work and pays for
+// it a prologue (patch table, max-|x| words, coefficients), 295 KB of weight fragments re-read from L2 (every wave its
+// own 32-column half of the 147 KB panel, once per workgroup), two barriers per 32-channel chunk and an epilogue, none of
+// which overlaps its own MFMAs.
+//
+// Here: 256 workgroups (one per CU, four waves with the whole register file: __launch_bounds__(256, 1) = 512 registers per
+// lane) each walk a contiguous range of 4 x 16-pixel tiles.
+//   * weights: a wave owns ONE 32-column tile for ALL of K: its 36 K-steps x 2 pieces = 72 B fragments (288 registers)
+//     are loaded once per workgroup and stay in registers -- no weight traffic, no weight address arithmetic, no LDS for
+//     them inside the tile loop;
+//   * waves = 2 column tiles x 2 patches: the two waves of a patch share its A fragments (LDS), the two patches of a tile
+//     sit side by side in the conflict-free image of conv_bf16.hip ([piece][8-channel plane][halo row][24 slots of 16 B]);
+//   * software pipeline over tiles, ONE raw barrier per tile: while the MFMAs of tile t run out of image buffer t & 1, the
+//     raw fp32 data of tile t + 1 (in registers since the previous tile) is scaled / split into its fp16 pieces
+//     (v_fma_mix{lo,hi}_f16: two instructions per element) and written to buffer (t + 1) & 1, then the loads of tile t + 2
+//     are issued into the same registers.  Both are unconditional (past the end the last tile is fetched again: a
+//     conditional fetch makes hipcc's wait-count pass drain the queue) and are slotted BETWEEN the MFMAs of a
+//     K-step in program order (the wave is alone on its SIMD: only what sits between two MFMAs overlaps them).
+// Arithmetic, K order (32-channel chunk, tap, 16-channel step; l*h and h*l into the minor accumulator, h*h into the main
+// one, folded once) and epilogue (conv_epilogue of conv_mfma.h) are those of conv_bf16_kernel<3, 1, ..., SPL = 2>:
+// results are bit-identical to every other tiling (tests/test_hip_wres.py), so the autotuner may pick it freely.
+#include "conv_mfma.h"
+
+namespace mc {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+struct WresCfg {
+    static constexpr int NT = 256;
+    static constexpr int IH = 6, IW = 10, NPIX = IH * IW, RS = 24;
+    static constexpr int PPB = IH * RS * 16;            // one 8-channel plane of the patch pair: 6 rows x 24 slots x 16 B
+    static constexpr int CPL = PPB + 32;                 // (+32: de-phases the planes' staging stores, see conv_bf16.hip)
+    static constexpr int NPL = 8;                        // planes per piece: 64 channels
+    static constexpr int PIECE = NPL * CPL;              // 18688
+    static constexpr int TILE = 2 * PIECE;               // both fp16 pieces of one tile's halo image: 37376
+    static constexpr int PINFO = 2 * TILE;               // ring of four patch tables [slot][2 patches][4]
+    static constexpr int LDS_BYTES = PINFO + 4 * 2 * 16;
+    static constexpr int C4 = 16;                        // channel quads per pixel
+    static constexpr int TOTAL = 2 * NPIX * C4;          // staging items per tile (float4 each): 1920
+    static constexpr int NIT = (TOTAL + NT - 1) / NT;    // 8 per thread, the last half-filled ...
+    static constexpr int KDUP = NT * NIT - TOTAL;        // ... threads beyond duplicate an earlier item of their quad (128)
+    static_assert(KDUP % C4 == 0 && KDUP <= TOTAL, "duplicate items keep the thread's channel quad");
+};
+
+// (x0, x1) * s -> packed fp16 pair of the hi pieces and of the lo pieces: hi = f16(x * s), lo = f16(x * s - hi), each ONE
+// rounding of an exact fp32 value -- the same bits as the cvt / sub / cvt sequence of conv_bf16_kernel
+__device__ __forceinline__ void wres_split_pair(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+    hi = h;
+    lo = l;
+}
+
+template <bool BM>
+__global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, const int tiles_per_row, const int tiles_per_img,
+                                                           const int total_tiles, const int tiles_per_wg, const int ngroups) {
+    using C = WresCfg;
+    constexpr int CPL = C::CPL, PIECE = C::PIECE, TILE = C::TILE, RS = C::RS, IW = C::IW, NIT = C::NIT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int *const pinfo_ring = reinterpret_cast<int *>(lds_raw + C::PINFO);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wp = wave >> 1;            // column tile, patch of the pair
+    const int g = lane >> 5, li = lane & 31;
+
+    const int bid = xcd_order(blockIdx.x, gridDim.x);
+    const int grp = __builtin_amdgcn_readfirstlane(bid % ngroups);
+    const int rng = __builtin_amdgcn_readfirstlane(bid / ngroups);
+    const int t_begin = rng * tiles_per_wg;
+    const int t_end = min(t_begin + tiles_per_wg, total_tiles);
+    if (t_begin >= t_end) return;
+    const int n0 = grp * 64;
+
+    // the max-|x| words of the input: requested first, reduced behind the weight loads (conv_bf16_kernel)
+    const unsigned am_raw = a.amax_in[0][lane < AMAX_SUB ? lane * AMAX_STRIDE : 0];
+
+    // ---- the wave's weight fragments: [K-step][piece], K-step s = (chunk s / 18, tap (s % 18) / 2, half s % 2)
+    const int Cin8 = a.Cin >> 3;
+    const int w_plane = 9 * a.Cin * a.CoutP * 2;          // bytes of one piece plane of the panel
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpk16, (unsigned)(2 * w_plane));
+    const int w_lane = (g * a.CoutP + n0 + wn * 32 + li) * 16;
+    h16x8 breg[36][2];
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+        const int kc = (s / 18) * 32, tap = (s % 18) / 2, m = s % 2;
+        const int soff = (tap * Cin8 + ((kc + m * 16) >> 3)) * a.CoutP * 16;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            breg[s][q] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, w_lane, soff + q * w_plane, 0));
+    }
+    const EpiCoef<1> coef = conv_epi_coef<2, 1, BM>(a, n0, wn, li);
+
+    // ---- staging plan: item e = tid + 256 i of [patch][halo pixel][channel quad]; its place in the tile never changes
+    const int c4 = tid % C::C4;
+    int rel[NIT], relb[NIT], sdst[NIT];   // rel: (halo row - 1) and (column - 1 relative to the tile origin), packed; relb: its byte offset
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int e0 = tid + C::NT * i, e = e0 < C::TOTAL ? e0 : e0 - C::KDUP;
+        const int t = e / C::C4;
+        const int pix = t % C::NPIX, p = t / C::NPIX;
+        const int iy = pix / IW, ix = pix % IW;
+        rel[i] = ((iy - 1) & 0xffff) | ((8 * p + ix - 1) << 16);
+        relb[i] = ((iy - 1) * a.Win + 8 * p + ix - 1) * 256 + c4 * 16;
+        sdst[i] = (c4 >> 1) * CPL + (iy * RS + ix + IW * p) * 16 + (c4 & 1) * 8;
+    }
+
+    // ---- tile cursors (wave-uniform): the fetch cursor runs two tiles ahead of the compute cursor
+    struct Cursor { int img, ty, tx; };
+    auto cursor_at = [&](int t) {
+        Cursor c;
+        c.img = __builtin_amdgcn_readfirstlane(t / tiles_per_img);
+        const int r = t - c.img * tiles_per_img;
+        c.ty = __builtin_amdgcn_readfirstlane(r / tiles_per_row);
+        c.tx = r - c.ty * tiles_per_row;
+        return c;
+    };
+    auto advance = [&](Cursor &c) {
+        if (++c.tx == tiles_per_row) {
+            c.tx = 0;
+            if ((++c.ty) * tiles_per_row == tiles_per_img) { c.ty = 0; ++c.img; }
+        }
+    };
+    f32x4 pv[NIT];
+    // loads of one tile into pv, in two parts: fetch_setup (scalars, the tile's patch table into ring slot `slot`) and one
+    // fetch_item per staging item
+    int f_oy = 0, f_ox = 0, f_base = 0;
+    __amdgpu_buffer_rsrc_t f_rsrc = make_rsrc(a.src[0].p, 0u);
+    auto fetch_setup = [&](const Cursor &c, int slot) {
+        f_oy = c.ty * 4; f_ox = c.tx * 16;
+        f_rsrc = make_rsrc(a.src[0].p + (size_t)c.img * a.Hin * a.Win * 64, (unsigned)(a.Hin * a.Win * 64) * 4u);
+        f_base = (f_oy * a.Win + f_ox) * 256;
+        if (tid < 2) {
+            int *pi = pinfo_ring + (slot * 2 + tid) * 4;
+            pi[0] = c.img; pi[1] = f_oy; pi[2] = f_ox + 8 * tid; pi[3] = 1;
+        }
+    };
+    auto fetch_item = [&](int i) {
+        const int y = f_oy + (int)(short)(rel[i] & 0xffff), x = f_ox + (rel[i] >> 16);
+        // (bitwise, unsigned: one compare per coordinate, no branch -- see conv_bf16_kernel)
+        const bool ok = ((unsigned)y < (unsigned)a.Hin) & ((unsigned)x < (unsigned)a.Win);
+        int off = f_base + relb[i];
+        asm volatile("" : "+v"(off));
+        pv[i] = buf_load4(f_rsrc, ok ? off : BUF_OOB, 0);
+    };
+    auto fetch = [&](const Cursor &c, int slot) {
+        fetch_setup(c, slot);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) fetch_item(i);
+    };
+    float a_scale = 1.f, omul = 1.f;
+    // conversion of item i (in pv) into image buffer `buf`, in two halves (each slotted behind one MFMA)
+    unsigned st_h01 = 0, st_l01 = 0;
+    auto stage_a = [&](int i) { wres_split_pair(pv[i][0], pv[i][1], a_scale, st_h01, st_l01); };
+    auto stage_b = [&](int i, int buf) {
+        unsigned h23, l23;
+        wres_split_pair(pv[i][2], pv[i][3], a_scale, h23, l23);
+        unsigned char *dst = lds_raw + buf * TILE + sdst[i];
+        u32x2_t hv, lv;
+        hv[0] = st_h01; hv[1] = h23; lv[0] = st_l01; lv[1] = l23;
+        *reinterpret_cast<u32x2_t *>(dst) = hv;
+        *reinterpret_cast<u32x2_t *>(dst + PIECE) = lv;
+    };
+
+    // ---- prologue: tile t_begin -> buffer 0, tile t_begin + 1 -> registers
+    Cursor cf = cursor_at(t_begin), cc = cf;
+    fetch(cf, t_begin & 3);
+    {   // operand scales (behind the loads): 2^e_a for the staging, the exact inverse of both scales for the epilogue
+        unsigned v = lane < AMAX_SUB ? am_raw : 0u;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
+        const int ea = f16_scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)v));
+        const int ew = f16_scale_exp(*a.amax_w);
+        a_scale = exp2i(ea);
+        omul = exp2i(-ea) * exp2i(-ew);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) { stage_a(i); stage_b(i, t_begin & 1); }
+    int tf = t_begin;                  // tile index the fetch cursor stands on
+    if (tf + 1 < t_end) { ++tf; advance(cf); }
+    fetch(cf, tf & 3);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int a_off = g * CPL + ((li >> 3) * RS + (li & 7) + IW * wp) * 16;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const unsigned char *abase = lds_raw + cur * TILE + a_off;
+        auto load_a = [&](h16x8(&dst)[2], int s) {
+            const int c = s / 18, tap = (s % 18) / 2, m = s % 2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                dst[q] = *reinterpret_cast<const h16x8 *>(abase + q * PIECE + (4 * c + 2 * m) * CPL + ((tap / 3) * RS + tap % 3) * 16);
+        };
+        f32x16 acc, accm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accm[r] = 0.f; }
+        // the tile after next (clamped: past the end the last tile is fetched again and never used)
+        const bool more = tf + 1 < t_end;
+        Cursor cn = cf;
+        if (more) advance(cn);
+        const int tn = more ? tf + 1 : tf;
+        h16x8 acur[2];
+        load_a(acur, 0);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            h16x8 anext[2];
+            if (s + 1 < 36) load_a(anext, s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[1], breg[s][0], accm, 0, 0, 0);      // l * h
+            __builtin_amdgcn_sched_barrier(0);
+            if (s < NIT) stage_a(s);                       // staging of tile t + 1: one item per K-step ...
+            if (s == NIT) fetch_setup(cn, tn & 3);         // ... then the loads of tile t + 2, one item per K-step
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[0], breg[s][0], acc, 0, 0, 0);        // h * h
+            __builtin_amdgcn_sched_barrier(0);
+            if (s < NIT) stage_b(s, nxt);
+            if (s > NIT && s <= 2 * NIT) fetch_item(s - NIT - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[0], breg[s][1], accm, 0, 0, 0);      // h * l
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < 36) { acur[0] = anext[0]; acur[1] = anext[1]; }
+        }
+        cf = cn; tf = tn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += accm[r];
+        f32x16 accs[1][1];
+        accs[0][0] = acc;
+        conv_epilogue<2, 2, 1, 1, 64, BM>(a, accs, pinfo_ring + (t & 3) * 8, (cc.ty * tiles_per_row + cc.tx) * 2, cc.img, n0, wp, wn, g, li,
+                                          coef, omul);
+        advance(cc);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+// eligible: f16x2 arithmetic on fp32 sources, 3x3 stride 1, ONE 64-channel source, dense NHWC output of whole 4x16 tiles
+bool conv_wres_ok(const ConvArgs &a, int ks, int stride) {
+    if (a.prec != 3 || !a.wpk16 || !a.amax_w || ks != 3 || stride != 1) return false;
+    if (a.nsrc != 1 || a.src[0].C != 64 || a.Cin != 64 || !a.amax_in[0] || a.pexp[0]) return false;
+    if (a.CoutP % 64 || a.Hin != a.Hout || a.Win != a.Wout || a.Wout % 16) return false;
+    if ((size_t)a.Hin * a.Win * 64 * 4 >= ((size_t)1 << 31)) return false;       // 32-bit buffer offsets per image
+    return true;
+}
+
+template <bool BM>
+static hipError_t launch_wres_one(const ConvArgs &a, int tpr, int tpi, int total, int per_wg, int ngroups, int nwg, hipStream_t st) {
+    auto kern = conv_wres_kernel<BM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)WresCfg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nwg * ngroups)), dim3(256), WresCfg::LDS_BYTES, st, a, tpr, tpi, total, per_wg, ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_wres(const ConvArgs &a_in, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
+    if (!conv_wres_ok(a_in, ks, stride)) return hipErrorInvalidValue;
+    ConvArgs a = a_in;
+    a.ppr = (a.Wout + 7) / 8;
+    a.ppi = a.ppr * ((a.Hout + 3) / 4);
+    a.chunks = a.ppi;
+    if (resolved) *resolved = a;
+    const int tpr = a.Wout / 16, tpi = tpr * ((a.Hout + 3) / 4), total = a.B * tpi, ngroups = a.CoutP / 64;
+    // one workgroup per CU and column group where the work allows (>= 8 tiles each: the weight prologue is ~2 tiles of time)
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    int nwg = ncu;
+    if (total < nwg * 8) nwg = (total + 7) / 8;
+    if (nwg < 1) nwg = 1;
+    const int per_wg = (total + nwg - 1) / nwg;
+    nwg = (total + per_wg - 1) / per_wg;
+    return a.bm_y ? launch_wres_one<true>(a, tpr, tpi, total, per_wg, ngroups, nwg, st)
+                  : launch_wres_one<false>(a, tpr, tpi, total, per_wg, ngroups, nwg, st);
+}
+
+}  // namespace mc

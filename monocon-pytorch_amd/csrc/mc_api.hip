@@ -328,7 +328,8 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     auto it = h->tuned.find(key);
     if (it != h->tuned.end()) return it->second;
     static const int cand[] = {CFG_128x128, CFG_128x64, CFG_128x64m, CFG_128x32, CFG_64x128, CFG_64x64,
-                               CFG_WS | CFG_128x128, CFG_WS | CFG_128x64m, CFG_WS | CFG_64x128, CFG_WS | CFG_64x64, CFG_SMALL};
+                               CFG_WS | CFG_128x128, CFG_WS | CFG_128x64m, CFG_WS | CFG_64x128, CFG_WS | CFG_64x64, CFG_SMALL,
+                               CFG_WRES | CFG_128x64};
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return heuristic;
     ConvArgs a = a_in;
@@ -338,6 +339,7 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     for (int c : cand) {
         if (c == CFG_SMALL ? !small_ok : (a.CoutP % conv_shape(c).BNT()) != 0) continue;
         if ((c & CFG_WS) && (ks >= 10 || b16)) continue;   // no wave-specialised build of these kernels
+        if ((c & CFG_WRES) && !conv_wres_ok(a, ks, stride)) continue;
         if (p16 && !conv_p16_cfg_ok(c, a.CoutP, ks)) continue;
         a.cfg = c;
         if (launch_conv(a, ks, stride, nullptr) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm / unsupported
@@ -1131,9 +1133,9 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
 
 int mc_set_conv_cfg(mc_handle *h, int cfg) {
     if (!h) return -1;
-    if (cfg != CFG_SMALL && (cfg < 0 || (cfg & 15) >= CFG_COUNT || (cfg & ~(15 | CFG_WS))))
+    if (cfg != CFG_SMALL && (cfg < 0 || (cfg & 15) >= CFG_COUNT || (cfg & ~(15 | CFG_WS | CFG_WRES))))
         return fail(h, "mc_set_conv_cfg: unknown shape id");
-    if ((cfg & CFG_WS) && !(cfg & 15)) return fail(h, "mc_set_conv_cfg: the wave-specialised flag needs a shape");
+    if ((cfg & (CFG_WS | CFG_WRES)) && !(cfg & 15)) return fail(h, "mc_set_conv_cfg: the kernel-variant flags need a shape");
     h->force_cfg = cfg;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
@@ -1172,7 +1174,8 @@ int mc_tune_import(mc_handle *h, const int *buf, int n_ints) {
         std::vector<int> key(buf + o, buf + o + kl);
         o += kl;
         const int cfg = buf[o++];
-        if (cfg != CFG_SMALL && (cfg <= 0 || (cfg & 15) >= CFG_COUNT || (cfg & ~(15 | CFG_WS))))
+        // (a shape id is CFG_SMALL, or a tiling 1 .. CFG_COUNT - 1 with optional kernel-variant flags: a flag alone is no shape)
+        if (cfg != CFG_SMALL && (cfg <= 0 || (cfg & 15) < 1 || (cfg & 15) >= CFG_COUNT || (cfg & ~(15 | CFG_WS | CFG_WRES))))
             return fail(h, "mc_tune_import: unknown shape id %d", cfg);
         h->tuned[key] = cfg;
         ++added;
