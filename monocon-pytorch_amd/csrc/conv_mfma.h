@@ -32,6 +32,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace mc {
 
@@ -234,8 +235,10 @@ __device__ __forceinline__ EpiCoef<WTN> conv_epi_coef(const ConvArgs &a, int n0,
 template <int WM, int WN, int WTM, int WTN, int BNT, bool BM = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[WTM][WTN], const int *pinfo,
                                               int patch0, int img, int n0, int wm, int wn, int g, int li,
-                                              const EpiCoef<WTN> &coef, float omul = 1.f) {
+                                              const EpiCoef<WTN> &coef, float omul = 1.f, float *vmax_acc = nullptr) {
     // omul: power-of-two rescale of the accumulator (fp16-split mode: undoes the operand scaling, exact); 1 otherwise
+    // vmax_acc: a persistent caller (conv_wres.hip) collects this lane's max |stored value| over its calls here and commits
+    // ConvArgs::amax_out once itself (amax_commit waits for a returned load: once per workgroup, not once per tile)
     const bool do_stats = a.stats != nullptr;
     float vmax = 0.f;                            // max |stored value| of this lane (ConvArgs::amax_out)
     const bool has_res = a.res != nullptr;
@@ -268,43 +271,55 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
             if (!pv) continue;
             float ssum = 0.f, ssq = 0.f;
             if (oy0 + 4 <= a.Hout && ox0 + 8 <= a.Wout) {
-                // whole patch inside the image: wave-uniform offsets only
+                // whole patch inside the image: wave-uniform offsets only.  One straight-line copy of the body per
+                // (residual, stored-mask) combination: with the optional loads under run-time conditions in ONE body, hipcc
+                // places the s_waitcnt vmcnt(N) of the loaded values behind the join -- and on the paths WITHOUT those loads
+                // the same waits then count the patch's own stores (gfx950 retires stores on vmcnt too): every second store
+                // waited for the write acknowledgement of an earlier one (round 5, found in the ISA of conv_wres_kernel).
                 const int s_out = (oy0 * a.o_row + ox0 * a.o_px) * 4;
                 const int s_res = (oy0 * a.r_row + ox0 * a.r_px) * 4;
-                float rv[16], yv[16], zv[16];
-                if (has_res) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        rv[r] = buf_load1(r_res, v_res, s_res + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
-                }
-                if (bm) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        yv[r] = buf_load1(r_y, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
-                    if (bm_relu == 1) {
+                auto body = [&](auto res_c, auto zmask_c) {
+                    constexpr bool RES = decltype(res_c)::value, ZMASK = decltype(zmask_c)::value;
+                    float rv[16], yv[16], zv[16];
+                    if constexpr (RES) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            zv[r] = buf_load1(r_z, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+                            rv[r] = buf_load1(r_res, v_res, s_res + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
                     }
-                }
+                    if constexpr (bm) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[tm][tn][r] * sc + bi;
-                    if (has_res) v += rv[r];
-                    if (bm) {
-                        const bool on = bm_relu == 0 || (bm_relu == 1 ? zv[r] > 0.f : fmaf(yv[r], ma, mb) > 0.f);
-                        v = on ? v : 0.f;
-                        ssum += v;
-                        ssq = fmaf(v, yv[r], ssq);
-                    } else if (do_stats) {
-                        const float d = v - sh;
-                        ssum += d;
-                        ssq += d * d;
+                        for (int r = 0; r < 16; ++r)
+                            yv[r] = buf_load1(r_y, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+                        if constexpr (ZMASK) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                zv[r] = buf_load1(r_z, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+                        }
                     }
-                    v = fmaxf(v, floor_v);
-                    vmax = fmaxf(vmax, fabsf(v));
-                    buf_store1(v, r_out, v_out, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
-                }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[tm][tn][r] * sc + bi;
+                        if constexpr (RES) v += rv[r];
+                        if constexpr (bm) {
+                            const bool on = ZMASK ? zv[r] > 0.f : (bm_relu == 0 || fmaf(yv[r], ma, mb) > 0.f);
+                            v = on ? v : 0.f;
+                            ssum += v;
+                            ssq = fmaf(v, yv[r], ssq);
+                        } else if (do_stats) {
+                            const float d = v - sh;
+                            ssum += d;
+                            ssq += d * d;
+                        }
+                        v = fmaxf(v, floor_v);
+                        vmax = fmaxf(vmax, fabsf(v));
+                        buf_store1(v, r_out, v_out, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+                    }
+                };
+                using T = std::true_type;
+                using Fz = std::false_type;
+                const bool zmask = bm && bm_relu == 1;
+                if (has_res) { if (zmask) body(T{}, T{}); else body(T{}, Fz{}); }
+                else { if (zmask) body(Fz{}, T{}); else body(Fz{}, Fz{}); }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -342,7 +357,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
             }
         }
     }
-    if (a.amax_out) amax_update_wave(a.amax_out, vmax);
+    if (vmax_acc) *vmax_acc = fmaxf(*vmax_acc, vmax);
+    else if (a.amax_out) amax_update_wave(a.amax_out, vmax);
 }
 
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN, bool BM = false>

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     };
     f32x4 pv[NIT];
     // loads of one tile into pv, in two parts: fetch_setup (scalars, the tile's patch table into ring slot `slot`) and one
-    // fetch_item per staging item
+    // fetch_addr / fetch_load per staging item
     int f_oy = 0, f_ox = 0, f_base = 0;
     __amdgpu_buffer_rsrc_t f_rsrc = make_rsrc(a.src[0].p, 0u);
     auto fetch_setup = [&](const Cursor &c, int slot) {
@@ -146,18 +146,20 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
             pi[0] = c.img; pi[1] = f_oy; pi[2] = f_ox + 8 * tid; pi[3] = 1;
         }
     };
-    auto fetch_item = [&](int i) {
+    int f_voff[NIT];
+    auto fetch_addr = [&](int i) {
         const int y = f_oy + (int)(short)(rel[i] & 0xffff), x = f_ox + (rel[i] >> 16);
         // (bitwise, unsigned: one compare per coordinate, no branch -- see conv_bf16_kernel)
         const bool ok = ((unsigned)y < (unsigned)a.Hin) & ((unsigned)x < (unsigned)a.Win);
         int off = f_base + relb[i];
         asm volatile("" : "+v"(off));
-        pv[i] = buf_load4(f_rsrc, ok ? off : BUF_OOB, 0);
+        f_voff[i] = ok ? off : BUF_OOB;
     };
+    auto fetch_load = [&](int i) { pv[i] = buf_load4(f_rsrc, f_voff[i], 0); };
     auto fetch = [&](const Cursor &c, int slot) {
         fetch_setup(c, slot);
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) fetch_item(i);
+        for (int i = 0; i < NIT; ++i) { fetch_addr(i); fetch_load(i); }
     };
     float a_scale = 1.f, omul = 1.f;
     // conversion of item i (in pv) into image buffer `buf`, in two halves (each slotted behind one MFMA)
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     const int a_off = g * CPL + ((li >> 3) * RS + (li & 7) + IW * wp) * 16;
+    float vmax = 0.f;                  // max |stored value| of this lane over all its tiles (ConvArgs::amax_out)
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
         const unsigned char *abase = lds_raw + cur * TILE + a_off;
@@ -212,6 +215,8 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         const int tn = more ? tf + 1 : tf;
         h16x8 acur[2];
         load_a(acur, 0);
+        constexpr int S0 = 16;
+        static_assert(S0 + 2 * NIT < 36, "staging and address slots inside the K loop");
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
             h16x8 anext[2];
@@ -219,13 +224,18 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
             __builtin_amdgcn_sched_barrier(0);
             accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[1], breg[s][0], accm, 0, 0, 0);      // l * h
             __builtin_amdgcn_sched_barrier(0);
-            if (s < NIT) stage_a(s);                       // staging of tile t + 1: one item per K-step ...
-            if (s == NIT) fetch_setup(cn, tn & 3);         // ... then the loads of tile t + 2, one item per K-step
+            // staging of tile t + 1 (K-steps S0 .. S0 + 7, one item each), then the ADDRESSES of tile t + 2 (one item per
+            // K-step); its loads go out behind the epilogue: the prefetch must be the YOUNGEST vector-memory work when it is
+            // consumed -- gfx950 retires loads and stores on one in-order counter, so a wait for a load that has the
+            // epilogue's stores queued behind it is a wait for those stores' acknowledgements (first version of this kernel:
+            // 4.7 us per tile)
+            if (s >= S0 && s < S0 + NIT) stage_a(s - S0);
+            if (s == S0 + NIT) fetch_setup(cn, tn & 3);
             __builtin_amdgcn_sched_barrier(0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[0], breg[s][0], acc, 0, 0, 0);        // h * h
             __builtin_amdgcn_sched_barrier(0);
-            if (s < NIT) stage_b(s, nxt);
-            if (s > NIT && s <= 2 * NIT) fetch_item(s - NIT - 1);
+            if (s >= S0 && s < S0 + NIT) stage_b(s - S0, nxt);
+            if (s > S0 + NIT && s <= S0 + 2 * NIT) fetch_addr(s - S0 - NIT - 1);
             __builtin_amdgcn_sched_barrier(0);
             accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[0], breg[s][1], accm, 0, 0, 0);      // h * l
             __builtin_amdgcn_sched_barrier(0);
@@ -237,10 +247,13 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         f32x16 accs[1][1];
         accs[0][0] = acc;
         conv_epilogue<2, 2, 1, 1, 64, BM>(a, accs, pinfo_ring + (t & 3) * 8, (cc.ty * tiles_per_row + cc.tx) * 2, cc.img, n0, wp, wn, g, li,
-                                          coef, omul);
+                                          coef, omul, &vmax);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) fetch_load(i);
         advance(cc);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    if (a.amax_out) amax_update_wave(a.amax_out, vmax);
 }
 
 // eligible: f16x2 arithmetic on fp32 sources, 3x3 stride 1, ONE 64-channel source, dense NHWC output of whole 4x16 tiles
