@@ -236,6 +236,10 @@ template <int WM, int WN, int WTM, int WTN, int BNT, bool BM = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[WTM][WTN], const int *pinfo,
                                               int patch0, int img, int n0, int wm, int wn, int g, int li,
                                               const EpiCoef<WTN> &coef, float omul = 1.f, float *vmax_acc = nullptr) {
+    // Every multiply-add below is written as the fma it is meant to be, and nothing else may be contracted: with
+    // -ffp-contract=fast the choice is the optimiser's, PER INSTANTIATION -- and the kernels that share this epilogue
+    // promise bit-identical results (round 5: one copy of `v = acc * sc + bi; v += res` came out differently for one r).
+#pragma clang fp contract(off)
     // omul: power-of-two rescale of the accumulator (fp16-split mode: undoes the operand scaling, exact); 1 otherwise
     // vmax_acc: a persistent caller (conv_wres.hip) collects this lane's max |stored value| over its calls here and commits
     // ConvArgs::amax_out once itself (amax_commit waits for a returned load: once per workgroup, not once per tile)
@@ -298,7 +302,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float v = acc[tm][tn][r] * sc + bi;
+                        float v = __builtin_fmaf(acc[tm][tn][r], sc, bi);
                         if constexpr (RES) v += rv[r];
                         if constexpr (bm) {
                             const bool on = ZMASK ? zv[r] > 0.f : (bm_relu == 0 || fmaf(yv[r], ma, mb) > 0.f);
@@ -308,7 +312,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         } else if (do_stats) {
                             const float d = v - sh;
                             ssum += d;
-                            ssq += d * d;
+                            ssq = __builtin_fmaf(d, d, ssq);
                         }
                         v = fmaxf(v, floor_v);
                         vmax = fmaxf(vmax, fabsf(v));
@@ -325,7 +329,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                 for (int r = 0; r < 16; ++r) {
                     const int y = oy0 + (r >> 2), x = ox0 + (r & 3) + 4 * g;
                     if (nok && y < a.Hout && x < a.Wout) {
-                        float v = acc[tm][tn][r] * sc + bi;
+                        float v = __builtin_fmaf(acc[tm][tn][r], sc, bi);
                         if (has_res) v += buf_load1(r_res, (y * a.r_row + x * a.r_px + n) * 4, 0);
                         if (bm) {
                             const float yy = buf_load1(r_y, (y * a.o_row + x * a.o_px + n) * 4, 0);
@@ -338,7 +342,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         } else {
                             const float d = v - sh;
                             ssum += d;
-                            ssq += d * d;
+                            ssq = __builtin_fmaf(d, d, ssq);
                         }
                         v = fmaxf(v, floor_v);
                         vmax = fmaxf(vmax, fabsf(v));
