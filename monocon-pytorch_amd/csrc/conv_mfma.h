@@ -312,7 +312,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         } else if (do_stats) {
                             const float d = v - sh;
                             ssum += d;
-                            ssq = __builtin_fmaf(d, d, ssq);
+                            ssq += d * d;      // (two roundings: contraction is off in this function)
                         }
                         v = fmaxf(v, floor_v);
                         vmax = fmaxf(vmax, fabsf(v));
@@ -342,7 +342,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         } else {
                             const float d = v - sh;
                             ssum += d;
-                            ssq = __builtin_fmaf(d, d, ssq);
+                            ssq += d * d;      // (two roundings: contraction is off in this function)
                         }
                         v = fmaxf(v, floor_v);
                         vmax = fmaxf(vmax, fabsf(v));
