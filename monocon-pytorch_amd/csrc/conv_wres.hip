@@ -12,19 +12,35 @@
 // Here: 256 workgroups (one per CU, four waves with the whole register file: __launch_bounds__(256, 1) = 512 registers per
 // lane) each walk a contiguous range of 4 x 16-pixel tiles.
 //   * weights: a wave owns ONE 32-column tile for ALL of K: its 36 K-steps x 2 pieces = 72 B fragments (288 registers)
-//     are loaded once per workgroup and stay in registers -- no weight traffic, no weight address arithmetic, no LDS for
-//     them inside the tile loop;
+//     are loaded once per workgroup and stay in registers -- the hi pieces in vector registers, the lo pieces in
+//     ACCUMULATION registers, from where the one MFMA per K-step that uses them reads them directly (inline asm: left to
+//     itself hipcc copies every such fragment to vector registers first, 225 instructions per tile);
 //   * waves = 2 column tiles x 2 patches: the two waves of a patch share its A fragments (LDS), the two patches of a tile
 //     sit side by side in the conflict-free image of conv_bf16.hip ([piece][8-channel plane][halo row][24 slots of 16 B]);
-//   * software pipeline over tiles, ONE raw barrier per tile: while the MFMAs of tile t run out of image buffer t & 1, the
-//     raw fp32 data of tile t + 1 (in registers since the previous tile) is scaled / split into its fp16 pieces
-//     (v_fma_mix{lo,hi}_f16: two instructions per element) and written to buffer (t + 1) & 1, then the loads of tile t + 2
-//     are issued into the same registers.  Both are unconditional (past the end the last tile is fetched again: a
-//     conditional fetch makes hipcc's wait-count pass drain the queue) and are slotted BETWEEN the MFMAs of a
-//     K-step in program order (the wave is alone on its SIMD: only what sits between two MFMAs overlaps them).
+//     fragments are requested two K-steps ahead;
+//   * software pipeline over tiles, ONE raw barrier per tile.  A wave that is alone on its SIMD issues in order, so only
+//     what stands BETWEEN two MFMAs in program order overlaps them (~5 instructions per 32-cycle MFMA); everything a tile
+//     needs besides its 108 MFMAs is therefore dealt out into those gaps, K-step by K-step:
+//       K-steps  0 .. 19   the EPILOGUE OF THE PREVIOUS TILE, one output row per step (its sums wait in 16 registers; the
+//                          residual / BatchNorm-backward operands of a row are requested three steps before it is due)
+//       K-steps 20 .. 27   conversion of the raw fp32 data of tile t + 1 (in registers since the end of tile t - 1) into
+//                          its fp16 pieces (v_fma_mix{lo,hi}_f16: two instructions per element) and into image buffer
+//                          (t + 1) & 1
+//       K-steps 28 .. 35   addresses of tile t + 2; its loads go out after the loop (the prefetch has to be the YOUNGEST
+//                          vector-memory work when it is consumed: gfx950 retires loads and stores on one in-order counter)
+//     The first tile of a workgroup has no predecessor: the loop body exists twice (with / without the epilogue slots),
+//     which also keeps every s_waitcnt the compiler derives exact (no merged paths with different queue contents).
+// Measured on the way (64 -> 64 at 96 x 320, B = 32; conv_bf16_kernel 283-295 us): phase removal on the first version
+// (epilogue as a block after the MFMAs): MFMAs alone 128-138 us, fragment waits +42, staging +37, epilogue +66-70 --
+// serial, in-order; per-wave cycle counters: 4370 cycles per tile in the MFMA loop (3456 of them matrix work), 1800 in the
+// epilogue, at 1.45 GHz (the chip is at its power limit).  An eight-wave variant (two K halves handing their accumulators
+// through LDS, 256 registers per wave: scratch/exp/conv_wres_8wave_pipeline.hip.txt) was 30 % SLOWER: one barrier per tile
+// couples all eight waves, and the wave that finishes a tile carries the epilogue and half of the MFMAs alone.
 // Arithmetic, K order (32-channel chunk, tap, 16-channel step; l*h and h*l into the minor accumulator, h*h into the main
-// one, folded once) and epilogue (conv_epilogue of conv_mfma.h) are those of conv_bf16_kernel<3, 1, ..., SPL = 2>:
-// results are bit-identical to every other tiling (tests/test_hip_wres.py), so the autotuner may pick it freely.
+// one, folded once) and the epilogue's operations and their order are those of conv_bf16_kernel<3, 1, ..., SPL = 2> with
+// conv_epilogue (conv_mfma.h): results are bit-identical to every other tiling (tests/test_hip_wres.py), so the autotuner
+// may choose by time.
+#include <cstdlib>
 #include "conv_mfma.h"
 
 namespace mc {
@@ -40,8 +56,7 @@ struct WresCfg {
     static constexpr int NPL = 8;                        // planes per piece: 64 channels
     static constexpr int PIECE = NPL * CPL;              // 18688
     static constexpr int TILE = 2 * PIECE;               // both fp16 pieces of one tile's halo image: 37376
-    static constexpr int PINFO = 2 * TILE;               // ring of four patch tables [slot][2 patches][4]
-    static constexpr int LDS_BYTES = PINFO + 4 * 2 * 16;
+    static constexpr int LDS_BYTES = 2 * TILE;
     static constexpr int C4 = 16;                        // channel quads per pixel
     static constexpr int TOTAL = 2 * NPIX * C4;          // staging items per tile (float4 each): 1920
     static constexpr int NIT = (TOTAL + NT - 1) / NT;    // 8 per thread, the last half-filled ...
@@ -61,13 +76,18 @@ __device__ __forceinline__ void wres_split_pair(float x0, float x1, float s, uns
     lo = l;
 }
 
-template <bool BM>
+// Template flags select ONE straight-line epilogue: RES residual (or the gradient accumulated so far), STATS per-patch
+// (sum, sum of squares) partials of a train-mode forward, BM backward-statistics mode (ConvArgs::bm_y; always with
+// partials), ZMASK its ReLU mask from the stored activation (bm_relu == 1).
+// EXP (measurement builds only, -DMC_WRES_EXP + MONOCON_WRES_EXP=bits; results WRONG by construction): 1 no MFMAs, 2 no
+// conversion / LDS writes, 4 no global loads, 8 no epilogue, 16 no fragment reads
+template <bool BM, bool RES, bool STATS, bool ZMASK, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, const int tiles_per_row, const int tiles_per_img,
                                                            const int total_tiles, const int tiles_per_wg, const int ngroups) {
+#pragma clang fp contract(off)
     using C = WresCfg;
     constexpr int CPL = C::CPL, PIECE = C::PIECE, TILE = C::TILE, RS = C::RS, IW = C::IW, NIT = C::NIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    int *const pinfo_ring = reinterpret_cast<int *>(lds_raw + C::PINFO);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,7 +120,16 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         for (int q = 0; q < 2; ++q)
             breg[s][q] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, w_lane, soff + q * w_plane, 0));
     }
+
+    // ---- the epilogue's per-lane constants (conv_epilogue: column n = lane & 31 of the wave's tile, rows = pixels)
+    const int ncol = n0 + wn * 32 + li;
+    const bool nok = ncol < a.Cout;
     const EpiCoef<1> coef = conv_epi_coef<2, 1, BM>(a, n0, wn, li);
+    const int v_out = nok ? (4 * g * a.o_px + a.out_coff + ncol) * 4 : BUF_OOB;
+    const int v_res = nok ? (4 * g * a.r_px + ncol) * 4 : BUF_OOB;
+    const int v_bm = nok ? (4 * g * a.o_px + ncol) * 4 : BUF_OOB;      // y / z share the dense layout of the output
+    const float floor_v = a.relu ? 0.f : -__builtin_inff();
+    const int bm_relu = a.bm_relu;
 
     // ---- staging plan: item e = tid + 256 i of [patch][halo pixel][channel quad]; its place in the tile never changes
     const int c4 = tid % C::C4;
@@ -133,18 +162,13 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         }
     };
     f32x4 pv[NIT];
-    // loads of one tile into pv, in two parts: fetch_setup (scalars, the tile's patch table into ring slot `slot`) and one
-    // fetch_addr / fetch_load per staging item
+    // loads of one tile into pv, in three parts: fetch_setup (scalars), fetch_addr and fetch_load per staging item
     int f_oy = 0, f_ox = 0, f_base = 0;
     __amdgpu_buffer_rsrc_t f_rsrc = make_rsrc(a.src[0].p, 0u);
-    auto fetch_setup = [&](const Cursor &c, int slot) {
+    auto fetch_setup = [&](const Cursor &c) {
         f_oy = c.ty * 4; f_ox = c.tx * 16;
         f_rsrc = make_rsrc(a.src[0].p + (size_t)c.img * a.Hin * a.Win * 64, (unsigned)(a.Hin * a.Win * 64) * 4u);
         f_base = (f_oy * a.Win + f_ox) * 256;
-        if (tid < 2) {
-            int *pi = pinfo_ring + (slot * 2 + tid) * 4;
-            pi[0] = c.img; pi[1] = f_oy; pi[2] = f_ox + 8 * tid; pi[3] = 1;
-        }
     };
     int f_voff[NIT];
     auto fetch_addr = [&](int i) {
@@ -155,17 +179,19 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         asm volatile("" : "+v"(off));
         f_voff[i] = ok ? off : BUF_OOB;
     };
-    auto fetch_load = [&](int i) { pv[i] = buf_load4(f_rsrc, f_voff[i], 0); };
-    auto fetch = [&](const Cursor &c, int slot) {
-        fetch_setup(c, slot);
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) { fetch_addr(i); fetch_load(i); }
+    auto fetch_load = [&](int i) {
+        if constexpr (EXP & 4) asm volatile("" : "+v"(pv[i]) : "v"(f_voff[i]));
+        else pv[i] = buf_load4(f_rsrc, f_voff[i], 0);
     };
     float a_scale = 1.f, omul = 1.f;
     // conversion of item i (in pv) into image buffer `buf`, in two halves (each slotted behind one MFMA)
     unsigned st_h01 = 0, st_l01 = 0;
-    auto stage_a = [&](int i) { wres_split_pair(pv[i][0], pv[i][1], a_scale, st_h01, st_l01); };
+    auto stage_a = [&](int i) {
+        if constexpr (EXP & 2) asm volatile("" ::"v"(pv[i]));
+        else wres_split_pair(pv[i][0], pv[i][1], a_scale, st_h01, st_l01);
+    };
     auto stage_b = [&](int i, int buf) {
+        if constexpr (EXP & 2) return;
         unsigned h23, l23;
         wres_split_pair(pv[i][2], pv[i][3], a_scale, h23, l23);
         unsigned char *dst = lds_raw + buf * TILE + sdst[i];
@@ -177,7 +203,9 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
 
     // ---- prologue: tile t_begin -> buffer 0, tile t_begin + 1 -> registers
     Cursor cf = cursor_at(t_begin), cc = cf;
-    fetch(cf, t_begin & 3);
+    fetch_setup(cf);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) { fetch_addr(i); fetch_load(i); }
     {   // operand scales (behind the loads): 2^e_a for the staging, the exact inverse of both scales for the epilogue
         unsigned v = lane < AMAX_SUB ? am_raw : 0u;
 #pragma unroll
@@ -191,67 +219,159 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     for (int i = 0; i < NIT; ++i) { stage_a(i); stage_b(i, t_begin & 1); }
     int tf = t_begin;                  // tile index the fetch cursor stands on
     if (tf + 1 < t_end) { ++tf; advance(cf); }
-    fetch(cf, tf & 3);
+    fetch_setup(cf);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) { fetch_addr(i); fetch_load(i); }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+    const float sc = coef.sc[0] * omul, bi = coef.bi[0], sh = coef.sh[0], ma = coef.ma[0], mb = coef.mb[0];
     const int a_off = g * CPL + ((li >> 3) * RS + (li & 7) + IW * wp) * 16;
     float vmax = 0.f;                  // max |stored value| of this lane over all its tiles (ConvArgs::amax_out)
-    for (int t = t_begin; t < t_end; ++t) {
+
+    // ---- the streamed epilogue: sums of the finished tile in Y, its place in e_*; one row (= r of the MFMA layout: pixel
+    //      (oy0 + (r >> 2), ox0 + (r & 3) + 4 g)) per call, operations and their order as in conv_epilogue
+    float Y[16];
+    __amdgpu_buffer_rsrc_t e_out = make_rsrc(a.out, 0u), e_res = e_out, e_y = e_out, e_z = e_out;
+    int e_sout = 0, e_sres = 0, e_patch = 0, e_img = 0;
+    float ssum = 0.f, ssq = 0.f;
+    float rvr[4], yvr[4], zvr[4];      // operands of the rows in flight (requested three K-steps ahead)
+    auto epi_setup = [&](const Cursor &c) {
+        const int oy0 = c.ty * 4, ox0 = c.tx * 16 + 8 * wp;
+        e_img = c.img;
+        e_patch = c.ty * (2 * tiles_per_row) + 2 * c.tx + wp;
+        e_out = make_rsrc(a.out + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
+        if constexpr (RES) e_res = make_rsrc(a.res + (size_t)c.img * a.r_img, (unsigned)a.r_img * 4u);
+        if constexpr (BM) e_y = make_rsrc(a.bm_y + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
+        if constexpr (BM && ZMASK) e_z = make_rsrc(a.bm_z + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
+        e_sout = (oy0 * a.o_row + ox0 * a.o_px) * 4;
+        e_sres = (oy0 * a.r_row + ox0 * a.r_px) * 4;
+        ssum = 0.f; ssq = 0.f;
+    };
+    auto epi_load = [&](int r) {
+        if constexpr (RES) rvr[r & 3] = buf_load1(e_res, v_res, e_sres + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
+        if constexpr (BM) yvr[r & 3] = buf_load1(e_y, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+        if constexpr (BM && ZMASK) zvr[r & 3] = buf_load1(e_z, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+    };
+    float e_v = 0.f;
+    auto epi_row_a = [&](int r) {
+        float v = __builtin_fmaf(Y[r], sc, bi);
+        if constexpr (RES) v += rvr[r & 3];
+        if constexpr (BM) {
+            const bool on = ZMASK ? zvr[r & 3] > 0.f : (bm_relu == 0 || __builtin_fmaf(yvr[r & 3], ma, mb) > 0.f);
+            v = on ? v : 0.f;
+            ssum += v;
+            ssq = __builtin_fmaf(v, yvr[r & 3], ssq);
+        } else if constexpr (STATS) {
+            const float d = v - sh;
+            ssum += d;
+            ssq += d * d;      // (two roundings: contraction is off, as in conv_epilogue)
+        }
+        v = fmaxf(v, floor_v);
+        vmax = fmaxf(vmax, fabsf(v));
+        e_v = v;
+    };
+    auto epi_row_b = [&](int r) { buf_store1(e_v, e_out, v_out, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4); };
+    auto epi_finish = [&] {
+        if constexpr (BM || STATS) {
+            ssum += __shfl_xor(ssum, 32);
+            ssq += __shfl_xor(ssq, 32);
+            if (g == 0 && nok) {
+                float *dst = a.stats + (((size_t)e_img * a.ppi + e_patch) * a.CoutP + ncol) * 2;
+                dst[0] = ssum;
+                dst[1] = ssq;
+            }
+        }
+    };
+
+    // ---- one tile: the 36 K-steps out of image buffer t & 1; in the gaps (EPI) the epilogue of the previous tile, the
+    //      staging of tile t + 1 and the addresses of tile t + 2
+    f32x16 acc, accm;
+    auto tile_body = [&](auto epi_c, int t, const Cursor &cn) {
+        constexpr bool EPI = decltype(epi_c)::value && !(EXP & 8);
         const int cur = t & 1, nxt = cur ^ 1;
         const unsigned char *abase = lds_raw + cur * TILE + a_off;
         auto load_a = [&](h16x8(&dst)[2], int s) {
             const int c = s / 18, tap = (s % 18) / 2, m = s % 2;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                dst[q] = *reinterpret_cast<const h16x8 *>(abase + q * PIECE + (4 * c + 2 * m) * CPL + ((tap / 3) * RS + tap % 3) * 16);
+            for (int q = 0; q < 2; ++q) {
+                if constexpr (EXP & 16) asm volatile("" : "+v"(dst[q]));
+                else dst[q] = *reinterpret_cast<const h16x8 *>(abase + q * PIECE + (4 * c + 2 * m) * CPL + ((tap / 3) * RS + tap % 3) * 16);
+            }
         };
-        f32x16 acc, accm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accm[r] = 0.f; }
+        // fragments are requested TWO K-steps ahead (ring of three): one step -- 96 cycles of matrix work -- does not cover
+        // an LDS round trip when the wave is alone on its SIMD
+        h16x8 afr[3][2];
+        load_a(afr[0], 0);
+        load_a(afr[1], 1);
+        constexpr int S0 = 20;         // first staging step
+        static_assert(S0 + 2 * NIT <= 36, "staging and address slots inside the K loop");
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (s + 2 < 36) load_a(afr[(s + 2) % 3], s + 2);
+            const h16x8 ah = afr[s % 3][0], al = afr[s % 3][1];
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (EXP & 1) asm volatile("" : "+v"(accm) : "v"(al), "v"(breg[s][0]));
+            else accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, breg[s][0], accm, 0, 0, 0);      // l * h
+            __builtin_amdgcn_sched_barrier(0);
+            if (EPI && s < 16) epi_load(s);
+            if (s >= S0 && s < S0 + NIT) stage_a(s - S0);
+            if (s == S0 + NIT) fetch_setup(cn);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (EXP & 1) asm volatile("" : "+v"(acc) : "v"(ah), "v"(breg[s][0]));
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, breg[s][0], acc, 0, 0, 0);        // h * h
+            __builtin_amdgcn_sched_barrier(0);
+            if (EPI && s >= 3 && s < 19) epi_row_a(s - 3);
+            if (s >= S0 && s < S0 + NIT) stage_b(s - S0, nxt);
+            if (s >= S0 + NIT && s < S0 + 2 * NIT) fetch_addr(s - S0 - NIT);
+            __builtin_amdgcn_sched_barrier(0);
+            // h * l: the lo pieces of the weights feed the MFMA from the accumulation registers they live in
+            if constexpr (EXP & 1) asm volatile("" : "+a"(accm) : "v"(ah), "a"(breg[s][1]));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(accm) : "v"(ah), "a"(breg[s][1]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (EPI && s >= 3 && s < 19) epi_row_b(s - 3);
+            if (EPI && s == 19) epi_finish();
+        }
+        // (the last MFMA is inline asm: hipcc does not pad its result hazard -- 8 passes: 12 wait states before a VALU read)
+        asm volatile("s_nop 15" : "+a"(accm));
+    };
+
+    Cursor cp = cc;                    // the tile whose sums wait in Y
+    for (int t = t_begin; t < t_end; ++t) {
         // the tile after next (clamped: past the end the last tile is fetched again and never used)
         const bool more = tf + 1 < t_end;
         Cursor cn = cf;
         if (more) advance(cn);
         const int tn = more ? tf + 1 : tf;
-        h16x8 acur[2];
-        load_a(acur, 0);
-        constexpr int S0 = 16;
-        static_assert(S0 + 2 * NIT < 36, "staging and address slots inside the K loop");
-#pragma unroll
-        for (int s = 0; s < 36; ++s) {
-            h16x8 anext[2];
-            if (s + 1 < 36) load_a(anext, s + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[1], breg[s][0], accm, 0, 0, 0);      // l * h
-            __builtin_amdgcn_sched_barrier(0);
-            // staging of tile t + 1 (K-steps S0 .. S0 + 7, one item each), then the ADDRESSES of tile t + 2 (one item per
-            // K-step); its loads go out behind the epilogue: the prefetch must be the YOUNGEST vector-memory work when it is
-            // consumed -- gfx950 retires loads and stores on one in-order counter, so a wait for a load that has the
-            // epilogue's stores queued behind it is a wait for those stores' acknowledgements (first version of this kernel:
-            // 4.7 us per tile)
-            if (s >= S0 && s < S0 + NIT) stage_a(s - S0);
-            if (s == S0 + NIT) fetch_setup(cn, tn & 3);
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[0], breg[s][0], acc, 0, 0, 0);        // h * h
-            __builtin_amdgcn_sched_barrier(0);
-            if (s >= S0 && s < S0 + NIT) stage_b(s - S0, nxt);
-            if (s > S0 + NIT && s <= S0 + 2 * NIT) fetch_addr(s - S0 - NIT - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(acur[0], breg[s][1], accm, 0, 0, 0);      // h * l
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < 36) { acur[0] = anext[0]; acur[1] = anext[1]; }
+        if (t == t_begin) {
+            tile_body(std::false_type{}, t, cn);
+        } else {
+            if constexpr (!(EXP & 8)) epi_setup(cp);
+            tile_body(std::true_type{}, t, cn);
         }
         cf = cn; tf = tn;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += accm[r];
-        f32x16 accs[1][1];
-        accs[0][0] = acc;
-        conv_epilogue<2, 2, 1, 1, 64, BM>(a, accs, pinfo_ring + (t & 3) * 8, (cc.ty * tiles_per_row + cc.tx) * 2, cc.img, n0, wp, wn, g, li,
-                                          coef, omul, &vmax);
+        for (int r = 0; r < 16; ++r) Y[r] = acc[r] + accm[r];
+        cp = cc;
+        advance(cc);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) fetch_load(i);
-        advance(cc);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // the last tile's epilogue, on its own
+    if constexpr (!(EXP & 8)) {
+        epi_setup(cp);
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+#pragma unroll
+            for (int r = r0; r < r0 + 4; ++r) epi_load(r);
+#pragma unroll
+            for (int r = r0; r < r0 + 4; ++r) { epi_row_a(r); epi_row_b(r); }
+        }
+        epi_finish();
+    } else {
+        asm volatile("" ::"v"(Y[0]), "v"(Y[15]));
     }
     if (a.amax_out) amax_update_wave(a.amax_out, vmax);
 }
@@ -260,14 +380,15 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
 bool conv_wres_ok(const ConvArgs &a, int ks, int stride) {
     if (a.prec != 3 || !a.wpk16 || !a.amax_w || ks != 3 || stride != 1) return false;
     if (a.nsrc != 1 || a.src[0].C != 64 || a.Cin != 64 || !a.amax_in[0] || a.pexp[0]) return false;
-    if (a.CoutP % 64 || a.Hin != a.Hout || a.Win != a.Wout || a.Wout % 16) return false;
+    if (a.CoutP % 64 || a.Hin != a.Hout || a.Win != a.Wout || a.Wout % 16 || a.Hout % 4) return false;
     if ((size_t)a.Hin * a.Win * 64 * 4 >= ((size_t)1 << 31)) return false;       // 32-bit buffer offsets per image
+    if (a.bm_y && !a.stats) return false;
     return true;
 }
 
-template <bool BM>
+template <bool BM, bool RES, bool STATS, bool ZMASK, int EXP = 0>
 static hipError_t launch_wres_one(const ConvArgs &a, int tpr, int tpi, int total, int per_wg, int ngroups, int nwg, hipStream_t st) {
-    auto kern = conv_wres_kernel<BM>;
+    auto kern = conv_wres_kernel<BM, RES, STATS, ZMASK, EXP>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -286,7 +407,7 @@ hipError_t launch_conv_wres(const ConvArgs &a_in, int ks, int stride, hipStream_
     a.ppi = a.ppr * ((a.Hout + 3) / 4);
     a.chunks = a.ppi;
     if (resolved) *resolved = a;
-    const int tpr = a.Wout / 16, tpi = tpr * ((a.Hout + 3) / 4), total = a.B * tpi, ngroups = a.CoutP / 64;
+    const int tpr = a.Wout / 16, tpi = tpr * (a.Hout / 4), total = a.B * tpi, ngroups = a.CoutP / 64;
     // one workgroup per CU and column group where the work allows (>= 8 tiles each: the weight prologue is ~2 tiles of time)
     static const int ncu = [] {
         int dev = 0, n = 256;
@@ -298,8 +419,25 @@ hipError_t launch_conv_wres(const ConvArgs &a_in, int ks, int stride, hipStream_
     if (nwg < 1) nwg = 1;
     const int per_wg = (total + nwg - 1) / nwg;
     nwg = (total + per_wg - 1) / per_wg;
-    return a.bm_y ? launch_wres_one<true>(a, tpr, tpi, total, per_wg, ngroups, nwg, st)
-                  : launch_wres_one<false>(a, tpr, tpi, total, per_wg, ngroups, nwg, st);
+#define WL(BM_, RES_, STATS_, ZM_, EXP_) launch_wres_one<BM_, RES_, STATS_, ZM_, EXP_>(a, tpr, tpi, total, per_wg, ngroups, nwg, st)
+#ifdef MC_WRES_EXP
+    static const int exp_bits = [] { const char *e = std::getenv("MONOCON_WRES_EXP"); return e ? std::atoi(e) : 0; }();
+    switch (exp_bits) {
+#define WX(N) case N: return WL(false, false, false, false, N);
+        WX(1) WX(2) WX(4) WX(8) WX(16) WX(6) WX(14) WX(30) WX(31)
+#undef WX
+        default: break;
+    }
+#endif
+    const bool res = a.res != nullptr, stats = a.stats != nullptr;
+    if (a.bm_y) {
+        const bool zm = a.bm_relu == 1;
+        return res ? (zm ? WL(true, true, true, true, 0) : WL(true, true, true, false, 0))
+                   : (zm ? WL(true, false, true, true, 0) : WL(true, false, true, false, 0));
+    }
+    return res ? (stats ? WL(false, true, true, false, 0) : WL(false, true, false, false, 0))
+               : (stats ? WL(false, false, true, false, 0) : WL(false, false, false, false, 0));
+#undef WL
 }
 
 }  // namespace mc
