@@ -338,18 +338,29 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     };
 
     Cursor cp = cc;                    // the tile whose sums wait in Y
+#ifdef MC_PHASE_TIMERS
+    unsigned long long tp_tail = 0, tp_bar = 0, tp_mfma = 0, tp_head = 0;
+    const unsigned long long tp_start = __builtin_readcyclecounter();
+#define WTP_NOW() __builtin_readcyclecounter()
+#else
+#define WTP_NOW() 0ull
+#endif
     for (int t = t_begin; t < t_end; ++t) {
+        [[maybe_unused]] const unsigned long long tp0 = WTP_NOW();
         // the tile after next (clamped: past the end the last tile is fetched again and never used)
         const bool more = tf + 1 < t_end;
         Cursor cn = cf;
         if (more) advance(cn);
         const int tn = more ? tf + 1 : tf;
+        [[maybe_unused]] unsigned long long tp1 = tp0;
         if (t == t_begin) {
             tile_body(std::false_type{}, t, cn);
         } else {
             if constexpr (!(EXP & 8)) epi_setup(cp);
+            tp1 = WTP_NOW();
             tile_body(std::true_type{}, t, cn);
         }
+        [[maybe_unused]] const unsigned long long tp2 = WTP_NOW();
         cf = cn; tf = tn;
 #pragma unroll
         for (int r = 0; r < 16; ++r) Y[r] = acc[r] + accm[r];
@@ -357,8 +368,18 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         advance(cc);
 #pragma unroll
         for (int i = 0; i < NIT; ++i) fetch_load(i);
+        [[maybe_unused]] const unsigned long long tp3 = WTP_NOW();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef MC_PHASE_TIMERS
+        { const unsigned long long tp4 = WTP_NOW(); tp_head += tp1 - tp0; tp_mfma += tp2 - tp1; tp_tail += tp3 - tp2; tp_bar += tp4 - tp3; }
+#endif
     }
+#ifdef MC_PHASE_TIMERS
+    if (a.phase_prof && lane == 0) {       // (reported by mc_bench_conv as: stage = tile tail, barriers, mfma-phase, epilogue = tile head)
+        unsigned long long *o = a.phase_prof + ((size_t)blockIdx.x * 4 + wave) * 5;
+        o[0] = tp_tail; o[1] = tp_bar; o[2] = tp_mfma; o[3] = tp_head; o[4] = WTP_NOW() - tp_start;
+    }
+#endif
     // the last tile's epilogue, on its own
     if constexpr (!(EXP & 8)) {
         epi_setup(cp);

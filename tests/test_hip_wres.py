@@ -37,7 +37,8 @@ CASES = [
     # (name, B, H, W, Cout, residual, relu, affine)
     ("one_tile", 1, 4, 16, 64, False, False, False),
     ("two_tiles_row", 1, 4, 32, 64, True, True, True),
-    ("odd_rows", 2, 6, 48, 64, True, True, True),          # last patch row half outside the image
+    ("odd_rows", 2, 6, 48, 64, True, True, True),          # last patch row half outside the image: not eligible, falls back
+    ("two_rows_res", 2, 8, 48, 64, True, True, True),
     ("many_tiles", 3, 24, 80, 64, False, True, True),       # 90 tiles: several per workgroup, image seams inside a range
     ("head_576", 2, 8, 32, 576, False, False, True),        # nine column groups
     ("cout_96_padded", 1, 8, 16, 96, False, True, True),    # CoutP = 128: the second group is half padding
