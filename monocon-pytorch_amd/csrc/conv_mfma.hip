@@ -1,4 +1,5 @@
 // Instantiations + dispatch of the fused MFMA convolution (see conv_mfma.h).
+#include <cstdlib>
 #include "conv_mfma.h"
 
 namespace mc {
@@ -133,7 +134,9 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
         }
     }
     if (a.cfg & CFG_WRES) {
-        if (conv_wres_ok(a, ks, stride)) return launch_conv_wres(a, ks, stride, st, resolved);
+        // MONOCON_HIP_WRES=0: A/B switch, every launch takes the tiling its shape bits name
+        static const bool wres_on = [] { const char *e = std::getenv("MONOCON_HIP_WRES"); return !e || std::atoi(e) != 0; }();
+        if (wres_on && conv_wres_ok(a, ks, stride)) return launch_conv_wres(a, ks, stride, st, resolved);
         a.cfg &= ~CFG_WRES;
     }
     if (a.prec >= 1 && conv_bf16_ok(a, ks, stride)) return launch_conv_bf16(a, ks, stride, st, resolved);

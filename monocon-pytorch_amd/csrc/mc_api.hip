@@ -117,7 +117,7 @@ static int build_layers(mc_handle *h) {
     if (dev_alloc(h, &h->stem_shift, 16, h->param_bufs, h->param_bytes)) return -1;
     ConvLayer &H3 = h->head3;
     H3.conv = "head.*.0"; H3.ks = 3; H3.stride = 1; H3.cin = 64; H3.cout = NUM_HEADS * HEAD_CH;
-    H3.cfg = CFG_128x64m;      // one head per 64-column tile
+    H3.cfg = CFG_128x64m | CFG_WRES;      // one head per 64-column tile (weight-resident kernel where the launch is eligible)
     H3.coutp = H3.cout;
     if (dev_alloc(h, &H3.wpk, (size_t)9 * 64 * H3.coutp, h->param_bufs, h->param_bytes)) return -1;
     { float *q = nullptr; if (dev_alloc(h, &q, (size_t)3 * 9 * 64 * H3.coutp / 2, h->param_bufs, h->param_bytes)) return -1; H3.wpk16 = q; }

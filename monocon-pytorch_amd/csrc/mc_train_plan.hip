@@ -178,6 +178,7 @@ struct TB {   // train plan builder
     // launch_noise_fill).  MEASURED (round 4, one session, B=32): 56.52 / 56.56 ms per step tuned on zeros, 56.51 / 56.62
     // tuned on noise -- the ranking of the shapes does not depend on it; off by default (MONOCON_HIP_TUNE_NOISE=1).
     bool tune_noise = [] { const char *e = std::getenv("MONOCON_HIP_TUNE_NOISE"); return e && std::atoi(e) != 0; }();
+    int wres_bwd = [] { const char *e = std::getenv("MONOCON_HIP_WRES_BWD"); return e ? std::atoi(e) : 1; }();
     float *alloc_map(size_t n) {
         float *p = alloc(n);
         if (p && !h->dry_alloc && h->autotune && tune_noise && n >= 4096)
@@ -481,6 +482,13 @@ struct TB {   // train plan builder
         if (sn.ginit) { d.res = sn.g; d.res_ld = sn.t.C; }
         if (Hd != sn.t.H || Wd != sn.t.W) { ts->ok = false; h->err = "train plan: dgrad shape mismatch"; }
         d.cfg = ts->ok ? mc_choose_conv_cfg(h, d, ks, 1) : CFG_128x32;
+        // The weight-resident kernel (conv_wres.hip) owns its CU -- four waves with the whole register file -- so beside the
+        // weight-gradient stream it cannot share one the way the tiled kernels do and the two streams take
+        // turns: measured in the step (rocprofv3, round 5) a plain 64 -> 64 data gradient takes ~595 us on it against 389 us
+        // on conv_bf16_kernel, although it is the faster kernel alone (244 vs 284 us).  Backward launches therefore keep the
+        // tiled kernel, except the backward-statistics twins, where even so it wins (595 vs 819 us; bn_backward sets the flag).
+        // MONOCON_HIP_WRES_BWD: 0 = never in the backward, 1 (default) = the twins only, 2 = wherever the autotuner chose it
+        if (wres_bwd < 2) d.cfg &= ~CFG_WRES;
         ts->dgrads.push_back(d);
         ConvArgs *dp = &ts->dgrads.back();
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(*dp, ks, 1, st)); return 0; });
@@ -563,6 +571,7 @@ struct TB {   // train plan builder
             float *partial = alloc((size_t)nbp * cstride * 2);
             lc->stats = partial;
             lc->bm_y = yp; lc->bm_z = zp; lc->bm_a = fa; lc->bm_b = fb; lc->bm_relu = relu;
+            if (wres_bwd >= 1 && !(lc->cfg & (CFG_SMALL | CFG_WS)) && conv_wres_ok(*lc, 3, 1)) lc->cfg |= CFG_WRES;      // (see emit_dgrad)
             if (dslot) lc->amax_out = dslot;
             double *fold = fold_scratch(nbp, C);
             if (want_skip_affine && !dyexp && !gres) {
