@@ -415,7 +415,10 @@ def test_bench_multi_rank_path_end_to_end(tmp_path):
     import json
     env = dict(os.environ, MONOCON_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
-           "--height", "64", "--width", "128", "--forward-steps", "2", "--no-cpu-baseline", "--no-extra-modes"]
+           "--height", "64", "--width", "128", "--forward-steps", "2", "--no-cpu-baseline", "--no-extra-modes",
+           # (its verbose report must not land on the default gpurun_out/bench_full.json: round 4 copied a report overwritten
+           #  by this test into profiles/ as the headline run's)
+           "--full-json", os.path.join(str(tmp_path), "bench_full.json")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
