@@ -335,15 +335,14 @@ int mc_profile_train(mc_handle *h, int iters, double ms[3], double flops[3], dou
  * partial products per multiply accumulated in fp32; as close to the fp64 reference as the fp32 MFMA path (same
  * parity tolerances), ~2.7x its matrix rate.  3: fp32 EMULATED on the fp16 pipe -- every operand tensor scaled by the
  * power of two its max |x| dictates, split into two fp16 pieces, three partial products per multiply; same parity
- * tolerances, half the matrix work of mode 2.  4 (round 4, EXPERIMENTAL): the arithmetic of mode 3 with the >= 64-channel
- * activations / BatchNorm-input gradients of the train plan stored pre-split ("P16", csrc/p16.h: the two fp16 pieces of
- * x * 2^e per element, one producer-chosen exponent per tensor) and both MFMA operands DMA-staged into LDS
- * (csrc/conv_p16.hip); forward equal to mode 3 to 1e-5, slower in the step, not a bench leg.
+ * tolerances, half the matrix work of mode 2.  (Round 4's experimental mode 4 -- mode 3 on activations stored pre-split
+ * and DMA-staged -- was retired in round 5: it lost in the step and its weight gradients were not bit-reproducible beside the
+ * weight-gradient stream; mode 4 is an error.)
  * Re-pack (mc_pack_params) before the next forward. */
 int mc_set_precision(mc_handle *h, int mode);
 /* Tuning / test aid: force one workgroup shape of the fused convolution (ids in
- * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel, 32 = the LDS-free
- * kernel for 16/32-channel 3x3 layers; 0 = automatic)
+ * csrc/conv_mfma.h: 1..8 = pixel x channel tile, +16 = wave-specialised kernel, +64 = the weight-resident persistent kernel
+ * (csrc/conv_wres.hip) wherever a launch is eligible, 32 = the LDS-free kernel for 16/32-channel 3x3 layers; 0 = automatic)
  * for mc_op_conv and for every layer of plans built afterwards that has no fixed shape. */
 int mc_set_conv_cfg(mc_handle *h, int cfg);
 /* Tuning aid: average duration (ms) of `iters` launches of one fused-conv shape on random data.

@@ -73,10 +73,7 @@ struct ConvCfgB16 {
     static constexpr size_t LDS_BYTES = TILE_BYTES + PB * 16;
 };
 
-// P16S (mode 4, SPL == 2, the stride-2 layers): the sources are stored as P16 (p16.h) -- the staging copies the two pieces
-// (two 8-byte loads per pixel and channel quad) instead of scaling / splitting fp32 values; one source, its exponent
-// from ConvArgs::pexp[0]
-template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false, bool P16S = false>
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
 __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kernel(const ConvArgs a) {
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
     typedef typename Piece<SPL>::T pc_t;
@@ -111,7 +108,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     // declared, every workgroup started with one exposed memory round trip per source of the virtual concat -- a short-K
     // layer (64 channels: 3.6 us of matrix work per workgroup) has nothing to hide it behind.
     unsigned am_raw[4] = {0u, 0u, 0u, 0u};
-    if constexpr (SPL == 2 && !P16S) {
+    if constexpr (SPL == 2) {
         const int al = lane < AMAX_SUB ? lane * AMAX_STRIDE : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) am_raw[i] = a.amax_in[i < a.nsrc ? i : 0][al];      // (extra copies of source 0: harmless)
@@ -136,18 +133,13 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     float a_scale = 1.f, omul = 1.f;
     auto operand_scales = [&] {
         if constexpr (SPL == 2) {
-            int ea;
-            if constexpr (P16S) {
-                ea = *a.pexp[0];
-            } else {
-                unsigned v = am_raw[0];
+            unsigned v = am_raw[0];
 #pragma unroll
-                for (int i = 1; i < 4; ++i) v = am_raw[i] > v ? am_raw[i] : v;
-                v = lane < AMAX_SUB ? v : 0u;
+            for (int i = 1; i < 4; ++i) v = am_raw[i] > v ? am_raw[i] : v;
+            v = lane < AMAX_SUB ? v : 0u;
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
-                ea = f16_scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)v));
-            }
+            for (int o = 8; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
+            const int ea = f16_scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)v));
             const int ew = f16_scale_exp(*a.amax_w);
             a_scale = exp2i(ea);
             omul = exp2i(-ea) * exp2i(-ew);
@@ -247,36 +239,17 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
             const int x = pinfo[p * 4 + 2] * S - PAD + ix;
             // (bitwise, unsigned: `a && b && ...` becomes a chain of branches, each with its own LDS round trip for pinfo)
             const bool ok = (e < TOTAL) & (pinfo[p * 4 + 3] != 0) & ((unsigned)y < (unsigned)a.Hin) & ((unsigned)x < (unsigned)a.Win);
-            int off = P16S ? (y * a.Win + x) * cs * 4 + (c4 >> 1) * 32 + (c4 & 1) * 8 : ((y * a.Win + x) * cs + c4 * 4) * 4;
+            int off = ((y * a.Win + x) * cs + c4 * 4) * 4;
             asm volatile("" : "+v"(off));      // computed for every lane, then selected: no branch around the multiplies
             voff[i] = ok ? off : BUF_OOB;
             sdst[i] = PLANAR ? (c4 >> 1) * CPL + (p >> 1) * PPB + (iy * RS + ix + IW * (p & 1)) * 16 + (c4 & 1) * 8
                              : (int)(stage_dst - lds_raw) + i * (NT / C4) * ROWB;
         }
     };
-    auto stage_load = [&](__amdgpu_buffer_rsrc_t r, int vo, int so) -> f32x4 {
-        if constexpr (P16S) {
-            typedef int i32x2_l __attribute__((ext_vector_type(2)));
-            const i32x2_l h = __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0);
-            const i32x2_l l = __builtin_amdgcn_raw_buffer_load_b64(r, vo == BUF_OOB ? BUF_OOB : vo + 16, so, 0);
-            i32x4 w;
-            w[0] = h[0]; w[1] = h[1]; w[2] = l[0]; w[3] = l[1];
-            return __builtin_bit_cast(f32x4, w);
-        } else {
-            return buf_load4(r, vo, so);
-        }
-    };
+    auto stage_load = [&](__amdgpu_buffer_rsrc_t r, int vo, int so) -> f32x4 { return buf_load4(r, vo, so); };
     auto stage_one = [&](const f32x4 &v, int i) {       // split one float4 into its pieces and write them to the LDS planes
         if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL)) {
             pc4 q[SPL];
-            if constexpr (P16S) {      // v = (hi pieces of the quad, lo pieces of the quad), 8 + 8 bytes
-                typedef int i32x2_l __attribute__((ext_vector_type(2)));
-                const i32x4 w = __builtin_bit_cast(i32x4, v);
-                i32x2_l h2, l2;
-                h2[0] = w[0]; h2[1] = w[1]; l2[0] = w[2]; l2[1] = w[3];
-                q[0] = __builtin_bit_cast(pc4, h2);
-                q[SPL - 1] = __builtin_bit_cast(pc4, l2);
-            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float r = SPL == 2 ? v[j] * a_scale : v[j];
@@ -285,7 +258,6 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
                     q[pz][j] = (pc_t)r;
                     r -= (float)q[pz][j];
                 }
-            }
             }
 #pragma unroll
             for (int pz = 0; pz < SPL; ++pz) *reinterpret_cast<pc4 *>(lds_raw + sdst[i] + pz * PLANE) = q[pz];
@@ -485,14 +457,9 @@ hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal,
 }
 
 // ---- dispatch
-template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false, bool P16S = false>
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
 static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
-    if constexpr (S == 2 && SPL == 2 && !P16S) {
-        if (a.pexp[0]) return a.nsrc == 1 ? launch_b16_one<KS, S, WM, WN, WTM, WTN, SPL, BM, true>(a, st, resolved) : hipErrorInvalidValue;
-    } else if constexpr (!P16S) {
-        if (a.pexp[0]) return hipErrorInvalidValue;
-    }
     if constexpr (!BM && S == 1 && (KS == 3 || KS == 1)) {      // backward-statistics epilogue: own instantiation
         if (a.bm_y) return launch_b16_one<KS, S, WM, WN, WTM, WTN, SPL, true>(a, st, resolved);
     } else if constexpr (!BM) {
@@ -505,7 +472,7 @@ static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved)
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
     static bool attr_set = false;
-    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL, BM, P16S>;
+    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL, BM>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
@@ -534,7 +501,7 @@ bool conv_bf16_ok(const ConvArgs &a, int ks, int stride) {
     if (a.prec == 3) {       // the fp16 split needs the maxima of every operand tensor
         if (!a.amax_w) return false;
         for (int i = 0; i < a.nsrc; ++i)
-            if (!a.amax_in[i] && !a.pexp[i]) return false;
+            if (!a.amax_in[i]) return false;
     }
     for (int i = 0; i < a.nsrc; ++i)
         if (a.src[i].C % 32) return false;

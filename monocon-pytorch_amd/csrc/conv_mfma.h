@@ -84,11 +84,6 @@ struct ConvArgs {
     const unsigned *amax_in[4];   // per source of the virtual concat
     const unsigned *amax_w;       // of the master weight(s) the panel was cut from
     unsigned *amax_out;           // optional: max |out| of this launch is folded in (eval plans: the consumer's amax_in)
-    // mode 4 (prec == 3 with pexp set; conv_p16.hip): the f16x2 arithmetic on sources STORED as P16 (p16.h: the fp16 pieces of x * 2^e, split once by
-    // the tensor's producer; src[i].p then points at P16 data).  pexp[i]: device word holding the exponent e of source i,
-    // written by whoever produced the tensor; null = source i is plain fp32 (the launch then takes the mode-3 kernels,
-    // which need amax_in[i])
-    const int *pexp[4];
     unsigned long long *phase_prof;   // measurement aid (-DMC_PHASE_TIMERS, mc_bench_conv): per workgroup and wave, cycles spent in
                                       // [0] staging, [1] barriers, [2] MFMA phases, [3] epilogue, [4] total
 };
@@ -765,9 +760,6 @@ hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal,
 hipError_t launch_absmax(const float *x, size_t n, unsigned *slot, hipStream_t st, bool single_word = false);
 bool conv_wres_ok(const ConvArgs &a, int ks, int stride);             // conv_wres.hip: mode 3, 3x3 stride 1, one 64-channel source
 hipError_t launch_conv_wres(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved);
-bool conv_p16_ok(const ConvArgs &a, int ks, int stride);              // conv_p16.hip: mode 4, stride 1, every source P16
-bool conv_p16_cfg_ok(int cfg, int CoutP, int ks);
-hipError_t launch_conv_p16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved);
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st);
 bool conv_thin_ok(const ConvArgs &a, int ks, int stride);            // conv_thin.hip
 hipError_t launch_conv_thin(const ConvArgs &a, hipStream_t st);

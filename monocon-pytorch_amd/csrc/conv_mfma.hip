@@ -121,18 +121,6 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
     }
     if (a.cfg == CFG_AUTO) a.cfg = conv_pick_cfg(a.Cout, a.CoutP, ks, stride, a.B, a.Hout, a.Wout);
     prof_last = conv_cost(a, ks);
-    {   // mode 4: sources stored as P16 -- all of them, or none (then this is a plain mode-3 launch)
-        int np16 = 0;
-        for (int i = 0; i < a.nsrc; ++i) np16 += a.pexp[i] != nullptr;
-        if (np16) {
-            if (np16 != a.nsrc) return hipErrorInvalidValue;
-            if (conv_p16_ok(a, ks, stride)) {
-                if (!conv_p16_cfg_ok(a.cfg, a.CoutP, ks)) a.cfg = a.CoutP % 128 == 0 ? CFG_64x128 : (a.CoutP % 64 == 0 ? CFG_128x64m : CFG_128x32);
-                return launch_conv_p16(a, ks, stride, st, resolved);
-            }
-            // (stride-2 3x3 layers: the register-staged kernel, whose staging then copies the pieces instead of making them)
-        }
-    }
     if (a.cfg & CFG_WRES) {
         // MONOCON_HIP_WRES=0: A/B switch, every launch takes the tiling its shape bits name
         static const bool wres_on = [] { const char *e = std::getenv("MONOCON_HIP_WRES"); return !e || std::atoi(e) != 0; }();

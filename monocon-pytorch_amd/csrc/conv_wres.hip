@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
 // eligible: f16x2 arithmetic on fp32 sources, 3x3 stride 1, ONE 64-channel source, dense NHWC output of whole 4x16 tiles
 bool conv_wres_ok(const ConvArgs &a, int ks, int stride) {
     if (a.prec != 3 || !a.wpk16 || !a.amax_w || ks != 3 || stride != 1) return false;
-    if (a.nsrc != 1 || a.src[0].C != 64 || a.Cin != 64 || !a.amax_in[0] || a.pexp[0]) return false;
+    if (a.nsrc != 1 || a.src[0].C != 64 || a.Cin != 64 || !a.amax_in[0]) return false;
     if (a.CoutP % 64 || a.Hin != a.Hout || a.Win != a.Wout || a.Wout % 16 || a.Hout % 4) return false;
     if ((size_t)a.Hin * a.Win * 64 * 4 >= ((size_t)1 << 31)) return false;       // 32-bit buffer offsets per image
     if (a.bm_y && !a.stats) return false;

@@ -7,7 +7,6 @@
 // ConvTranspose2d in the reference's BasicBlock, Root, Tree, Conv2dBlock, IDAUp
 // (model/backbone/dla.py:34-51,124-132,187-205; dla_neck.py:34-38,94-106).
 #include "conv_mfma.h"
-#include "p16.h"
 #include "train.h"
 #include <cstdlib>
 #include <cstring>
@@ -27,23 +26,11 @@ static int red_rows(int B, int rows_per_img) {
     while (r > 32 && (long long)B * ((rows_per_img + r - 1) / r) < 1024) r >>= 1;
     return r;
 }
-// hi pieces (as floats: only their sign is used) of quad element `e` = pixel * C4 + q of a P16 tensor
-__device__ __forceinline__ f32x4 p16_hi4(const float *base, unsigned e, int C4) {
-    const unsigned pix = e / (unsigned)C4, q = e % (unsigned)C4;
-    const f16x4 h = *reinterpret_cast<const f16x4 *>(reinterpret_cast<const char *>(base) + (size_t)pix * C4 * 16 + p16_quad_off((int)q));
-    f32x4 v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (float)h[j];
-    return v;
-}
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restrict__ y, const float *__restrict__ dz,
                                                           const float *__restrict__ z, const float *__restrict__ shift,
                                                           int rows_per_img, int RED_ROWS, int C, int mode, int relu,
                                                           float *__restrict__ partial, int Cstride,
-                                                          const float *__restrict__ fa, const float *__restrict__ fb,
-                                                          int z16, unsigned *__restrict__ amax_d) {
-    // z16 (mode 4): z is stored as P16 -- the mask needs only the sign of its hi piece; amax_d: max |masked d| into the slot
-    float vmax = 0.f;
+                                                          const float *__restrict__ fa, const float *__restrict__ fb) {
     const int C4 = C >> 2;
     const int RG = 256 / C4 > 0 ? 256 / C4 : 1;
     const int tid = threadIdx.x;
@@ -70,7 +57,6 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
                     if (relu == 1) d[j] = zv[j] > 0.f ? d[j] : 0.f;
                     else if (relu == 2) d[j] = fmaf(yv[j], ma[j], mb[j]) > 0.f ? d[j] : 0.f;
                     s1[j] += d[j]; s2[j] += d[j] * yv[j];
-                    vmax = fmaxf(vmax, fabsf(d[j]));
                 }
             }
         };
@@ -89,7 +75,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
                 for (int u = 0; u < 4; ++u) dv[u] = d4[e + u * step];
                 if (relu == 1) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) zv[u] = z16 ? p16_hi4(z, e + u * step, C4) : z4[e + u * step];
+                    for (int u = 0; u < 4; ++u) zv[u] = z4[e + u * step];
                 }
             }
 #pragma unroll
@@ -97,7 +83,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
         }
         for (; r < r1; r += RG) {
             const unsigned e = base + (unsigned)r * C4;
-            one(y4[e], mode != 0 ? d4[e] : zero, (mode != 0 && relu == 1) ? (z16 ? p16_hi4(z, e, C4) : z4[e]) : zero);
+            one(y4[e], mode != 0 ? d4[e] : zero, (mode != 0 && relu == 1) ? z4[e] : zero);
         }
     }
     __shared__ float red[256 * 8];
@@ -113,7 +99,6 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float *__restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) { dst[j * 2] = a1[j]; dst[j * 2 + 1] = a2[j]; }
     }
-    if (amax_d) amax_update_block(amax_d, vmax);
 }
 
 // Measurement aid, compiled in ONLY with -DMC_DEBUG_HOOKS (never in the shipped library: a stray environment
@@ -138,12 +123,12 @@ int chan_reduce_blocks(int B, int rows_per_img) {
 }
 hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, const float *shift, int B, int rows_per_img,
                               int C, int mode, int relu, float *partial, int Cstride, hipStream_t st, const float *fa,
-                              const float *fb, int z16, unsigned *amax_d) {
+                              const float *fb) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
     if (relu == 2 && (!fa || !fb)) return hipErrorInvalidValue;
     if (dbg_skip("cred")) return hipSuccess;
     hipLaunchKernelGGL(chan_reduce_kernel, dim3(chan_reduce_blocks(B, rows_per_img)), dim3(256), 0, st, y, dz, z, shift,
-                       rows_per_img, red_rows(B, rows_per_img), C, mode, relu, partial, Cstride, fa, fb, z16, amax_d);
+                       rows_per_img, red_rows(B, rows_per_img), C, mode, relu, partial, Cstride, fa, fb);
     return hipGetLastError();
 }
 
@@ -602,8 +587,7 @@ hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C
 // ... and wrt the (C,1,4,4) weights: dw[c,ky,kx] = sum_{b,iy,ix} in[b,iy,ix,c] * dout[b,2iy-1+ky,2ix-1+kx,c].
 // One workgroup per (image row-block); partial [blocks][16][C] then reduced by colsum-like pass.
 __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restrict__ in, const float *__restrict__ dout,
-                                                            int B, int H, int W, int C, float *__restrict__ partial,
-                                                            const int *__restrict__ e_in /*non-null: `in` is stored as P16*/) {
+                                                            int B, int H, int W, int C, float *__restrict__ partial) {
     // one workgroup per (b, iy) input row; a thread owns 4 channels and every XG-th column, 16-byte
     // loads; the column groups are summed by wave shuffles + one LDS image (fixed order)
     __shared__ float red[16][256];
@@ -614,10 +598,8 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
     f32x4 acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float in_inv = e_in ? exp2i(-*e_in) : 1.f;
     for (int ix = xg; ix < W; ix += XG) {
-        const f32x4 v = e_in ? p16_load4(reinterpret_cast<const char *>(in) + (((size_t)b * H + iy) * W + ix) * C4 * 16, c4, in_inv)
-                             : in4[(((size_t)b * H + iy) * W + ix) * C4 + c4];
+        const f32x4 v = in4[(((size_t)b * H + iy) * W + ix) * C4 + c4];
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
             const int oy = 2 * iy - 1 + ky;
@@ -667,9 +649,9 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_reduce_kernel(const float *
 }
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C) { return (size_t)B * H * 16 * C; }
 hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
-                                hipStream_t st, const int *e_in) {
+                                hipStream_t st) {
     if (C % 4 || C > 256 || 256 % (C / 4)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(deconv4_bwd_w_kernel, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, e_in);
+    hipLaunchKernelGGL(deconv4_bwd_w_kernel, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial);
     hipLaunchKernelGGL(deconv4_bwd_w_reduce_kernel, dim3(C * 16), dim3(256), 0, st, partial, B * H, C, dw);
     return hipGetLastError();
 }

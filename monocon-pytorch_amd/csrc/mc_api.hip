@@ -24,7 +24,6 @@
 
 #include <cstdint>
 #include "mc_internal.h"
-#include "p16.h"
 
 std::string g_create_err;
 
@@ -311,19 +310,10 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     if (small_ok && !(a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride))) return CFG_SMALL;
     if (h->force_cfg) return h->force_cfg;   // mc_set_conv_cfg: every other layer
     int heuristic = small_ok ? (int)CFG_SMALL : conv_pick_cfg(a_in.Cout, a_in.CoutP, ks, stride, a_in.B, a_in.Hout, a_in.Wout);
-    {
-        bool all16 = a_in.nsrc > 0;
-        for (int i = 0; i < a_in.nsrc; ++i) all16 = all16 && a_in.pexp[i];
-        if (all16 && conv_p16_ok(a_in, ks, stride) && !conv_p16_cfg_ok(heuristic, a_in.CoutP, ks))
-            heuristic = a_in.CoutP % 128 == 0 ? CFG_64x128 : (a_in.CoutP % 64 == 0 ? CFG_128x64m : CFG_128x32);
-    }
     if (!h->autotune) return heuristic;
     const bool b16 = a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride);
-    bool p16 = a_in.nsrc > 0;                       // mode 4: the DMA-staged kernel has its own shape list
-    for (int i = 0; i < a_in.nsrc; ++i) p16 = p16 && a_in.pexp[i];
-    p16 = p16 && conv_p16_ok(a_in, ks, stride);
     std::vector<int> key = {a_in.B, a_in.Hin, a_in.Win, ks, stride, a_in.Cout, a_in.CoutP, a_in.nsrc,
-                            (a_in.res ? 1 : 0) | (b16 ? 2 * a_in.prec : 0) | (p16 ? 16 : 0)};
+                            (a_in.res ? 1 : 0) | (b16 ? 2 * a_in.prec : 0)};
     for (int i = 0; i < a_in.nsrc; ++i) key.push_back(a_in.src[i].C);
     auto it = h->tuned.find(key);
     if (it != h->tuned.end()) return it->second;
@@ -340,7 +330,6 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
         if (c == CFG_SMALL ? !small_ok : (a.CoutP % conv_shape(c).BNT()) != 0) continue;
         if ((c & CFG_WS) && (ks >= 10 || b16)) continue;   // no wave-specialised build of these kernels
         if ((c & CFG_WRES) && !conv_wres_ok(a, ks, stride)) continue;
-        if (p16 && !conv_p16_cfg_ok(c, a.CoutP, ks)) continue;
         a.cfg = c;
         if (launch_conv(a, ks, stride, nullptr) != hipSuccess) { (void)hipGetLastError(); continue; }   // warm / unsupported
         float t_min = 1e30f;
@@ -915,20 +904,6 @@ int mc_op_conv(mc_handle *h, const float *const src[], const int src_channels[],
         HIPCHK(h, launch_pack_conv_w_bf16(weight_oihw, Cout, cin, ksize, wpk16.p, cin, a.CoutP, 0, 0, pieces, st, sl));
         a.wpk16 = wpk16.p; a.prec = h->prec;
     }
-    ScratchBuf p16buf[4], p16exp;     // mode 4: the sources enter as fp32 -- re-stored as P16 with their maximum's exponent
-    if (h->p16 && h->prec == 3 && a.wpk16 && a.amax_in[0]) {
-        HIPCHK(h, p16exp.alloc(4 * sizeof(int)));
-        for (int i = 0; i < nsrc; ++i) {
-            const size_t px = (size_t)B * Hin * Win;
-            HIPCHK(h, p16buf[i].alloc(px * src_channels[i] * 4));
-            HIPCHK(h, launch_p16_encode(src[i], px, src_channels[i], a.amax_in[i], p16buf[i].p, p16exp.as<int>() + i, st));
-            a.src[i].p = p16buf[i].as<float>();
-            a.pexp[i] = p16exp.as<int>() + i;
-        }
-        // (shapes neither P16 kernel takes -- 16-channel layers, stride 2 with a source that is no multiple of 32 -- stay fp32)
-        if (!(conv_p16_ok(a, ksize, stride) || (stride == 2 && nsrc == 1 && conv_bf16_ok(a, ksize, stride))))
-            for (int i = 0; i < nsrc; ++i) { a.src[i].p = src[i]; a.pexp[i] = nullptr; }
-    }
     a.scale = scale; a.bias = bias; a.res = residual; a.res_ld = Cout;
     a.out = out; a.out_ld = Cout; a.out_coff = 0; a.relu = relu;
     a.cfg = h->force_cfg;
@@ -1185,16 +1160,15 @@ int mc_tune_import(mc_handle *h, const int *buf, int n_ints) {
 
 int mc_set_precision(mc_handle *h, int mode) {
     if (!h) return -1;
-    if (mode < 0 || mode > 4)
+    // (mode 4 of round 4 -- mode 3 on activations stored pre-split, DMA-staged -- was retired in round 5: slower in the step,
+    //  and its weight gradients were not bit-reproducible beside the weight-gradient stream)
+    if (mode < 0 || mode > 3)
         return fail(h, "mc_set_precision: mode must be 0 (fp32 MFMA), 1 (bf16 MFMA operands), 2 (fp32 emulated by a 3-way bf16 "
-                       "split), 3 (fp32 emulated by a 2-way fp16 split) or 4 (mode 3 on P16-stored activations)");
-    const bool p16 = mode == 4;
-    if (p16) mode = 3;          // the same arithmetic; what changes is where the split is made (p16.h)
-    if (mode == h->prec && p16 == h->p16) return 0;
+                       "split) or 3 (fp32 emulated by a 2-way fp16 split)");
+    if (mode == h->prec) return 0;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     h->prec = mode;
-    h->p16 = p16;
     for (auto &kv : h->plans)
         for (void *q : kv.second->bufs) (void)hipFree(q);
     h->plans.clear();

@@ -236,28 +236,38 @@ int mc_comm_init(mc_handle *h, int rank, int world, const void *id128) {
     std::memcpy(&id, id128, sizeof id);
     // ncclCommInitRank blocks until ALL ranks have joined: a rank that died on its way here (or never got the id) would
     // leave the others waiting forever, with nothing on the screen.  The call therefore runs on a helper thread under a
-    // watchdog (MONOCON_HIP_COMM_TIMEOUT_S, default 60 s): on expiry this rank reports who it is and fails -- the
-    // binding then raises / falls back on every rank together.  (The helper stays blocked inside RCCL; it holds no
-    // reference to the handle.)
-    struct Pending { std::mutex m; std::condition_variable cv; bool done = false; int rc = 0; Comm comm = nullptr; };
+    // watchdog (MONOCON_HIP_COMM_TIMEOUT_S; default 60 s + 5 s per rank: a cold multi-process start-up takes longer the
+    // more ranks there are): on expiry this rank reports who it is and fails -- the binding then raises / falls back on every
+    // rank together.  The helper stays blocked inside RCCL and holds no reference to the handle; should the late rank still
+    // arrive, the helper finds the call ABANDONED and destroys the communicator it was handed (it used to leak
+    // on this rank while the peers held a live one).
+    struct Pending { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; int rc = 0; Comm comm = nullptr; };
     auto pend = std::make_shared<Pending>();
     const int device = h->device;
     const CommInitRankFn init_fn = g_rccl.comm_init_rank;
-    std::thread([pend, device, init_fn, world, id, rank] {
+    const auto destroy_fn = g_rccl.comm_destroy;
+    std::thread([pend, device, init_fn, destroy_fn, world, id, rank] {
         (void)hipSetDevice(device);
         Comm cm = nullptr;
         const int r = init_fn(&cm, world, id, rank);
-        std::lock_guard<std::mutex> lk(pend->m);
-        pend->rc = r; pend->comm = cm; pend->done = true;
-        pend->cv.notify_all();
+        bool orphan = false;
+        {
+            std::lock_guard<std::mutex> lk(pend->m);
+            pend->rc = r; pend->comm = cm; pend->done = true;
+            orphan = pend->abandoned;
+            pend->cv.notify_all();
+        }
+        if (orphan && r == 0 && cm && destroy_fn) (void)destroy_fn(cm);
     }).detach();
-    double timeout_s = 60.0;
+    double timeout_s = 60.0 + 5.0 * world;
     if (const char *e = std::getenv("MONOCON_HIP_COMM_TIMEOUT_S")) timeout_s = std::atof(e) > 0 ? std::atof(e) : timeout_s;
     {
         std::unique_lock<std::mutex> lk(pend->m);
-        if (!pend->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return pend->done; }))
+        if (!pend->cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return pend->done; })) {
+            pend->abandoned = true;
             return fail(h, "mc_comm_init: rank %d of %d still waits in ncclCommInitRank after %.0f s -- not every rank reached it "
                            "(device %d; MONOCON_HIP_COMM_TIMEOUT_S changes the limit)", rank, world, timeout_s, device);
+        }
         c->comm = pend->comm;
         if (pend->rc) return fail(h, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_err(pend->rc));
     }

@@ -46,7 +46,6 @@ struct Tensor {   // NHWC activation
     float *p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;
     unsigned *amax = nullptr;   // slot receiving max |x| of the tensor (precision mode 3: operand scale of its consumers)
-    int *pexp = nullptr;        // mode 4: the tensor is stored as P16 (p16.h); device word with its exponent, written by its producer
     size_t numel() const { return (size_t)B * H * W * C; }
 };
 
@@ -121,7 +120,6 @@ struct mc_handle {
     size_t decode_count_n = 0;
     int force_cfg = 0;   // tuning aid (mc_bench_conv)
     int prec = 0;        // mc_set_precision: 0 fp32 MFMA, 1 bf16 operands, 2 three-way bf16 split, 3 two-way fp16 split
-    bool p16 = false;    // mc_set_precision(4): prec == 3 arithmetic with the >= 64-channel activations / gradients stored as P16
     unsigned *w_amax_arena = nullptr;                    // mode 3: max |w| per conv layer (+ the fused head panel)
     int w_amax_n = 0;
     std::map<const float *, unsigned *> w_amax_of;       // master weight -> its slot (train plan: data-gradient panels)

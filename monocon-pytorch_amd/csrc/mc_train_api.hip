@@ -1,6 +1,5 @@
 // Training-side C-ABI: target generation, losses (+ gradients wrt the prediction maps).
 #include "mc_internal.h"
-#include "p16.h"
 
 #include <algorithm>
 #include <cmath>
@@ -188,30 +187,6 @@ int mc_op_conv_wgrad(mc_handle *h, const float *const src[], const int src_chann
         HIPCHK(h, mc::launch_absmax(dy, (size_t)B * a.Hout * a.Wout * Cout, sl + 4 * mc::AMAX_WORDS, st));
         a.amax_dy = sl + 4 * mc::AMAX_WORDS;
     }
-    // mode 4: operands of >= 64 channels are stored as P16 inside a plan (test hook: MONOCON_HIP_P16_OPERANDS = x, d or xd
-    // picks which of the two enter that way here; default both)
-    ScratchBuf x16[4], d16, exps;
-    if (h->p16 && h->prec == 3) {
-        const char *sel = std::getenv("MONOCON_HIP_P16_OPERANDS");
-        const bool want_x = !sel || std::strchr(sel, 'x'), want_d = !sel || std::strchr(sel, 'd');
-        HIPCHK(h, exps.alloc(5 * sizeof(int)));
-        bool x_ok = want_x;
-        for (int i = 0; i < nsrc; ++i) x_ok = x_ok && src_channels[i] % 8 == 0;
-        for (int i = 0; i < nsrc && x_ok; ++i) {
-            const size_t px = (size_t)B * Hin * Win;
-            HIPCHK(h, x16[i].alloc(px * src_channels[i] * 4));
-            HIPCHK(h, mc::launch_p16_encode(src[i], px, src_channels[i], a.amax_x[i], x16[i].p, exps.as<int>() + i, st));
-            a.src[i].p = x16[i].as<float>();
-            a.pexp_x[i] = exps.as<int>() + i;
-        }
-        if (want_d && Cout % 8 == 0) {
-            const size_t px = (size_t)B * a.Hout * a.Wout;
-            HIPCHK(h, d16.alloc(px * Cout * 4));
-            HIPCHK(h, mc::launch_p16_encode(dy, px, Cout, a.amax_dy, d16.p, exps.as<int>() + 4, st));
-            a.dy = d16.as<float>();
-            a.pexp_dy = exps.as<int>() + 4;
-        }
-    }
     mc::wgrad_plan(a, ksize, stride);
     void *part = nullptr;
     HIPCHK(h, hipMalloc(&part, mc::wgrad_partial_floats(a, ksize) * sizeof(float)));
@@ -248,12 +223,6 @@ int mc_op_conv_dgrad(mc_handle *h, const float *dy, const float *weight_oihw, in
         HIPCHK(h, mc::launch_absmax(dy, (size_t)B * Ho * Wo * Cout, sl, st));
         HIPCHK(h, mc::launch_absmax(weight_oihw, (size_t)Cout * CinTotal * ksize * ksize, sl + mc::AMAX_WORDS, st, true));
     }
-    ScratchBuf dy16, dy16e;   // mode 4: dY re-stored as P16 (inside a train plan its producer writes it that way)
-    if (h->p16 && sl && Cout % 32 == 0) {
-        HIPCHK(h, dy16.alloc((size_t)B * Ho * Wo * Cout * 4));
-        HIPCHK(h, dy16e.alloc(sizeof(int)));
-        HIPCHK(h, mc::launch_p16_encode(dy, (size_t)B * Ho * Wo, Cout, sl, dy16.p, dy16e.as<int>(), st));
-    }
     for (int cls = 0; cls < nclass && e == hipSuccess; ++cls) {
         const int cid = stride == 2 ? cls : -1;
         const int py = cls >> 1, px = cls & 1;
@@ -279,7 +248,6 @@ int mc_op_conv_dgrad(mc_handle *h, const float *dy, const float *weight_oihw, in
         d.Cin = Cout; d.Cout = Cs; d.CoutP = CsP; d.wpk = static_cast<float *>(panel);
         d.wpk16 = panel16; d.prec = panel16 ? h->prec : 0;
         if (sl) { d.amax_in[0] = sl; d.amax_w = sl + mc::AMAX_WORDS; }
-        if (dy16.p && panel16) { d.src[0].p = dy16.as<float>(); d.pexp[0] = dy16e.as<int>(); }
         d.out = dx; d.out_ld = Cs;
         int kk = ksize;
         if (stride == 2) {

@@ -12,7 +12,6 @@
 #include <functional>
 
 #include "mc_internal.h"
-#include "p16.h"
 
 using namespace mc;
 
@@ -98,9 +97,6 @@ struct TrainState {
     // precision mode 3: one max-|x| slot per activation / gradient tensor, zeroed at the start of every forward
     unsigned *amax_arena = nullptr;
     int amax_used = 0;
-    // mode 4: one exponent word per P16-stored tensor (p16.h), written by the tensor's producer
-    int *exp_arena = nullptr;
-    int exp_used = 0;
     // plan-owned
     mc_targets targets{};
     float *dpred[10] = {nullptr};
@@ -130,19 +126,11 @@ struct TB {   // train plan builder
     std::map<const float *, int> pooled;
     void *last_panel16 = nullptr;   // bf16 twin of the panel the last pack_job() made
 
-    static constexpr int AMAX_SLOTS = 1024, EXP_SLOTS = 1024;
+    static constexpr int AMAX_SLOTS = 1024;
     // bn_backward(): the caller consumes (d, y, coef) itself -- no element-wise dY pass (the stem, whose dY is read by its
     // weight gradient only); honoured on the backward-statistics-epilogue path, reported back in did_skip_affine
     bool want_skip_affine = false, did_skip_affine = false;
     float *skip_coef = nullptr;
-    // mode 4: which tensors are stored as P16 -- activations and BatchNorm-input gradients of >= 64 channels (the 16- and
-    // 32-channel maps of the stem / level0 / level1 keep fp32 and their own kernels)
-    bool is16(int C) const { return h->p16 && h->prec == 3 && C >= 64 && C % 8 == 0; }
-    int *eslot() {
-        if (!ts->exp_arena) ts->exp_arena = reinterpret_cast<int *>(alloc(EXP_SLOTS));
-        if (ts->exp_used >= EXP_SLOTS) { ts->ok = false; h->err = "train plan: exponent slot table overflow"; return nullptr; }
-        return ts->exp_arena ? ts->exp_arena + ts->exp_used++ : nullptr;
-    }
     unsigned *slot() {        // mode 3: a fresh max-|x| slot (null in the other modes)
         if (h->prec != 3) return nullptr;
         if (!ts->amax_arena) ts->amax_arena = reinterpret_cast<unsigned *>(alloc((size_t)AMAX_SLOTS * AMAX_WORDS));
@@ -230,12 +218,11 @@ struct TB {   // train plan builder
         for (char c : ts->bwd_side) k += c != 0;
         return k - 1;
     }
-    int node(int B, int H, int W, int C, bool needs_grad = true, bool allow16 = true) {
+    int node(int B, int H, int W, int C, bool needs_grad = true) {
         TNode n;
         n.t.B = B; n.t.H = H; n.t.W = W; n.t.C = C;
         n.t.p = alloc_map(n.t.numel());
         n.t.amax = slot();
-        if (allow16 && is16(C)) n.t.pexp = eslot();
         n.needs_grad = needs_grad;
         if (needs_grad && !pool_on) n.g = alloc(n.t.numel());
         ts->nodes.push_back(n);
@@ -295,19 +282,9 @@ struct TB {   // train plan builder
         a.wpk = Lr.wpk; a.out = r.y.p; a.out_ld = Lr.cout;
         a.wpk16 = Lr.wpk16; a.prec = h->prec;
         if (h->prec == 3) {
-            int n16 = 0;
-            for (int i = 0; i < a.nsrc; ++i) {
-                a.amax_in[i] = ts->nodes[srcs[i]].t.amax;
-                a.pexp[i] = ts->nodes[srcs[i]].t.pexp;
-                n16 += a.pexp[i] != nullptr;
-            }
-            if (n16 && n16 != a.nsrc) { ts->ok = false; h->err = "train plan: mixed fp32 / P16 sources at " + Lr.conv; }
+            for (int i = 0; i < a.nsrc; ++i) a.amax_in[i] = ts->nodes[srcs[i]].t.amax;
             a.amax_w = Lr.w_amax;
         }
-        // mode 4: the BatchNorm apply that follows writes z as P16 and needs max |y| BEFORE it starts (its exponent bound)
-        unsigned *yslot = is16(Lr.cout) ? slot() : nullptr;
-        r.y.amax = yslot;
-        a.amax_out = yslot;
         a.cfg = ts->ok ? mc_choose_conv_cfg(h, a, Lr.ks, Lr.stride) : CFG_128x32;
         const int chunks = conv_chunks_per_image(a.cfg, Ho, Wo);
         float *stats = alloc((size_t)B * chunks * Lr.coutp * 2);
@@ -325,12 +302,8 @@ struct TB {   // train plan builder
             unsigned *zmax = ts->nodes[r.z].t.amax;
             const size_t rows = (size_t)Ho * Wo;
             const int C = Lr.cout, rl = relu;
-            int *zexp = ts->nodes[r.z].t.pexp;
-            const int *rexp = res >= 0 ? ts->nodes[res].t.pexp : nullptr;
-            if (zexp && res >= 0 && !rexp) { ts->ok = false; h->err = "train plan: fp32 residual into a P16 map at " + Lr.conv; }
             ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                if (zexp) HIPCHK(hh, launch_affine_act_p16(yp, ca, cb, rp, rexp, B, rows, C, rl, zp, zexp, yslot, st));
-                else HIPCHK(hh, launch_affine_act(yp, ca, cb, rp, B, rows, C, 0, rl, zp, st, zmax));
+                HIPCHK(hh, launch_affine_act(yp, ca, cb, rp, B, rows, C, 0, rl, zp, st, zmax));
                 return 0;
             });
         }
@@ -342,16 +315,13 @@ struct TB {   // train plan builder
         const Tensor t = ts->nodes[x].t;           // by value (see conv_bn)
         auto it = pooled.find(t.p);
         if (it != pooled.end()) return it->second;
-        const int o = node(t.B, t.H / 2, t.W / 2, t.C, true, t.pexp != nullptr);
+        const int o = node(t.B, t.H / 2, t.W / 2, t.C, true);
         ts->nodes[o].t.amax = t.amax;          // max |pool(x)| <= max |x|: the input's slot serves
-        ts->nodes[o].t.pexp = t.pexp;          // (mode 4: a selection keeps the exponent)
         const float *ip = t.p;
         float *op = ts->nodes[o].t.p;
         const int B = t.B, H = t.H, W = t.W, C = t.C;
-        const bool p16 = t.pexp != nullptr;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            if (p16) HIPCHK(hh, launch_maxpool2_p16(ip, B, H, W, C, op, st));
-            else HIPCHK(hh, launch_maxpool2(ip, B, H, W, C, op, st));
+            HIPCHK(hh, launch_maxpool2(ip, B, H, W, C, op, st));
             return 0;
         });
         Rec r;
@@ -363,21 +333,13 @@ struct TB {   // train plan builder
 
     int deconv(DeconvLayer &D, int x) {
         const Tensor t = ts->nodes[x].t;           // by value (see conv_bn)
-        const int o = node(t.B, t.H * 2, t.W * 2, t.C, true, t.pexp != nullptr);
+        const int o = node(t.B, t.H * 2, t.W * 2, t.C, true);
         const float *ip = t.p, *w = D.wpk;
         float *op = ts->nodes[o].t.p;
         unsigned *omax = ts->nodes[o].t.amax;
         const int B = t.B, H = t.H, W = t.W, C = t.C;
-        const int *iexp = t.pexp;
-        int *oexp = ts->nodes[o].t.pexp;
-        float *wb = iexp ? alloc(1) : nullptr;          // mode 4: max_c sum_taps |w|, refreshed with the weights every forward
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            if (iexp) {
-                HIPCHK(hh, launch_deconv_wbound(w, C, wb, st));
-                HIPCHK(hh, launch_deconv4_p16(ip, iexp, B, H, W, C, w, wb, op, oexp, st));
-            } else {
-                HIPCHK(hh, launch_deconv4(ip, B, H, W, C, w, op, st, omax));
-            }
+            HIPCHK(hh, launch_deconv4(ip, B, H, W, C, w, op, st, omax));
             return 0;
         });
         Rec r;
@@ -451,7 +413,6 @@ struct TB {   // train plan builder
                 d.Cin = dy.C; d.Cout = sn.t.C; d.CoutP = csp; d.wpk = panel;
                 d.wpk16 = last_panel16; d.prec = last_panel16 ? h->prec : 0;
                 d.amax_in[0] = dy.amax; d.amax_w = w_slot(w_master);
-                d.pexp[0] = last_panel16 ? dy.pexp : nullptr;
                 const int ld = sn.t.C;
                 d.out = sn.g + ((size_t)py * sn.t.W + px) * ld; d.out_ld = ld;
                 d.o_px = 2 * ld; d.o_row = 2 * sn.t.W * ld; d.o_img = sn.t.H * sn.t.W * ld;
@@ -477,7 +438,6 @@ struct TB {   // train plan builder
         d.Cin = dy.C; d.Cout = sn.t.C; d.CoutP = csp; d.wpk = panel;
         d.wpk16 = last_panel16; d.prec = last_panel16 ? h->prec : 0;
         d.amax_in[0] = dy.amax; d.amax_w = w_slot(w_master);
-        d.pexp[0] = last_panel16 ? dy.pexp : nullptr;
         d.out = sn.g; d.out_ld = sn.t.C;
         if (sn.ginit) { d.res = sn.g; d.res_ld = sn.t.C; }
         if (Hd != sn.t.H || Wd != sn.t.W) { ts->ok = false; h->err = "train plan: dgrad shape mismatch"; }
@@ -505,11 +465,9 @@ struct TB {   // train plan builder
             a.src[i].p = ts->nodes[srcs[i]].t.p;
             a.src[i].C = ts->nodes[srcs[i]].t.C;
             a.amax_x[i] = ts->nodes[srcs[i]].t.amax;
-            a.pexp_x[i] = ts->nodes[srcs[i]].t.pexp;
             cin += a.src[i].C;
         }
         a.amax_dy = dy.amax;
-        a.pexp_dy = dy.pexp;
         const Tensor &s0 = ts->nodes[srcs[0]].t;
         a.B = s0.B; a.Hin = s0.H; a.Win = s0.W; a.Hout = dy.H; a.Wout = dy.W; a.Cin = cin; a.Cout = Cout;
         a.dy = dy.p; a.dy_ld = dy_ld;
@@ -528,13 +486,6 @@ struct TB {   // train plan builder
         dy.p = zn.g;
         dy.amax = slot();
         unsigned *dymax = dy.amax;
-        // mode 4: dY of a >= 64-channel layer is stored as P16; its exponent bound needs max |d| (the masked gradient of z)
-        // and max |y| before the pass starts
-        dy.pexp = (is16(r.y.C) && r.y.amax) ? eslot() : nullptr;
-        int *dyexp = dy.pexp;
-        unsigned *dslot = dyexp ? slot() : nullptr;
-        const unsigned *yslot = r.y.amax;
-        const bool z16 = zn.t.pexp != nullptr;
         const int B = r.y.B, C = r.y.C, rows = r.y.H * r.y.W;
         const float *yp = r.y.p, *gz = zn.g, *zp = zn.t.p, *gamma = P(bn + ".weight"), *mean = r.mean, *rstd = r.rstd;
         float *dg = G(bn + ".weight"), *db = G(bn + ".bias"), *dyp = dy.p;
@@ -561,10 +512,7 @@ struct TB {   // train plan builder
         if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
             fprintf(stderr, "[plan] bn_backward %-40s %4d ch %4dx%-4d relu %d res %d last-writer-conv %d\n", bn.c_str(), C, r.y.H,
                     r.y.W, relu, r.res >= 0, lc != nullptr);
-        // (mode 4: the epilogue's ReLU mask from a STORED activation reads fp32 z -- residual layers, whose z is P16 here,
-        //  take the reduction pass instead)
-        if (lc && lc->out == zn.g && lc->Cout == C && lc->out_ld == C && lc->Hout == r.y.H && lc->Wout == r.y.W && !lc->stats &&
-            !(z16 && relu == 1)) {
+        if (lc && lc->out == zn.g && lc->Cout == C && lc->out_ld == C && lc->Hout == r.y.H && lc->Wout == r.y.W && !lc->stats) {
             // the gradient of this map was completed by a data-gradient conv: its epilogue masks it and emits the
             // (sum d, sum d*y) partials per 4x8 patch -- no reduction pass, and the affine pass needs no mask
             const int ppi = conv_chunks_per_image(lc->cfg, r.y.H, r.y.W), nbp = B * ppi, cstride = lc->CoutP;   // per 4x8 patch / per row
@@ -572,9 +520,8 @@ struct TB {   // train plan builder
             lc->stats = partial;
             lc->bm_y = yp; lc->bm_z = zp; lc->bm_a = fa; lc->bm_b = fb; lc->bm_relu = relu;
             if (wres_bwd >= 1 && !(lc->cfg & (CFG_SMALL | CFG_WS)) && conv_wres_ok(*lc, 3, 1)) lc->cfg |= CFG_WRES;      // (see emit_dgrad)
-            if (dslot) lc->amax_out = dslot;
             double *fold = fold_scratch(nbp, C);
-            if (want_skip_affine && !dyexp && !gres) {
+            if (want_skip_affine && !gres) {
                 // the epilogue also leaves max |d| (for the consumer's operand scale); only the coefficients are computed here
                 lc->amax_out = dymax;
                 ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
@@ -587,12 +534,8 @@ struct TB {   // train plan builder
             }
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, cstride, n, C, gamma, mean, rstd, dg, db, coef, st, fold));
-                if (dyexp)
-                    HIPCHK(hh, launch_affine_bwd_p16(gz, nullptr, yp, coef, B, (size_t)rows, C, 0, dyp, gres, gmode, nullptr, nullptr, dyexp,
-                                                     dslot, yslot, st));
-                else
-                    HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, 0, dyp, gres, gmode, st, nullptr, nullptr, nullptr,
-                                                 nullptr, dymax));
+                HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, 0, dyp, gres, gmode, st, nullptr, nullptr, nullptr,
+                                             nullptr, dymax));
                 return 0;
             });
             return dy;
@@ -600,14 +543,9 @@ struct TB {   // train plan builder
         const int nb = chan_reduce_blocks(B, rows);
         float *partial = alloc((size_t)nb * C * 2);
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_chan_reduce(yp, gz, zp, nullptr, B, rows, C, 1, relu, partial, C, st, fa, fb, z16 ? 1 : 0, dslot));
+            HIPCHK(hh, launch_chan_reduce(yp, gz, zp, nullptr, B, rows, C, 1, relu, partial, C, st, fa, fb));
             HIPCHK(hh, launch_bn_bwd_finalize(partial, nb, C, n, C, gamma, mean, rstd, dg, db, coef, st));
-            if (dyexp)
-                HIPCHK(hh, launch_affine_bwd_p16(gz, zp, yp, coef, B, (size_t)rows, C, relu, dyp, gres, gmode, fa, fb, dyexp, dslot, yslot, st));
-            else if (z16)
-                return fail(hh, "train plan: fp32 dY of a layer whose activation is stored as P16");
-            else
-                HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, relu, dyp, gres, gmode, st, fa, fb, nullptr, nullptr,
+            HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, relu, dyp, gres, gmode, st, fa, fb, nullptr, nullptr,
                                              dymax));
             return 0;
         });
@@ -636,7 +574,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     if (head_only) {
         // the heads on their own (MonoConDenseHeads.forward_train, monocon_heads.py:150-157): the neck output is an
         // external NCHW tensor, copied into the plan's NHWC node; its gradient is copied out after the backward
-        feat = b.node(B, fh, fw, 64, true, /*allow16=*/false);
+        feat = b.node(B, fh, fw, 64, true);
         float *fp = ts->nodes[feat].t.p;
         unsigned *fmax = ts->nodes[feat].t.amax;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
@@ -739,7 +677,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         c3.B = B; c3.Hin = fh; c3.Win = fw; c3.Hout = fh; c3.Wout = fw; c3.Cin = 64; c3.Cout = CP; c3.CoutP = h->head3.coutp;
         c3.wpk = h->head3.wpk; c3.bias = h->head_bias; c3.out = xh.p; c3.out_ld = CP; c3.cfg = h->head3.cfg;
         c3.wpk16 = h->head3.wpk16; c3.prec = h->prec;
-        if (h->prec == 3) { c3.amax_in[0] = fn.t.amax; c3.pexp[0] = fn.t.pexp; c3.amax_w = h->head3.w_amax; }
+        if (h->prec == 3) { c3.amax_in[0] = fn.t.amax; c3.amax_w = h->head3.w_amax; }
         at.chunks = conv_chunks_per_image(c3.cfg, fh, fw);
         at.stat_ld = h->head3.coutp;
         float *stats = b.alloc((size_t)B * at.chunks * at.stat_ld * 2);
@@ -909,10 +847,8 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             const float *xp = in.t.p, *go = o.g;
             float *gi = b.g_acquire(r.in);
             const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C, acc = in.ginit;
-            const bool x16 = in.t.pexp != nullptr;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                if (x16) HIPCHK(hh, launch_maxpool2_bwd_p16(xp, go, Bq, Hq, Wq, Cq, gi, acc, st));
-                else HIPCHK(hh, launch_maxpool2_bwd(xp, go, Bq, Hq, Wq, Cq, gi, acc, st));
+                HIPCHK(hh, launch_maxpool2_bwd(xp, go, Bq, Hq, Wq, Cq, gi, acc, st));
                 return 0;
             });
             in.ginit = true;
@@ -927,10 +863,9 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             float *gi = b.g_acquire(r.in), *dw = b.G(r.D->name + ".weight");
             const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C;
             float *part = b.alloc(deconv4_bwd_w_partial_floats(Bq, Hq, Cq));
-            const int *xexp = in.t.pexp;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 HIPCHK(hh, launch_deconv4_bwd_data(go, Bq, Hq, Wq, Cq, wp, gi, st));
-                HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st, xexp));
+                HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st));
                 return 0;
             });
             in.ginit = true;
@@ -954,7 +889,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             // mode 3: the stem's dY has ONE reader, its weight gradient -- which forms it on the fly from (d, y, coefficients)
             // instead of reading what an element-wise pass wrote (MONOCON_HIP_STEM_FUSE=0: the separate pass)
             static const bool stem_fuse = [] { const char *e = std::getenv("MONOCON_HIP_STEM_FUSE"); return !e || std::atoi(e) != 0; }();
-            b.want_skip_affine = stem_fuse && h->prec == 3 && !h->p16 && ts->img_amax && r.y.amax && W % 4 == 0 && W >= 16;
+            b.want_skip_affine = stem_fuse && h->prec == 3 && ts->img_amax && r.y.amax && W % 4 == 0 && W >= 16;
             b.did_skip_affine = false;
             Tensor dy = b.bn_backward(r, r.bn);
             b.want_skip_affine = false;
@@ -1132,14 +1067,6 @@ int mc_train_debug_node(mc_handle *h, int node, int which, float *out_nchw, int 
     const float *src = which ? n.g : n.t.p;
     if (!src) return fail(h, "mc_train_debug_node: node has no such buffer");
     hipStream_t dst_st = static_cast<hipStream_t>(stream);
-    if (!which && n.t.pexp) {        // mode 4: the activation is stored as P16 -- decode into a temporary first
-        ScratchBuf tmp;
-        HIPCHK(h, tmp.alloc(n.t.numel() * sizeof(float)));
-        HIPCHK(h, launch_p16_decode(n.t.p, (size_t)n.t.B * n.t.H * n.t.W, n.t.C, n.t.pexp, tmp.as<float>(), dst_st));
-        HIPCHK(h, launch_nhwc_to_nchw(tmp.as<float>(), n.t.B, n.t.C, n.t.H, n.t.W, out_nchw, dst_st));
-        HIPCHK(h, hipStreamSynchronize(dst_st));
-        return 0;
-    }
     HIPCHK(h, launch_nhwc_to_nchw(src, n.t.B, n.t.C, n.t.H, n.t.W, out_nchw, dst_st));
     return 0;
 }

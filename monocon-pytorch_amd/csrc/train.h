@@ -104,7 +104,7 @@ int opt_partial_floats();
 int chan_reduce_blocks(int B, int rows_per_img);
 hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, const float *shift, int B, int rows_per_img,
                               int C, int mode, int relu, float *partial, int Cstride, hipStream_t st, const float *fa = nullptr,
-                              const float *fb = nullptr, int z16 = 0, unsigned *amax_d = nullptr);   // mode 4: z stored as P16; max |masked d|
+                              const float *fb = nullptr);
 hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
                               const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
                               long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st,
@@ -130,18 +130,7 @@ hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C
                                    hipStream_t st);
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C);
 hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
-                                hipStream_t st, const int *e_in = nullptr);      // e_in: `in` is stored as P16 with this exponent
-// ---- mode 4: the passes that produce / consume P16 tensors (kernels_p16.hip; layout and exponents: p16.h)
-hipError_t launch_affine_act_p16(const float *y, const float *a, const float *b, const void *res16, const int *e_res, int B,
-                                 size_t rows_per_img, int C, int relu, void *z16, int *e_out, const unsigned *y_amax, hipStream_t st);
-hipError_t launch_affine_bwd_p16(const float *dz, const void *z16, const float *y, const float *coef, int B, size_t rows_per_img, int C,
-                                 int relu, void *dy16, float *gres, int gres_mode, const float *fa, const float *fb, int *e_out,
-                                 const unsigned *d_amax, const unsigned *y_amax, hipStream_t st);
-hipError_t launch_maxpool2_p16(const void *in16, int B, int H, int W, int C, void *out16, hipStream_t st);
-hipError_t launch_maxpool2_bwd_p16(const void *x16, const float *dout, int B, int H, int W, int C, float *dx, int accumulate, hipStream_t st);
-hipError_t launch_deconv4_p16(const void *in16, const int *e_in, int B, int H, int W, int C, const float *wpk, const float *wbound,
-                              void *out16, int *e_out, hipStream_t st);
-hipError_t launch_deconv_wbound(const float *wpk, int C, float *out, hipStream_t st);
+                                hipStream_t st);
 
 // ---- head / stem train kernels (kernels_head_train.hip)
 hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
@@ -194,7 +183,6 @@ struct WgradArgs {
     int pb;                   // 32-pixel patches per staged group (2, or 1 for the split kernels)
     int pipe;                 // != 0: the software-pipelined fp16-split kernel (wgrad_pipe.hip) with this tile; ksplit = slices
     const unsigned *amax_x[4], *amax_dy;   // prec 3: max |x| (bit patterns) of every source and of dY (see ConvArgs::amax_in)
-    const int *pexp_x[4], *pexp_dy;        // mode 4: non-null = that operand is stored as P16 with this exponent (p16.h)
 };
 void wgrad_plan(WgradArgs &a, int ks, int stride);            // fills the tiling fields
 size_t wgrad_partial_floats(const WgradArgs &a, int ks);

@@ -23,7 +23,6 @@
 #include <algorithm>
 #include <cstdlib>
 #include "conv_mfma.h"
-#include "p16.h"
 #include "train.h"
 
 namespace mc {
@@ -74,20 +73,6 @@ __device__ __forceinline__ int lds_skew(int channel) { return ((channel >> 4) & 
 // 4-11 with 20-27 gives every group the 16 channels of ONE block: window = (7 or 15) * channel + const mod 16, a bijection.
 __device__ __forceinline__ int lane_chan(int li) { return ((li & 15) >= 4 && (li & 15) < 12) ? (li ^ 16) : li; }
 
-typedef int i32x2_t __attribute__((ext_vector_type(2)));
-// one channel quad of one pixel: fp32 (16 bytes), or P16 (8 bytes of hi pieces + 8 bytes of lo pieces, 16 bytes apart)
-template <bool P16>
-__device__ __forceinline__ f32x4 ld_quad(__amdgpu_buffer_rsrc_t r, int voff) {
-    if constexpr (P16) {
-        const i32x2_t h = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
-        const i32x2_t l = __builtin_amdgcn_raw_buffer_load_b64(r, voff == BUF_OOB ? BUF_OOB : voff + 16, 0, 0);
-        i32x4 v;
-        v[0] = h[0]; v[1] = h[1]; v[2] = l[0]; v[3] = l[1];
-        return __builtin_bit_cast(f32x4, v);
-    } else {
-        return buf_load4(r, voff, 0);
-    }
-}
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     bf16x2 v;
     v[0] = (__bf16)a;
@@ -99,9 +84,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __device__ int g_phase_delay = 0, g_phase_mode = 0;
 __device__ unsigned *g_lds_dbg = nullptr;
 #endif
-template <int KS, int S, int WN, int WC, int SPL, bool X16 = false, bool D16 = false>
-// X16 / D16 (mode 4, SPL == 2): that operand is stored as P16 (p16.h) -- already scaled and split by its producer, so its
-// staging only transposes (two 8-byte loads per pixel and channel quad, a bit-field merge per packed pixel pair)
+template <int KS, int S, int WN, int WC, int SPL>
 // stride 2 stages 2.7x the halo of stride 1 (6 instead of 2 float4 pairs per thread in flight across the MFMA phase): at
 // two workgroups per CU (256 registers) the kernel spills 17-23 registers; one workgroup per CU without spills is faster
 // (one-session A/B, weight-gradient bucket per step: fp32 kernel 14.6 ms, two per CU 14.0, one per CU 13.6)
@@ -150,8 +133,8 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
     const int cs0 = c0 - cbase;
     float x_scale = 1.f, d_scale = 1.f, omul = 1.f;      // SPL == 2: operand scales and the exact inverse of their product
     if constexpr (SPL == 2) {
-        const int ex = X16 ? *a.pexp_x[si] : f16_scale_exp(amax_read(a.amax_x[si]));
-        const int ed = D16 ? *a.pexp_dy : f16_scale_exp(amax_read(a.amax_dy));
+        const int ex = f16_scale_exp(amax_read(a.amax_x[si]));
+        const int ed = f16_scale_exp(amax_read(a.amax_dy));
         x_scale = exp2i(ex);
         d_scale = exp2i(ed);
         omul = exp2i(-ex) * exp2i(-ed);
@@ -181,8 +164,7 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
             ix = pr * 2 - PAD; roff = pr * 4;
         }
         x_ix[i] = (xc_ok && e < XP) ? ix : DEAD;
-        x_stat[i] = X16 ? ((iy - PAD) * a.Win + ix) * Cs * 4 + p16_quad_off((cs0 >> 2) + xc4)
-                        : (((iy - PAD) * a.Win + ix) * Cs + cs0 + xc4 * 4) * 4;
+        x_stat[i] = (((iy - PAD) * a.Win + ix) * Cs + cs0 + xc4 * 4) * 4;
         x_dst[i] = (xc4 * 4) * XCH + lds_skew(xc4 * 4) + iy * XROW + roff;
     }
     int d_stat[NID], d_mx[NID], d_dst[NID];
@@ -191,8 +173,7 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
         const int e = tid + NT * i, item = (e / NC4) % 16;
         const int my = item / 4, mx = (item % 4) * 2;
         d_mx[i] = (dn_ok && e < DP) ? mx : DEAD;
-        d_stat[i] = D16 ? (my * a.Wout + mx) * a.dy_ld * 4 + p16_quad_off((n0 >> 2) + dn4)
-                        : ((my * a.Wout + mx) * a.dy_ld + n0 + dn4 * 4) * 4;
+        d_stat[i] = ((my * a.Wout + mx) * a.dy_ld + n0 + dn4 * 4) * 4;
         d_dst[i] = (dn4 * 4) * DCH + lds_skew(dn4 * 4) + my * 16 + mx * 2;
     }
 
@@ -225,15 +206,15 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
         for (int i = 0; i < NIX; ++i) {
             const int xx = ox * S + x_ix[i];
             const bool in0 = (unsigned)xx < (unsigned)a.Win, in1 = (unsigned)(xx + XSTEP) < (unsigned)a.Win;
-            xv[slot][p][i][0] = ld_quad<X16>(r_x, in0 ? xb + x_stat[i] : BUF_OOB);
-            xv[slot][p][i][1] = ld_quad<X16>(r_x, in1 ? xb + x_stat[i] + XSTEP * Cs * 4 : BUF_OOB);
+            xv[slot][p][i][0] = buf_load4(r_x, in0 ? xb + x_stat[i] : BUF_OOB, 0);
+            xv[slot][p][i][1] = buf_load4(r_x, in1 ? xb + x_stat[i] + XSTEP * Cs * 4 : BUF_OOB, 0);
         }
 #pragma unroll
         for (int i = 0; i < NID; ++i) {
             const int xx = ox + d_mx[i];
             const bool in0 = (unsigned)xx < (unsigned)a.Wout, in1 = (unsigned)(xx + 1) < (unsigned)a.Wout;
-            dv[slot][p][i][0] = ld_quad<D16>(r_d, in0 ? db + d_stat[i] : BUF_OOB);
-            dv[slot][p][i][1] = ld_quad<D16>(r_d, in1 ? db + d_stat[i] + a.dy_ld * 4 : BUF_OOB);
+            dv[slot][p][i][0] = buf_load4(r_d, in0 ? db + d_stat[i] : BUF_OOB, 0);
+            dv[slot][p][i][1] = buf_load4(r_d, in1 ? db + d_stat[i] + a.dy_ld * 4 : BUF_OOB, 0);
         }
     };
     // piece q of (a, b): h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (mode 2), packed pixel pair per channel
@@ -252,31 +233,16 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
             }
         }
     };
-    // P16 operand: v0 / v1 = (hi pieces of 4 channels, lo pieces of 4 channels) of the two pixels, 2 + 2 dwords each; the
-    // packed pixel pair of channel j and piece q is a half of dword 2q + j / 2 of each
-    auto put16 = [&](unsigned char *dst, int plane, f32x4 v0, f32x4 v1, int chan_stride) {
-        const u32x4 a0 = __builtin_bit_cast(u32x4, v0), a1 = __builtin_bit_cast(u32x4, v1);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned w0 = a0[2 * q + (j >> 1)], w1 = a1[2 * q + (j >> 1)];
-                const unsigned pr = (j & 1) ? ((w0 >> 16) | (w1 & 0xffff0000u)) : ((w0 & 0xffffu) | (w1 << 16));
-                *reinterpret_cast<unsigned *>(dst + q * plane + j * chan_stride) = pr;
-            }
-    };
     auto store = [&](int p, int slot) {
 #pragma unroll
         for (int i = 0; i < NIX; ++i)
             if (NT * (i + 1) <= XP || tid + NT * i < XP) {
-                if constexpr (X16) put16(xt + p * CB * XCH + x_dst[i], XPL, xv[slot][p][i][0], xv[slot][p][i][1], XCH);
-                else put(xt + p * CB * XCH + x_dst[i], XPL, xv[slot][p][i][0], xv[slot][p][i][1], XCH, x_scale);
+                put(xt + p * CB * XCH + x_dst[i], XPL, xv[slot][p][i][0], xv[slot][p][i][1], XCH, x_scale);
             }
 #pragma unroll
         for (int i = 0; i < NID; ++i)
             if (NT * (i + 1) <= DP || tid + NT * i < DP) {
-                if constexpr (D16) put16(dyt + p * NB * DCH + d_dst[i], DPL, dv[slot][p][i][0], dv[slot][p][i][1], DCH);
-                else put(dyt + p * NB * DCH + d_dst[i], DPL, dv[slot][p][i][0], dv[slot][p][i][1], DCH, d_scale);
+                put(dyt + p * NB * DCH + d_dst[i], DPL, dv[slot][p][i][0], dv[slot][p][i][1], DCH, d_scale);
             }
     };
 
@@ -398,20 +364,11 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
     }
 }
 
-template <int KS, int S, int WN, int WC, int SPL, bool X16 = false, bool D16 = false>
+template <int KS, int S, int WN, int WC, int SPL>
 static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
     using Cfg = WgB16Cfg<KS, S, WN, WC, SPL>;
     if (a.pb != Cfg::PB) return hipErrorInvalidValue;
-    if constexpr (SPL == 2 && !X16 && !D16) {      // mode 4: operands stored as P16 take the copy-staging builds
-        bool x16 = a.pexp_x[0] != nullptr;
-        for (int i = 0; i < a.nsrc; ++i)
-            if ((a.pexp_x[i] != nullptr) != x16) return hipErrorInvalidValue;     // all sources alike
-        const bool d16 = a.pexp_dy != nullptr;
-        if (x16 && d16) return launch_wg16<KS, S, WN, WC, SPL, true, true>(a, st);
-        if (x16) return launch_wg16<KS, S, WN, WC, SPL, true, false>(a, st);
-        if (d16) return launch_wg16<KS, S, WN, WC, SPL, false, true>(a, st);
-    }
-    auto kern = wgrad_bf16_kernel<KS, S, WN, WC, SPL, X16, D16>;
+    auto kern = wgrad_bf16_kernel<KS, S, WN, WC, SPL>;
     static bool attr_set = false;
     // experiment knob (only with -DMC_DEBUG_HOOKS): MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the
     // workgroups per CU
@@ -446,13 +403,11 @@ bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride) {
     }
     for (int i = 0; i < a.nsrc; ++i)
         if (a.src[i].C % 4) return false;
-    if (a.prec == 3) {        // the fp16 split needs the maxima of both operand tensors (or their P16 exponents, mode 4)
-        if (!a.amax_dy && !a.pexp_dy) return false;
+    if (a.prec == 3) {        // the fp16 split needs the maxima of both operand tensors
+        if (!a.amax_dy) return false;
         for (int i = 0; i < a.nsrc; ++i) {
-            if (!a.amax_x[i] && !a.pexp_x[i]) return false;
-            if (a.pexp_x[i] && a.src[i].C % 8) return false;
+            if (!a.amax_x[i]) return false;
         }
-        if (a.pexp_dy && a.dy_ld % 8) return false;
     }
     return a.dy_ld % 4 == 0;
 }

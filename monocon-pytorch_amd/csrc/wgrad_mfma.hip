@@ -433,11 +433,6 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
     prof_last = {2, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks,
                  4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.B * a.Hout * a.Wout * a.Cout + (double)ks * ks * a.Cin * a.Cout)};
     hipError_t e = hipErrorInvalidValue;
-    {   // mode 4: P16 operands are only understood by the fp16-split kernel
-        bool any16 = a.pexp_dy != nullptr;
-        for (int i = 0; i < a.nsrc; ++i) any16 = any16 || a.pexp_x[i];
-        if (any16 && (a.small || !(a.prec == 3 && wgrad_bf16_ok(a, ks, stride)))) return hipErrorInvalidValue;
-    }
     if (a.pipe) {
         e = launch_wgrad_pipe(a, ks, st);
     } else if (a.small && wgrad_thin_ok(a, ks, stride)) {

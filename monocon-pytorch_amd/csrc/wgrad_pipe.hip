@@ -308,9 +308,9 @@ int wgrad_pipe_tile(const WgradArgs &a, int ks, int stride) {
     const char *en = std::getenv("MONOCON_HIP_WGRAD_PIPE");
     const int enabled = en ? std::atoi(en) : 1;
     if (!enabled || a.prec != 3 || stride != 1 || ks != 3 || a.small) return 0;
-    if (a.Wout != a.Win || a.Hout != a.Hin || a.dy_ld % 4 || !a.amax_dy || a.pexp_dy) return 0;
+    if (a.Wout != a.Win || a.Hout != a.Hin || a.dy_ld % 4 || !a.amax_dy) return 0;
     for (int i = 0; i < a.nsrc; ++i)
-        if (!a.amax_x[i] || a.pexp_x[i] || a.src[i].C % 4) return 0;
+        if (!a.amax_x[i] || a.src[i].C % 4) return 0;
     auto src_mult = [&](int m) {       // a c-tile must lie inside one source of the virtual concat
         for (int i = 0; i < a.nsrc; ++i)
             if (a.nsrc > 1 && a.src[i].C % m) return false;

@@ -156,7 +156,8 @@ class MonoConDataset(BaseKITTIMono3DDataset):
 
     def _reseed_in_worker(self):
         info = torch.utils.data.get_worker_info()
-        if self._aug_rng is None or info is None or self._aug_rng_worker == info.id:
+        rng = getattr(self, '_aug_rng', None)      # (an instance restored from a foreign pickle has no such attribute)
+        if rng is None or info is None or getattr(self, '_aug_rng_worker', None) == info.id:
             return
         base = int(self._aug_rng.bit_generator.random_raw())          # same in every copy: the parent's stream position
         ss = np.random.SeedSequence([base, info.id, int(info.seed) % (2 ** 63)])

@@ -17,7 +17,7 @@ import torch
 from config.cfgnode import CfgNode
 from hipmonocon import dist as hdist
 from utils.decorators import decorator_timer
-from utils.engine_utils import count_trainable_params, export_cfg, load_cfg, load_checkpoint_file, tprint
+from utils.engine_utils import OpaqueReferenceObject, count_trainable_params, export_cfg, load_cfg, load_checkpoint_file, tprint
 
 try:
     from torch.utils.tensorboard import SummaryWriter
@@ -161,9 +161,13 @@ class BaseEngine:
 
     def load_checkpoint(self, ckpt_file: str, verbose: bool = False) -> None:
         d = load_checkpoint_file(ckpt_file)       # (tolerant of the reference's pickled dataset / transform objects)
+        # Only plain bookkeeping attributes are adopted.  The reference's save (engine/base_engine.py:171, a missing comma) lets
+        # its whole pickled `test_dataset` into this dict: objects of the live run (`_ATTR_EXCEPT`: loaders, datasets, model,
+        # optimizer ...) are never replaced from a file, and stand-ins for classes this tree does not have are dropped.
         for k, v in d['engine_attrs'].items():
-            if k not in ('world', 'rank', 'local_rank'):
-                setattr(self, k, v)
+            if k in ('world', 'rank', 'local_rank') or k in BaseEngine._ATTR_EXCEPT or isinstance(v, OpaqueReferenceObject):
+                continue
+            setattr(self, k, v)
         sd = d['state_dict']
         if sd['model'] is not None and self.model is not None:
             self.model.load_state_dict(sd['model'])

@@ -84,6 +84,29 @@ def state_checksum(module):
     return tot
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """Process group for the small host-side votes of the step path.  On the 'nccl' backend a collective on a device tensor
+    is ordered behind everything already queued on the stream, and reading its result is a host sync that stops the host
+    from running ahead of the GPU; a gloo group carries the same few bytes between the hosts in ~0.1 ms without touching
+    the device.  Created once, COLLECTIVELY (dist.new_group): call it first from a point every rank reaches (the engine's
+    distributed set-up at its first step).  None = use the default group (gloo runs, or gloo unavailable)."""
+    global _HOST_GROUP
+    if not is_distributed():
+        return None
+    import torch.distributed as dist
+    if _HOST_GROUP is None:
+        _HOST_GROUP = False
+        if dist.get_backend() == "nccl":
+            try:
+                _HOST_GROUP = dist.new_group(backend="gloo")
+            except Exception:           # noqa: BLE001  (no gloo in this build: the votes fall back to device tensors)
+                _HOST_GROUP = False
+    return _HOST_GROUP or None
+
+
 def all_ranks_ok(ok, device=None):
     """Logical AND of a per-rank flag, so that an assertion fires on every rank together instead of leaving the
     others hanging in the next collective."""
@@ -178,41 +201,71 @@ def share_tune_table(engine, B, H, W, src=0):
     """Identical convolution tilings on every rank: rank ``src`` builds (and autotunes) its train plan for this shape
     -- no kernel of the step, no collective -- and broadcasts the table of chosen workgroup shapes; the other ranks adopt
     it before they build their own plans.  (Concurrent timing-based tuning can pick different shapes per rank: results
-    would stay bit-identical, step times would not.)  Returns the number of table entries; 0 outside a distributed run."""
+    would stay bit-identical, step times would not.)  Returns the number of table entries; 0 outside a distributed run.
+    COLLECTIVE: call it from a point every rank reaches (setup_engine_dp: the engine's first distributed step).  Every rank
+    runs the same sequence whatever happens locally -- header broadcast (entry count, or the length of rank ``src``'s error
+    text), body broadcast, one vote on the import -- and all of them raise together, with the source's error text."""
     if not is_distributed():
         return 0
     import torch.distributed as dist
     rank = dist.get_rank()
     dev = engine.device if dist.get_backend() == "nccl" else torch.device("cpu")
-    table, ok = [], True
+    table, err = [], None
     if rank == src:
         try:
             engine.build_train_plan(B, H, W)
             table = engine.tune_export()
-        except Exception:               # noqa: BLE001  (the other ranks wait in the broadcast: report through the header)
-            ok, table = False, []
-    head = torch.tensor([len(table) if ok else -1], dtype=torch.int64, device=dev)
+        except Exception as e:          # noqa: BLE001  (the other ranks wait in the broadcast: report through the header)
+            err = ("%s: %s" % (type(e).__name__, e)).encode("utf-8", "replace")[:2000]
+    head = torch.tensor([len(table), len(err) if err is not None else -1], dtype=torch.int64, device=dev)
     dist.broadcast(head, src=src)
-    n = int(head.item())
-    if n < 0:
-        raise RuntimeError("rank %d could not build / autotune its train plan" % src)
+    n, nerr = int(head[0].item()), int(head[1].item())
+    if nerr >= 0:       # the source failed: its message travels instead of the table
+        msg = torch.frombuffer(bytearray(err), dtype=torch.uint8).to(dev) if rank == src else torch.zeros(nerr, dtype=torch.uint8, device=dev)
+        if nerr:
+            dist.broadcast(msg, src=src)
+        raise RuntimeError("rank %d could not build / autotune its train plan: %s"
+                           % (src, bytes(msg.cpu().numpy().tobytes()).decode("utf-8", "replace")))
     body = torch.tensor(table, dtype=torch.int32, device=dev) if rank == src else torch.zeros(n, dtype=torch.int32, device=dev)
     if n:
         dist.broadcast(body, src=src)
+    ok, ierr = True, None
     if rank != src and n:
-        engine.tune_import(body.cpu().tolist())
+        try:
+            engine.tune_import(body.cpu().tolist())
+        except Exception as e:          # noqa: BLE001  (voted on below: nobody is left alone in the next collective)
+            ok, ierr = False, e
+    if not all_ranks_ok(ok, engine.device):
+        raise RuntimeError("tune table of rank %d could not be imported on every rank%s" % (src, (": %s" % (ierr,)) if ierr is not None else ""))
     return n
 
 
-def all_ranks_ok_many(flags, device=None):
-    """element-wise logical AND over ranks of several per-rank flags, in ONE collective"""
+def setup_engine_dp(engine, B, H, W):
+    """The engine's data-parallel set-up, at its FIRST distributed step -- a point every rank of an SPMD loop reaches
+    together, whatever its later batches look like (the tune-table broadcast used to be gated on the rank's
+    own last input shape, so an uneven last batch on one rank mis-paired the collectives): the host-side vote group, one
+    tuning table for all ranks, the handle's communicator.  Shapes that appear LATER are tuned locally by each rank, without
+    a collective (results do not depend on the tilings; only step times can differ)."""
+    if not is_distributed() or getattr(engine, "_dp_ready", False):
+        return
+    host_group()
+    share_tune_table(engine, B, H, W)
+    if not engine.comm_world:
+        ensure_engine_comm(engine)                     # 'rccl' backend: the handle exchanges the gradients itself
+    engine._dp_ready = True
+
+
+def all_ranks_ok_many(flags, device=None, host=False):
+    """element-wise logical AND over ranks of several per-rank flags, in ONE collective.  ``host``: over the host-side
+    group (host_group(): no device work, no stream sync) when there is one."""
     flags = [bool(f) for f in flags]
     if not is_distributed():
         return flags
     import torch.distributed as dist
-    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    grp = host_group() if host else None
+    dev = device if (grp is None and device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
     t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=grp)
     return [bool(v) for v in t.tolist()]
 
 

@@ -109,7 +109,7 @@ class HipRuntime:
         self.engine = None
         self.precision = 0     # 0 fp32 MFMA, 1 bf16 operands, 2 fp32 as a 3-way bf16 split, 3 fp32 as a 2-way fp16 split
 
-    PRECISION_MODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp32_split": 2, "f16x2": 3, "fp16x2": 3, "f16x2p": 4, "p16": 4}
+    PRECISION_MODES = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 2, "fp32_split": 2, "f16x2": 3, "fp16x2": 3}
 
     def set_precision(self, mode):
         if isinstance(mode, str) and mode not in self.PRECISION_MODES:

@@ -149,32 +149,40 @@ def _require_objects(detector, label, pad_hw, num_classes=3):
     mask = label["mask"]
     seen = getattr(detector, "_mask_validated", None)
     cached = seen is not None and seen[0]() is mask and seen[1] == mask._version
-    if cached:
-        # No collective here: a per-step vote on "is everybody's mask cached" was a host sync on every step of
-        # the data-parallel path -- the very sync the cache exists to avoid -- ahead of the overlapped gradient exchange.
-        # The contract instead: the ranks of an SPMD loop either all re-use their label tensors (a resident batch stepped
-        # repeatedly) or all feed fresh ones (a DataLoader); fresh labels are validated below, with ONE collective that
-        # makes every rank raise together.
+    # Data parallel: whether the verdict has to be read back is a per-rank fact (one rank re-uses its label tensors, another
+    # feeds fresh ones: an uneven tail, a retry), but the collective that lets all ranks raise together must be entered by
+    # ALL of them or none (a rank that skipped it left the others waiting).  So every step votes first on "is
+    # everybody's mask already validated" -- over the host-side group (gloo between the hosts, ~0.1 ms, no device work and
+    # no stream sync: the host keeps running ahead of the GPU; ADVICE r3 was about a vote that synchronised the stream) --
+    # and only when somebody's is not do all ranks enter the verdict's collective, the validated ones with (True, True).
+    dp = _dist.is_distributed()
+    if dp:
+        all_cached, = _dist.all_ranks_ok_many((cached,), mask.device, host=True)
+        if all_cached:
+            return
+    elif cached:
         return
     H, W = pad_hw
     fh, fw = H // 4, W // 4
-    bb, cls = label["gt_bboxes"], label["gt_labels"]
-    # same fp32 arithmetic as make_targets_kernel: centre = (x1 + x2) * (fw / W) / 2, truncated toward zero
-    wr = torch.tensor(fw / W, dtype=torch.float32, device=bb.device)
-    hr = torch.tensor(fh / H, dtype=torch.float32, device=bb.device)
-    xi = ((bb[..., 0] + bb[..., 2]) * wr / 2.0).trunc()
-    yi = ((bb[..., 1] + bb[..., 3]) * hr / 2.0).trunc()
-    bad = ((xi < 0) | (xi >= fw) | (yi < 0) | (yi >= fh) | (cls < 0) | (cls >= num_classes)) & (mask != 0)
-    n_valid, n_bad = torch.stack([mask.sum(), bad.sum().to(mask.dtype)]).tolist()
+    n_valid, n_bad = 1, 0
+    if not cached:      # (a rank whose labels are validated joins the others' collective with a clean verdict)
+        bb, cls = label["gt_bboxes"], label["gt_labels"]
+        # same fp32 arithmetic as make_targets_kernel: centre = (x1 + x2) * (fw / W) / 2, truncated toward zero
+        wr = torch.tensor(fw / W, dtype=torch.float32, device=bb.device)
+        hr = torch.tensor(fh / H, dtype=torch.float32, device=bb.device)
+        xi = ((bb[..., 0] + bb[..., 2]) * wr / 2.0).trunc()
+        yi = ((bb[..., 1] + bb[..., 3]) * hr / 2.0).trunc()
+        bad = ((xi < 0) | (xi >= fw) | (yi < 0) | (yi >= fh) | (cls < 0) | (cls >= num_classes)) & (mask != 0)
+        n_valid, n_bad = torch.stack([mask.sum(), bad.sum().to(mask.dtype)]).tolist()
     # data parallel: every rank raises together (a lone raise would leave the others in the all-reduce); both verdicts
     # travel in ONE two-element MIN all-reduce
-    ok_valid, ok_inside = _dist.all_ranks_ok_many((n_valid != 0, n_bad == 0), mask.device)
+    ok_valid, ok_inside = _dist.all_ranks_ok_many((n_valid != 0, n_bad == 0), mask.device, host=True)
     if not ok_valid:
         raise AssertionError("no valid objects in the batch: l1_loss requires target.numel() > 0")
     if not ok_inside:
-        raise IndexError("%d labelled object(s) with a box centre outside the %dx%d feature map or a class id outside "
+        raise IndexError("%s with a box centre outside the %dx%d feature map or a class id outside "
                          "[0, %d): the reference's target generator indexes out of bounds for such labels"
-                         % (int(n_bad), fh, fw, num_classes))
+                         % (("%d labelled object(s)" % int(n_bad)) if n_bad else "labelled object(s) on another rank", fh, fw, num_classes))
     object.__setattr__(detector, "_mask_validated", (weakref.ref(mask), mask._version))
 
 
@@ -192,12 +200,7 @@ def forward_train(detector, data_dict):
             p.grad = p.grad.clone()
     eng = detector._rt.get(tb.state(detector))
     if _dist.is_distributed():
-        shape = tuple(img.shape)
-        if getattr(eng, "_tune_shared_for", None) != shape:   # first step of this shape: rank 0 tunes, everyone adopts
-            _dist.share_tune_table(eng, shape[0], shape[2], shape[3])
-            eng._tune_shared_for = shape
-        if not eng.comm_world:
-            _dist.ensure_engine_comm(eng)                     # 'rccl' backend: the handle exchanges the gradients itself
+        _dist.setup_engine_dp(eng, img.shape[0], img.shape[2], img.shape[3])      # collective, once per engine (its first step)
     params = [p for _, p in tb.named]
     out = _HipTrainStep.apply(detector, tb, eng, img.contiguous(), label, detector.head.max_objs, *params)
     losses, preds = out[:10], out[10:]

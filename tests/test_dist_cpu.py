@@ -243,3 +243,83 @@ def test_world8_start_up_protocol_and_bucket_schedule():
     # bucket ranges are disjoint and cover the buffer in order
     rng = r0["buckets"]
     assert all(rng[i][2] <= rng[i + 1][1] for i in range(3))
+
+
+# ----------------------------------------------------------------------------- rank-local state must not gate collectives
+class _FailingEngine(_FakeEngine):
+    def __init__(self, rank, fail_build=False, fail_import_on=()):
+        super().__init__(rank)
+        self.fail_build, self.fail_import_on = fail_build, set(fail_import_on)
+
+    def build_train_plan(self, B, H, W):
+        if self.fail_build:
+            raise MemoryError("train plan: out of device memory (injected)")
+        super().build_train_plan(B, H, W)
+
+    def tune_import(self, table):
+        if self.rank in self.fail_import_on:
+            raise ValueError("mc_tune_import: unknown shape id 99 (injected)")
+        return super().tune_import(table)
+
+
+class _Det:
+    """stands in for the detector in _require_objects (it only carries the validated-mask note)"""
+
+
+def _asym_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MONOCON_HIP_DP="rccl")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hipmonocon import dist as hdist, train as htrain
+    res = {}
+    # (1) the source rank cannot build its plan: every rank raises, with the SOURCE's message
+    try:
+        hdist.share_tune_table(_FailingEngine(rank, fail_build=(rank == 0)), 32, 384, 1280)
+        res["build"] = "no error"
+    except RuntimeError as e:
+        res["build"] = str(e)
+    # (2) ONE rank cannot import the table: every rank raises (the others are not left in the next collective)
+    try:
+        hdist.share_tune_table(_FailingEngine(rank, fail_import_on={2}), 32, 384, 1280)
+        res["import"] = "no error"
+    except RuntimeError as e:
+        res["import"] = str(e)[:60]
+    # (3) set-up runs once per engine, whatever shapes come later; a later shape issues NO collective
+    eng = _FakeEngine(rank)
+    hdist.setup_engine_dp(eng, 32, 384, 1280)
+    hdist.setup_engine_dp(eng, 7 + rank, 384, 1280)          # rank-dependent "uneven last batch": nothing to mis-pair
+    res["setup"] = (eng.built, eng.comm_world, getattr(eng, "_dp_ready", False))
+    # (4) label validation with DIFFERENT cache states per rank: rank 0 re-uses its (validated) label tensors, the others
+    #     feed fresh ones -- all return, nobody waits in a collective the others skipped; then a bad label on ONE rank
+    #     raises on ALL of them
+    det = _Det()
+    lab = {"mask": torch.ones(2, 30), "gt_bboxes": torch.tensor([10.0, 10.0, 40.0, 40.0]).repeat(2, 30, 1),
+           "gt_labels": torch.zeros(2, 30)}
+    htrain._require_objects(det, lab, (64, 128))             # step 1: everybody validates
+    for step in range(3):
+        if rank != 0:                                         # fresh tensors on the other ranks, the same objects on rank 0
+            lab = {k: v.clone() for k, v in lab.items()}
+        htrain._require_objects(det, lab, (64, 128))
+    bad = {k: v.clone() for k, v in lab.items()}
+    if rank == 1:
+        bad["gt_labels"][0, 0] = 9.0
+    try:
+        htrain._require_objects(det, bad if rank == 1 else lab, (64, 128))
+        res["labels"] = "no error"
+    except IndexError:
+        res["labels"] = "IndexError"
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collectives_of_the_dp_start_up_and_label_vote_do_not_depend_on_rank_local_state():
+    world, port = 4, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_asym_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        o = out[r]
+        assert "rank 0 could not build" in o["build"] and "out of device memory (injected)" in o["build"], o["build"]
+        assert o["import"].startswith("tune table of rank 0 could not be imported"), o["import"]
+        assert o["setup"] == ([(32, 384, 1280)] if r == 0 else [], world, True), o["setup"]
+        assert o["labels"] == "IndexError"

@@ -444,3 +444,15 @@ def test_f16x2_operand_scaling_covers_the_fp32_range(xscale, wscale):
     assert rel_err(got.permute(0, 3, 1, 2), y.detach()) < 5e-6
     assert rel_err(gw, wd.grad) < 5e-6
     assert rel_err(gx.permute(0, 3, 1, 2), xd.grad) < 5e-6
+
+
+def test_retired_mode_4_is_an_error():
+    """round 4's experimental mode 4 (mode 3 on pre-split, DMA-staged activations) is gone from the ABI: its weight gradients
+    were not bit-reproducible beside the weight-gradient stream"""
+    from hipmonocon.engine import Engine
+    from hipmonocon.lib import MonoconHipError
+    from model import MonoConDetector
+    with pytest.raises(MonoconHipError, match="mode must be"):
+        Engine().set_precision(4)
+    with pytest.raises(ValueError, match="unknown precision mode"):
+        MonoConDetector(34, pretrained_backbone=False).set_precision("f16x2p")

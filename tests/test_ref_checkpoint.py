@@ -143,6 +143,9 @@ def test_reference_checkpoint_layout_and_host_side_load(golden_sd, tmp_path):
     st.scheduler = CyclicScheduler(st.optimizer, total_steps=1000)
     BaseEngine.load_checkpoint(st, path)
     assert st.epochs == 3 and st.global_iters == 931 and st.epoch_times == [101.5, 99.25] and st.weight_dir == "./exps/ref/checkpoints"
+    # the pickled dataset the reference's missing comma let into `engine_attrs`, and the stand-in for a class only the
+    # reference has, are NOT adopted as engine attributes
+    assert not hasattr(st, "test_dataset") and not hasattr(st, "leftover_transform")
     assert torch.equal(st.model.state_dict()["backbone.level2.tree1.conv1.weight"], golden_sd["backbone.level2.tree1.conv1.weight"])
     osd = st.optimizer.state_dict()
     assert osd["param_groups"][0]["lr"] == og["lr"] and tuple(osd["param_groups"][0]["betas"]) == tuple(og["betas"])
