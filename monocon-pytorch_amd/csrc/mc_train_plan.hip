@@ -520,6 +520,9 @@ struct TB {   // train plan builder
             lc->stats = partial;
             lc->bm_y = yp; lc->bm_z = zp; lc->bm_a = fa; lc->bm_b = fb; lc->bm_relu = relu;
             if (wres_bwd >= 1 && !(lc->cfg & (CFG_SMALL | CFG_WS)) && conv_wres_ok(*lc, 3, 1)) lc->cfg |= CFG_WRES;      // (see emit_dgrad)
+            if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
+                fprintf(stderr, "[plan]   twin of %-36s cfg %3d  K %4d  Cout %3d  %dx%d  res %d  nsrc %d srcC %d wres %d\n", bn.c_str(), lc->cfg,
+                        lc->Cin, lc->Cout, lc->Hout, lc->Wout, lc->res != nullptr, lc->nsrc, lc->src[0].C, (lc->cfg & CFG_WRES) != 0);
             double *fold = fold_scratch(nbp, C);
             if (want_skip_affine && !gres) {
                 // the epilogue also leaves max |d| (for the consumer's operand scale); only the coefficients are computed here
