@@ -252,13 +252,20 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         if constexpr (BM) yvr[r & 3] = buf_load1(e_y, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
         if constexpr (BM && ZMASK) zvr[r & 3] = buf_load1(e_z, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
     };
+    // a row in three parts, one per MFMA gap of its K-step: (1) value + mask, (2) statistics, ReLU, max |v|, (3) the store
     float e_v = 0.f;
-    auto epi_row_a = [&](int r) {
+    auto epi_row_a1 = [&](int r) {
         float v = __builtin_fmaf(Y[r], sc, bi);
         if constexpr (RES) v += rvr[r & 3];
         if constexpr (BM) {
             const bool on = ZMASK ? zvr[r & 3] > 0.f : (bm_relu == 0 || __builtin_fmaf(yvr[r & 3], ma, mb) > 0.f);
             v = on ? v : 0.f;
+        }
+        e_v = v;
+    };
+    auto epi_row_a2 = [&](int r) {
+        float v = e_v;
+        if constexpr (BM) {
             ssum += v;
             ssq = __builtin_fmaf(v, yvr[r & 3], ssq);
         } else if constexpr (STATS) {
@@ -315,14 +322,14 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
             if constexpr (EXP & 1) asm volatile("" : "+v"(accm) : "v"(al), "v"(breg[s][0]));
             else accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, breg[s][0], accm, 0, 0, 0);      // l * h
             __builtin_amdgcn_sched_barrier(0);
-            if (EPI && s < 16) epi_load(s);
+            if (EPI && s >= 3 && s < 19) epi_row_a1(s - 3);
             if (s >= S0 && s < S0 + NIT) stage_a(s - S0);
             if (s == S0 + NIT) fetch_setup(cn);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (EXP & 1) asm volatile("" : "+v"(acc) : "v"(ah), "v"(breg[s][0]));
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, breg[s][0], acc, 0, 0, 0);        // h * h
             __builtin_amdgcn_sched_barrier(0);
-            if (EPI && s >= 3 && s < 19) epi_row_a(s - 3);
+            if (EPI && s >= 3 && s < 19) epi_row_a2(s - 3);
             if (s >= S0 && s < S0 + NIT) stage_b(s - S0, nxt);
             if (s >= S0 + NIT && s < S0 + 2 * NIT) fetch_addr(s - S0 - NIT);
             __builtin_amdgcn_sched_barrier(0);
@@ -331,6 +338,7 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
             else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(accm) : "v"(ah), "a"(breg[s][1]));
             __builtin_amdgcn_sched_barrier(0);
             if (EPI && s >= 3 && s < 19) epi_row_b(s - 3);
+            if (EPI && s < 16) epi_load(s);          // operands of row s, due in three K-steps
             if (EPI && s == 19) epi_finish();
         }
         // (the last MFMA is inline asm: hipcc does not pad its result hazard -- 8 passes: 12 wait states before a VALU read)
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
 #pragma unroll
             for (int r = r0; r < r0 + 4; ++r) epi_load(r);
 #pragma unroll
-            for (int r = r0; r < r0 + 4; ++r) { epi_row_a(r); epi_row_b(r); }
+            for (int r = r0; r < r0 + 4; ++r) { epi_row_a1(r); epi_row_a2(r); epi_row_b(r); }
         }
         epi_finish();
     } else {

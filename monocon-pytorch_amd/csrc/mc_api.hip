@@ -1046,6 +1046,24 @@ int mc_bench_conv(mc_handle *h, int B, int Hin, int Win, int nsrc, const int src
     a.out = alloc_fill((size_t)B * a.Hout * a.Wout * Cout, 0.0f);
     if (!a.wpk || !a.scale || !a.bias || !a.out) return fail(h, "mc_bench_conv: out of memory");
     a.out_ld = Cout; a.relu = 1; a.cfg = cfg;
+    // MONOCON_BENCH_STATS=1: the train-mode forward's statistics partials; MONOCON_BENCH_BM=1 / 2: the backward-statistics
+    // epilogue (mask recomputed from y / read from a stored activation), =3: the latter with an accumulated gradient
+    if (const char *e = std::getenv("MONOCON_BENCH_STATS")) {
+        if (std::atoi(e)) a.stats = alloc_fill((size_t)B * ((a.Hout + 3) / 4) * ((a.Wout + 7) / 8) * a.CoutP * 2, 0.f);
+    }
+    if (const char *e = std::getenv("MONOCON_BENCH_BM")) {
+        const int m = std::atoi(e);
+        if (m) {
+            const size_t on = (size_t)B * a.Hout * a.Wout * Cout;
+            a.relu = 0;
+            a.stats = alloc_fill((size_t)B * ((a.Hout + 3) / 4) * ((a.Wout + 7) / 8) * a.CoutP * 2, 0.f);
+            a.bm_y = alloc_fill(on, 1.0f);
+            a.bm_a = a.scale; a.bm_b = a.bias; a.bm_relu = m == 1 ? 2 : 1;
+            if (m >= 2) a.bm_z = alloc_fill(on, 1.0f);
+            if (m >= 3) { a.res = alloc_fill(on, 1.0f); a.res_ld = Cout; }
+            if (!a.stats || !a.bm_y || (m >= 2 && !a.bm_z) || (m >= 3 && !a.res)) return fail(h, "mc_bench_conv: out of memory");
+        }
+    }
     if (h->prec >= 1 && cin % 32 == 0) {        // bf16 / fp16 pipe: piece panels (random finite bit patterns) + unit maxima
         const size_t wn = (size_t)ksize * ksize * cin * a.CoutP;
         std::vector<unsigned short> hw(wn * 3);

@@ -166,7 +166,7 @@ struct TB {   // train plan builder
     // launch_noise_fill).  MEASURED (round 4, one session, B=32): 56.52 / 56.56 ms per step tuned on zeros, 56.51 / 56.62
     // tuned on noise -- the ranking of the shapes does not depend on it; off by default (MONOCON_HIP_TUNE_NOISE=1).
     bool tune_noise = [] { const char *e = std::getenv("MONOCON_HIP_TUNE_NOISE"); return e && std::atoi(e) != 0; }();
-    int wres_bwd = [] { const char *e = std::getenv("MONOCON_HIP_WRES_BWD"); return e ? std::atoi(e) : 1; }();
+    int wres_bwd = [] { const char *e = std::getenv("MONOCON_HIP_WRES_BWD"); return e ? std::atoi(e) : 0; }();
     float *alloc_map(size_t n) {
         float *p = alloc(n);
         if (p && !h->dry_alloc && h->autotune && tune_noise && n >= 4096)
@@ -445,9 +445,11 @@ struct TB {   // train plan builder
         // The weight-resident kernel (conv_wres.hip) owns its CU -- four waves with the whole register file -- so beside the
         // weight-gradient stream it cannot share one the way the tiled kernels do and the two streams take
         // turns: measured in the step (rocprofv3, round 5) a plain 64 -> 64 data gradient takes ~595 us on it against 389 us
-        // on conv_bf16_kernel, although it is the faster kernel alone (244 vs 284 us).  Backward launches therefore keep the
-        // tiled kernel, except the backward-statistics twins, where even so it wins (595 vs 819 us; bn_backward sets the flag).
-        // MONOCON_HIP_WRES_BWD: 0 = never in the backward, 1 (default) = the twins only, 2 = wherever the autotuner chose it
+        // on conv_bf16_kernel, although it is the faster kernel alone (244 vs 284 us); its backward-statistics twins take
+        // 546 us in the step (303 alone).  One-session A/B of the whole step: 52.61 ms without it in the backward, 53.24 ms
+        // with the twins on it.  Backward launches therefore keep the tiled kernels.
+        // MONOCON_HIP_WRES_BWD: 0 (default) = never in the backward, 1 = the twins (bn_backward sets the flag), 2 = wherever
+        // the autotuner chose it
         if (wres_bwd < 2) d.cfg &= ~CFG_WRES;
         ts->dgrads.push_back(d);
         ConvArgs *dp = &ts->dgrads.back();
