@@ -146,3 +146,24 @@ def test_wres_train_step_is_bit_identical_to_the_tiled_kernels():
         assert torch.equal(g0[n], g1[n]), n
     for n in b0:
         assert torch.equal(b0[n], b1[n]), n
+
+
+def test_default_train_plan_keeps_the_epilogue_twins_on_the_tiled_kernels(monkeypatch, capfd):
+    """the defaults of the two plan policies (mc_train_plan.hip): every BatchNorm whose input gradient is completed by a data
+    gradient gets that launch's backward-statistics epilogue (MONOCON_HIP_BM_EPILOGUE default 1), and no backward launch
+    takes the weight-resident kernel (MONOCON_HIP_WRES_BWD default 0: one-session A/B)"""
+    import os
+    from model import MonoConDetector
+    monkeypatch.setenv("MONOCON_HIP_PLAN_DEBUG", "1")
+    monkeypatch.delenv("MONOCON_HIP_BM_EPILOGUE", raising=False)
+    monkeypatch.delenv("MONOCON_HIP_WRES_BWD", raising=False)
+    batch = synth.make_batch(5, 2, 384, 1280)
+    gb = {"img": batch["img"].cuda(), "label": {k: v.cuda() for k, v in batch["label"].items()}, "img_metas": batch["img_metas"]}
+    m = MonoConDetector(34, pretrained_backbone=False).cuda().train().set_precision("f16x2")
+    _, loss = m(gb)
+    sum(loss.values()).backward()
+    torch.cuda.synchronize()
+    err = capfd.readouterr().err
+    twins = [l for l in err.splitlines() if l.startswith("[plan]   twin of")]
+    assert len(twins) >= 25, err[-2000:]          # 33 at this shape (rocprofv3: 33 launches of the <..., true> kernels per step)
+    assert all(l.rstrip().endswith("wres 0") for l in twins), [l for l in twins if not l.rstrip().endswith("wres 0")]
