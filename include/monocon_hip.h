@@ -92,7 +92,8 @@ int mc_head_forward(mc_handle *h, const float *feat, int B, int H, int W,
 /* ---- decode -------------------------------------------------------------------------
  * Replaces MonoConDenseHeads.decode_heatmap + _get_bboxes origin shift
  * (model/dense_heads/monocon_heads.py:313-329,379-558) and utils/tensor_ops.py:17-31
- * (get_local_maximum, get_topk_from_heatmap).  3x3 local-maximum filter, per-image top-K
+ * (get_local_maximum, get_topk_from_heatmap).  k x k local-maximum filter (k = 3 unless
+ * mc_set_local_maximum_kernel changed it), per-image top-K
  * over the flattened C*H*W map (ties: score desc, flat index asc), gathers, box assembly.
  * preds: the ten NCHW maps (only those the reference reads are touched); P2: (B,3,4);
  * P2inv: (B,4,4) inverse of the view-padded projection (monocon_heads.py:544-546).
@@ -100,6 +101,9 @@ int mc_head_forward(mc_handle *h, const float *feat, int B, int H, int W,
  *   scores (B,K) f32 raw heat-map peaks; flat_index (B,K) i64 into C*H*W; cls (B,K) i64;
  *   box2d (B,K,5) = x1,y1,x2,y2,score*sigma; box3d (B,K,7) = x,y+h/2,z,dim(3),rot_y;
  *   keep_localmax (B,C,H,W) u8 or NULL; keep_thr (B,K) u8 = box2d[...,4] > thr. */
+/* test_config['local_maximum_kernel'] (model/detector/monocon_detector.py:18, utils/tensor_ops.py:17 `kernel`): the window
+ * of the filter, odd, 1 .. 31; a setting of the handle (default 3), read by every later mc_decode. */
+int mc_set_local_maximum_kernel(mc_handle *h, int kernel);
 int mc_decode(mc_handle *h, const float *const preds[MC_NUM_PREDS], const float *P2,
               const float *P2inv, int B, int C, int H, int W, int K, float thr,
               float pad_h, float pad_w, float *scores, int64_t *flat_index, int64_t *cls,

@@ -104,6 +104,7 @@ struct DecodeArgs {
     const float *pred[10];
     const float *P2, *P2inv;
     int B, C, H, W, K;
+    int lm_kernel;           // window of the local-maximum filter (odd; utils/tensor_ops.py:17 `kernel`)
     float thr, pad_h, pad_w;
     float *scores;
     int64_t *flat_index, *cls;

@@ -1,4 +1,4 @@
-// Heat-map decode: 3x3 local-maximum filter, exact per-image top-K over the flattened C*H*W map,
+// Heat-map decode: k x k local-maximum filter (k odd, 3 in every reference configuration), exact per-image top-K over the flattened C*H*W map,
 // gathers and 2D/3D box assembly.  Replaces reference utils/tensor_ops.py:17-31 and
 // model/dense_heads/monocon_heads.py:313-329,379-558 (decode_heatmap, decode_alpha,
 // calculate_roty, convert_pts2D_to_pts3D, _get_bboxes origin shift).
@@ -21,11 +21,12 @@ __device__ __forceinline__ unsigned f2key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// 3x3 local-maximum filter + compaction: every surviving strictly positive value becomes a (key, flat index)
+// local-maximum filter (any odd window) + compaction: every surviving strictly positive value becomes a (key, flat index)
 // candidate of its image (list order is arbitrary -- the selection below orders by key, then index).  After the
 // filter at most ~1/9 of a heat map survives, so the selection reads ~10x less than the map.
 constexpr int LM_THREADS = 1024, LM_PER_THREAD = 4, LM_CHUNK = LM_THREADS * LM_PER_THREAD;
 __global__ __launch_bounds__(LM_THREADS) void localmax_compact_kernel(const float *__restrict__ heat, int C, int H, int W,
+                                                                      int R,      // window radius: (kernel - 1) / 2
                                                                       float *__restrict__ filt, uint8_t *__restrict__ keep,
                                                                       unsigned *__restrict__ cand_key,
                                                                       int *__restrict__ cand_idx,
@@ -48,12 +49,11 @@ __global__ __launch_bounds__(LM_THREADS) void localmax_compact_kernel(const floa
             const float *plane = heat + (size_t)b * N + (e - y * W - x);
             const float c = plane[y * W + x];
             float m = c;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
+            // (max_pool2d pads with -inf: positions outside the map do not take part)
+            for (int dy = -R; dy <= R; ++dy) {
                 const int yy = y + dy;
                 if (yy < 0 || yy >= H) continue;
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
+                for (int dx = -R; dx <= R; ++dx) {
                     const int xx = x + dx;
                     if (xx < 0 || xx >= W) continue;
                     m = fmaxf(m, plane[yy * W + xx]);
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(LM_THREADS) void localmax_compact_kernel(const floa
     }
 }
 
-// Same filter for W % 4 == 0: a thread owns four consecutive pixels of a row -- three 16-byte loads (rows y-1, y,
+// The 3x3 filter for W % 4 == 0: a thread owns four consecutive pixels of a row -- three 16-byte loads (rows y-1, y,
 // y+1) plus the two edge columns from the neighbouring lanes (v_mov_dpp-style shuffles; only a wave's first / last
 // lane reloads them) instead of 36 dword loads, which is what bounds the scalar kernel (texture-address rate).
 __global__ __launch_bounds__(LM_THREADS) void localmax_compact_v4_kernel(const float *__restrict__ heat, int C, int H, int W,
@@ -418,11 +418,12 @@ hipError_t launch_decode(const DecodeArgs &a, hipStream_t st) {
     if (!a.cand_key || !a.cand_idx || !a.cand_count) return hipErrorInvalidValue;
     const int N = a.C * a.H * a.W;
     const dim3 grid((unsigned)((N + LM_CHUNK - 1) / LM_CHUNK), (unsigned)a.B);
-    if (a.W % 4 == 0)
+    if (a.lm_kernel < 1 || a.lm_kernel % 2 == 0) return hipErrorInvalidValue;
+    if (a.W % 4 == 0 && a.lm_kernel == 3)
         hipLaunchKernelGGL(localmax_compact_v4_kernel, grid, dim3(LM_THREADS), 0, st, a.pred[0], a.C, a.H, a.W, a.filt,
                            a.keep_localmax, a.cand_key, a.cand_idx, a.cand_count);
     else
-        hipLaunchKernelGGL(localmax_compact_kernel, grid, dim3(LM_THREADS), 0, st, a.pred[0], a.C, a.H, a.W, a.filt,
+        hipLaunchKernelGGL(localmax_compact_kernel, grid, dim3(LM_THREADS), 0, st, a.pred[0], a.C, a.H, a.W, a.lm_kernel / 2, a.filt,
                            a.keep_localmax, a.cand_key, a.cand_idx, a.cand_count);
     hipLaunchKernelGGL(topk_decode_kernel, dim3(a.B), dim3(DEC_THREADS), 0, st, a);
     return hipGetLastError();

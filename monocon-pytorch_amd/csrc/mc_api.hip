@@ -841,6 +841,7 @@ int mc_decode(mc_handle *h, const float *const preds[MC_NUM_PREDS], const float 
     for (int i = 0; i < MC_NUM_PREDS; ++i) a.pred[i] = preds[i];
     a.P2 = P2; a.P2inv = P2inv;
     a.B = B; a.C = C; a.H = H; a.W = W; a.K = K;
+    a.lm_kernel = h->lm_kernel;
     a.thr = thr; a.pad_h = pad_h; a.pad_w = pad_w;
     a.scores = scores; a.flat_index = flat_index; a.cls = cls;
     a.box2d = box2d; a.box3d = box3d;
@@ -1174,6 +1175,16 @@ int mc_tune_import(mc_handle *h, const int *buf, int n_ints) {
         ++added;
     }
     return added;
+}
+
+int mc_set_local_maximum_kernel(mc_handle *h, int kernel) {
+    if (!h) return -1;
+    // max_pool2d(heat, k, stride 1, padding (k - 1) / 2) has the heat map's size for odd k only: with an even k the
+    // reference's `hmax == heat` (utils/tensor_ops.py:19-20) does not broadcast and raises
+    if (kernel < 1 || kernel > 31 || kernel % 2 == 0)
+        return fail(h, "mc_set_local_maximum_kernel: the window must be odd, 1 .. 31 (got %d)", kernel);
+    h->lm_kernel = kernel;
+    return 0;
 }
 
 int mc_set_precision(mc_handle *h, int mode) {

@@ -119,6 +119,7 @@ struct mc_handle {
     size_t decode_filt_n = 0;
     size_t decode_count_n = 0;
     int force_cfg = 0;   // tuning aid (mc_bench_conv)
+    int lm_kernel = 3;   // mc_set_local_maximum_kernel: window of the decode's local-maximum filter (test_config['local_maximum_kernel'])
     int prec = 0;        // mc_set_precision: 0 fp32 MFMA, 1 bf16 operands, 2 three-way bf16 split, 3 two-way fp16 split
     unsigned *w_amax_arena = nullptr;                    // mode 3: max |w| per conv layer (+ the fused head panel)
     int w_amax_n = 0;

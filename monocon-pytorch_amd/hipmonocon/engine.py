@@ -48,6 +48,7 @@ class Engine:
         self._sig = None
         self._keep = None
         self.comm_world = 0        # > 0: the handle owns an RCCL communicator (comm_init)
+        self._lm_kernel = 3        # the handle's local-maximum window (mc_set_local_maximum_kernel)
 
     def close(self):
         if getattr(self, "h", None):
@@ -220,9 +221,13 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ decode
-    def decode(self, pred, P2, P2inv, pad_hw, topk, thres, want_keep=False):
-        """Dense decode.  pred: dict of NCHW CUDA maps; P2 (B,3,4), P2inv (B,4,4) CUDA fp32."""
+    def decode(self, pred, P2, P2inv, pad_hw, topk, thres, want_keep=False, local_maximum_kernel=3):
+        """Dense decode.  pred: dict of NCHW CUDA maps; P2 (B,3,4), P2inv (B,4,4) CUDA fp32.
+        local_maximum_kernel: window of the peak filter (odd; test_config['local_maximum_kernel'])."""
         heat = _need_cuda(pred["center_heatmap_pred"], "center_heatmap_pred")
+        if int(local_maximum_kernel) != self._lm_kernel:
+            _lib.check(self.h, self.lib.mc_set_local_maximum_kernel(self.h, int(local_maximum_kernel)), "mc_set_local_maximum_kernel")
+            self._lm_kernel = int(local_maximum_kernel)
         B, Cc, H, W = heat.shape
         dev = heat.device
         arr = (C.c_void_p * _lib.NUM_PREDS)()

@@ -144,16 +144,18 @@ class MonoConDenseHeads(nn.Module):
     def _decode_dense(self, data_dict: Dict[str, Any], pred_dict: Dict[str, torch.Tensor], engine=None):
         img_h, img_w = data_dict['img_metas']['pad_shape'][0]
         heat = pred_dict['center_heatmap_pred']
-        if self.local_maximum_kernel != 3:
-            raise NotImplementedError("local_maximum_kernel=%r (the HIP decode implements the 3x3 filter)"
-                                      % self.local_maximum_kernel)
+        k = int(self.local_maximum_kernel)
+        if k < 1 or k % 2 == 0:
+            # the reference fails here too: max_pool2d(heat, k, 1, (k - 1) // 2) of an even k is one pixel smaller than
+            # the heat map and `hmax == heat` does not broadcast (utils/tensor_ops.py:17-21)
+            raise RuntimeError("local_maximum_kernel=%r: the peak filter needs an odd window" % self.local_maximum_kernel)
         calib = data_dict['calib']
         if not isinstance(calib, (list, tuple)):
             calib = [calib] * heat.shape[0]
         P2, P2inv = self._calib_tensors(calib, heat.device)
         eng = engine if engine is not None else self._engine()
         return eng.decode({k: v.contiguous() for k, v in pred_dict.items()}, P2, P2inv, (img_h, img_w),
-                          self.topk, self.test_thres)
+                          self.topk, self.test_thres, local_maximum_kernel=k)
 
     def decode_heatmap(self, data_dict: Dict[str, Any], pred_dict: Dict[str, torch.Tensor],
                        engine=None) -> Tuple[List[torch.Tensor]]:

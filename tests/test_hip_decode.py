@@ -16,13 +16,13 @@ def eng():
     return Engine()
 
 
-def run(eng, d, K, thres=0.4, want_keep=True, pad_hw=(384, 1280)):
+def run(eng, d, K, thres=0.4, want_keep=True, pad_hw=(384, 1280), window=3):
     from hipmonocon.engine import p2_inverse
     B = d["center_heatmap_pred"].shape[0]
     pred = {k: torch.from_numpy(v).to(eng.device) for k, v in d.items()}
     P2 = np.stack([synth.KITTI_P2] * B)
     return eng.decode(pred, torch.from_numpy(P2).to(eng.device), torch.from_numpy(p2_inverse(P2)).to(eng.device),
-                      pad_hw, K, thres, want_keep=want_keep)
+                      pad_hw, K, thres, want_keep=want_keep, local_maximum_kernel=window)
 
 
 @pytest.mark.parametrize("K", [30, 100])
@@ -41,6 +41,36 @@ def test_decode_vs_reference_golden(eng, K):
         assert rel_err(R["box2d"][i].cpu()[mk], g["box2d.%d" % i]) < 1e-4
         assert rel_err(R["box3d"][i].cpu()[mk], g["box3d.%d" % i]) < 1e-4
         assert np.array_equal(R["cls"][i].cpu()[mk].numpy(), g["label.%d" % i])
+
+
+@pytest.mark.parametrize("window", [1, 5, 7, 3])
+def test_decode_peak_filter_windows_vs_reference_golden(eng, window):
+    """test_config['local_maximum_kernel'] other than 3: bit-exact against the reference's own filter + top-k
+    (tests/golden/localmax_windows.npz) and, for the boxes, the oracle run with the same window; 3 last -- the handle's
+    setting must come back"""
+    from oracle import monocon_oracle as O
+    g = load_golden("localmax_windows.npz")
+    K, B, H, W = 20, 2, 24, 44
+    d = synth.make_decode_inputs(int(g["seed"]), B, H, W, topk=K)
+    R = run(eng, d, K, pad_hw=(4 * H, 4 * W), window=window)
+    assert np.array_equal(np.packbits(R["keep"].cpu().numpy().astype(bool)), g["keep_packed.%d" % window])
+    assert np.array_equal((R["flat_index"] % (H * W)).cpu().numpy(), g["ind.%d" % window])
+    assert np.array_equal(R["cls"].cpu().numpy(), g["cls.%d" % window])
+    assert np.array_equal(R["scores"].cpu().numpy(), g["scores.%d" % window])
+    ref = O.decode({k: torch.from_numpy(v) for k, v in d.items()}, np.stack([synth.KITTI_P2] * B), (4 * H, 4 * W), topk=K,
+                   thres=0.4, kernel=window)
+    assert torch.equal(R["box_mask"].cpu(), ref["box_mask"])
+    assert rel_err(R["box2d"].cpu(), ref["box2d"]) < 1e-4
+    assert rel_err(R["box3d"].cpu(), ref["box3d_shift"]) < 1e-4
+
+
+def test_decode_even_peak_filter_window_is_an_error(eng):
+    from hipmonocon.lib import MonoconHipError
+    d = synth.make_decode_inputs(5, 1, 8, 16, topk=4)
+    with pytest.raises(MonoconHipError, match="odd"):
+        run(eng, d, 4, pad_hw=(32, 64), window=4)
+    R = run(eng, d, 4, pad_hw=(32, 64))        # the handle keeps its previous (valid) setting
+    assert R["scores"].shape == (1, 4)
 
 
 def test_decode_config5_b64_k100_vs_oracle(eng):

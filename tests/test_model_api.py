@@ -69,7 +69,8 @@ def test_initialisers_pinned_to_the_reference():
         ref = g["moments"][i]
         if same_build:
             assert zlib.crc32(v.detach().contiguous().numpy().tobytes()) == int(g["crc32"][i]), k
-            assert np.array_equal(mom, ref), k
+            # identical bytes; the fp64 mean / std are reduced in an order that depends on the host's threads / vector width
+            assert np.allclose(mom, ref, rtol=1e-9, atol=1e-12), k
         else:   # another torch build may draw different normals: distribution-level agreement
             n = max(f.numel(), 1)
             assert abs(mom[0] - ref[0]) <= 6 * max(ref[1], 1e-6) / n ** 0.5 + 1e-6, k

@@ -148,6 +148,21 @@ def test_decode(K):
         assert np.array_equal(R["cls"][i][mk].numpy(), g["label.%d" % i])
 
 
+@pytest.mark.parametrize("window", [1, 3, 5, 7])
+def test_decode_peak_filter_windows(window):
+    """test_config['local_maximum_kernel'] other than 3 (utils/tensor_ops.py:17-21): keep mask, peak scores, indices and
+    classes against the reference's own get_local_maximum / get_topk_from_heatmap (tests/golden/make_localmax_golden.py)"""
+    g = load_golden("localmax_windows.npz")
+    K, B, H, W = 20, 2, 24, 44
+    d = synth.make_decode_inputs(int(g["seed"]), B, H, W, topk=K)
+    R = O.decode({k: torch.from_numpy(v) for k, v in d.items()}, np.stack([synth.KITTI_P2] * B), (4 * H, 4 * W), topk=K, thres=0.4,
+                 kernel=window)
+    assert np.array_equal(np.packbits(R["keep"].numpy()), g["keep_packed.%d" % window])
+    assert np.array_equal(R["ind"].numpy(), g["ind.%d" % window])
+    assert np.array_equal(R["cls"].numpy(), g["cls.%d" % window])
+    assert np.array_equal(R["scores"].numpy(), g["scores.%d" % window])
+
+
 @pytest.mark.parametrize("case", [0, 1])
 def test_conditioned_train_fixture(cond_sd, case):
     """the oracle's fp32 train step on a flip-free fixture (make_golden.py cond_train): every loss within 1e-4 of
