@@ -1275,6 +1275,15 @@ int mc_profile_forward(mc_handle *h, int iters, float out_ms[3], int out_n[3], v
             float ms = 0;
             HIPCHK(h, hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             if (pl->ops[i].kind == OP_CONV) { acc_conv += ms; ++n_conv; } else { acc_other += ms; ++n_other; }
+            if (it == 0 && std::getenv("MONOCON_HIP_PROFILE_DUMP")) {       // measurement aid: one line per op of the eval plan
+                const Op &o = pl->ops[i];
+                if (o.kind == OP_CONV)
+                    std::fprintf(stderr, "fprof %zu conv k%d s%d %4d -> %-4d (%d src) %3dx%-4d res %d cfg %3d  ms %.4f  gflop %.2f  TF(fp32-eq) %.1f\n", i, o.ks,
+                                 o.stride, o.ca.Cin, o.ca.Cout, o.ca.nsrc, o.ca.Hout, o.ca.Wout, o.ca.res != nullptr, o.ca.cfg, ms, o.flops * 1e-9,
+                                 o.flops / (ms * 1e-3) * 1e-12);
+                else
+                    std::fprintf(stderr, "fprof %zu kind %d  ms %.4f  mb %.1f\n", i, (int)o.kind, ms, o.bytes * 1e-6);
+            }
         }
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, ev[0], ev[nops]));
