@@ -230,13 +230,24 @@ MODES = {
 }
 
 
+# the kernels behind launch_conv() in the split modes: the event-timed conv bucket is their sum (conv_bf16_kernel dominates:
+# 1 860 of the 1 976 sampled launches in profiles/r5m_pmc.txt)
+CONV_FAMILY = ("mc::conv_bf16_kernel", "mc::conv_wres_kernel", "mc::conv_thin16_kernel", "mc::conv_small_kernel")
+
+
 def _traffic(family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected in-process)"""
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes (cannot be collected in-process);
+    for the conv family of the split modes: launch-weighted over the kernels launch_conv() dispatches to"""
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "latest_traffic.json")))
-        fam = tj["families"][family]
-        pmc = {k: round(fam[k], 3) for k in ("mfma_busy", "clock_ghz") if fam.get(k) is not None}
-        return round((fam["hbm_read_bytes_per_launch"] + fam["hbm_write_bytes_per_launch"]) / 1e6, 1), tj["source"], pmc
+        members = [m for m in (CONV_FAMILY if family == CONV_FAMILY[0] else (family,)) if m in tj["families"]]
+        fams = [tj["families"][m] for m in members]
+        n = sum(f["launches_sampled"] for f in fams)
+        mb = sum((f["hbm_read_bytes_per_launch"] + f["hbm_write_bytes_per_launch"]) * f["launches_sampled"] for f in fams) / n / 1e6
+        t = sum(f["avg_us_under_pmc"] * f["launches_sampled"] for f in fams)
+        pmc = {k: round(sum(f[k] * f["avg_us_under_pmc"] * f["launches_sampled"] for f in fams) / t, 3)
+               for k in ("mfma_busy", "clock_ghz") if all(f.get(k) is not None for f in fams)}
+        return round(mb, 1), tj["source"] + " [" + ", ".join(members) + "]", pmc
     except Exception:
         return None, None, {}
 

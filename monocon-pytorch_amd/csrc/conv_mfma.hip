@@ -8,8 +8,11 @@ thread_local ProfLast prof_last = {0, 0.0, 0.0};
 static ProfLast conv_cost(const ConvArgs &a, int ks) {
     const double px_in = (double)a.B * a.Hin * a.Win, px_out = (double)a.B * a.Hout * a.Wout;
     const double taps = win_h(ks) * win_w(ks);
+    // algorithmic bytes: the input, the output (+ the residual / the gradient accumulated into), the weights, and for a
+    // backward-statistics launch the forward's y (and z where the ReLU mask is the stored activation's)
+    const int extra = (a.res ? 1 : 0) + (a.bm_y ? 1 : 0) + ((a.bm_y && a.bm_relu == 1) ? 1 : 0);
     return {1, 2.0 * px_out * a.Cout * a.Cin * taps,
-            4.0 * (px_in * a.Cin + px_out * a.Cout * (a.res ? 2 : 1) + taps * a.Cin * a.Cout)};
+            4.0 * (px_in * a.Cin + px_out * a.Cout * (1 + extra) + taps * a.Cin * a.Cout)};
 }
 
 template <int KS, int S, int CK, int WM, int WN, int WTM, int WTN, bool BM = false>
