@@ -71,9 +71,11 @@ def parse():
                     help="precision mode of the headline value: all three keep fp32 values and meet the fp32 parity tolerances")
     ap.add_argument("--realistic-steps", type=int, default=6,
                     help="steps of the realistic_loop leg (fresh labels + H2D of uint8 frames + loss.item() per step); 0 = skip")
-    ap.add_argument("--allow-fallback", action="store_true",
-                    help="N > 1: if the handle cannot build its own RCCL communicator, fall back to torch.distributed's all_reduce "
-                         "(also RCCL) instead of failing; the line then says path = torch")
+    ap.add_argument("--strict-comm", action="store_true",
+                    help="N > 1: exit non-zero if the handle cannot build its own RCCL communicator.  Default: measure with "
+                         "torch.distributed's all_reduce (also RCCL, not overlapped) instead and SAY SO -- comm_path = 'torch "
+                         "(FALLBACK: <reason>)' in the line, the reason on stderr; never silent")
+    ap.add_argument("--allow-fallback", action="store_true", help="(the default since round 5; kept for old command lines)")
     ap.add_argument("--full-json", default=None,
                     help="where the verbose report (every leg with its prose notes) goes; default gpurun_out/bench_full.json when "
                          "that directory exists, else bench_full.json beside this file.  stdout carries ONE compact line")
@@ -349,9 +351,10 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the exchange path is part of what is measured: without --allow-fallback a communicator the handle cannot build
-        # is a hard error on every rank (non-zero exit), not a silent switch to torch.distributed's all_reduce
-        os.environ["MONOCON_HIP_DP_FALLBACK"] = "1" if args.allow_fallback else "0"
+        # the exchange path is part of what is measured and is NAMED in the line (comm_path): a communicator the handle cannot
+        # build switches every rank (voted) to torch.distributed's all_reduce with the reason in the line and on stderr;
+        # --strict-comm makes it a hard error on every rank (non-zero exit) instead
+        os.environ["MONOCON_HIP_DP_FALLBACK"] = "0" if args.strict_comm else "1"
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -426,7 +429,8 @@ def main():
             dist.all_gather(allt, t)
             out["per_rank_ms_per_step"] = [round(float(x[0]), 3) for x in allt]
             out["per_rank_exposed_allreduce_ms"] = [round(float(x[1]), 3) for x in allt]
-            out["comm"] = eng_.comm_info() if eng_.comm_world else {"path": "torch.distributed all_reduce after backward"}
+            out["comm"] = eng_.comm_info() if eng_.comm_world else {"path": "torch.distributed all_reduce after backward",
+                                                                     "fallback_reason": getattr(eng_, "comm_fallback_reason", None)}
         if profile and rank == 0:
             out["profile"] = m._rt.engine.profile_train(iters=2)   # HIP events around every launch on the launch stream
             out["workspace_gb"] = m._rt.engine.workspace_bytes() / 1e9
@@ -677,7 +681,12 @@ def main():
             comm = head.get("comm") or {}
             out["comm_world"] = comm.get("world", 0)                         # ranks in the handle's own RCCL communicator (0: none)
             out["n_collectives"] = comm.get("collectives_per_exchange", 1 if "path" in comm else None)
-            out["comm_path"] = "rccl (handle-owned communicator, overlapped buckets)" if comm.get("world") else "torch"
+            if comm.get("world"):
+                out["comm_path"] = "rccl (handle-owned communicator, overlapped buckets)"
+            elif comm.get("fallback_reason"):
+                out["comm_path"] = "torch (FALLBACK: %s)" % comm["fallback_reason"]
+            else:
+                out["comm_path"] = "torch"
             out["per_rank_ms_per_step"] = head.get("per_rank_ms_per_step")
             out["per_rank_exposed_allreduce_ms"] = head.get("per_rank_exposed_allreduce_ms")
         if dec is not None:

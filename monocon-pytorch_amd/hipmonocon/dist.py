@@ -189,8 +189,12 @@ def ensure_engine_comm(engine, force=False):
         if engine.comm_world:
             engine.comm_destroy()
         if os.environ.get("MONOCON_HIP_DP_FALLBACK", "0") == "1" and not force:
+            import sys
             if rank == 0:
-                print("[hipmonocon] RCCL communicator unavailable (%s): falling back to torch.distributed all_reduce" % (err,), flush=True)
+                print("[hipmonocon] RCCL communicator unavailable (%s): falling back to torch.distributed all_reduce" % (err,),
+                      file=sys.stderr, flush=True)
+            # (err is None on a rank whose own init succeeded and which lost the vote)
+            engine.comm_fallback_reason = str(err) if err is not None else "another rank could not join the communicator"
             os.environ["MONOCON_HIP_DP"] = "torch"
             return False
         raise RuntimeError("could not build the handle's RCCL communicator: %s" % (err,))

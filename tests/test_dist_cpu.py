@@ -200,6 +200,7 @@ def _world8_worker(rank, world, port, out):
     os.environ["MONOCON_HIP_DP"] = "rccl"
     e3 = _FakeEngine(rank, fail_init_on={5})
     res["fallback_init"] = (hdist.ensure_engine_comm(e3), e3.comm_world)
+    res["fallback_reason"] = getattr(e3, "comm_fallback_reason", None)       # bench.py prints it as comm_path
     os.environ["MONOCON_HIP_DP"] = "rccl"
     os.environ["MONOCON_HIP_DP_FALLBACK"] = "0"
     e4 = _FakeEngine(rank, fail_init_on={3})
@@ -239,6 +240,7 @@ def test_world8_start_up_protocol_and_bucket_schedule():
         assert o["inited"] == (r, world, _FakeEngine(0).comm_unique_id())
         assert o["fallback_uid"] is False
         assert o["fallback_init"] == (False, 0)
+        assert o["fallback_reason"]             # every rank can name why (its own error, or "another rank ...")
         assert o["hard"].startswith("could not build the handle's RCCL")
     # bucket ranges are disjoint and cover the buffer in order
     rng = r0["buckets"]
