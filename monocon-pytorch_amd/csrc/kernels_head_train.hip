@@ -69,75 +69,154 @@ struct HeadBwdArgs {
     const float *scale, *shift;       // [B][CP] AttnBN coefficients of the forward (used when z is null)
     float *d, *dw_partial, *red_partial;
     int HW, rows_per_block, blocks_per_img;
+    // MODE 2 (head_dx_kernel): [B][CP] float4 (P, Q, R, -) of the AttnBN backward; d receives dx = P*d + Q*x + R;
+    // csum [blocks][CP][2]: column sums of dx per workgroup; amax: max |dx|
+    const float *coef;
+    float *csum;
+    unsigned *amax;
 };
 // The rows of draw are the same for all lanes of a wave.  Round 2 took them down the scalar path (s_load per pixel):
 // measured in round 3 (rocprofv3: 2.07 ms, 2.4 TB/s, waves parked 85 % of the time) that path has no prefetch -- every
 // pixel of the 24-row head waited a full memory round trip for its 96 bytes.  Now a workgroup stages the rows of HB_PX
 // pixels in LDS with coalesced 16-byte loads (fetched one block ahead into registers) and every wave reads its rows as
 // LDS broadcasts.
-constexpr int HB_PX = 32, HB_LD = 80;
-template <int RB, int NR>
-__device__ __forceinline__ void head_bwd_block(const HeadBwdArgs &a, const float (*gsh)[HB_LD], int lane, int n, const float *xp,
-                                               const float *zp, float *dp, bool rez, float zsc, float zsh, const float (&w)[NR],
-                                               float (&acc)[NR], float &s1, float &s2) {
-    constexpr int CP = NUM_HEADS * HEAD_CH;
-    auto one = [&](int i, float zv, float xv) {
-        const float *g = &gsh[i][RB];
+constexpr int HB_PX = 64, HB_LD = 80;
+// Work per pixel is proportional to a head's row count (2 ... 24): with one wave per head in a nine-wave workgroup the two
+// widest heads set the pace of all nine (round 5, rows cut to two per head: 1.17 -> 0.50 ms).  The head is a GRID dimension
+// now: a workgroup = (pixel block, head), four waves that take the pixels i % 4 == wave of every staged block and fold their
+// sums through LDS in wave order (fixed order: deterministic); the hardware's workgroup scheduler does the balancing.
+constexpr int HB_WAVES = 4, HB_NT = HB_WAVES * 64, HB_MAXR = 24;
+
+// MODE 0: the pass as described above; 1: the same without storing d (the plan's default since round 5: 2.3 GB less written
+// here and 2.3 GB less read by the pass that follows); 2: head_dx_kernel -- d is formed again by the same fma chain
+// (bit-identical) and leaves as dx = P*d + Q*x + R, s1 = column sum of dx, s2 = max |dx|
+template <int RB, int NR, int MODE>
+struct HeadPart {
+    static constexpr int CP = NUM_HEADS * HEAD_CH;
+    float w[NR], acc[NR];
+    float s1, s2, zsc, zsh, cp, cq, cr;
+    const float *xp, *zp;
+    float *dp;
+    bool rez;
+    int h, sub, nsub;
+
+    __device__ __forceinline__ void init(const HeadBwdArgs &a, int h_, int lane, size_t p0, int b, int sub_, int nsub_) {
+        h = h_; sub = sub_; nsub = nsub_;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { w[r] = a.w1[(RB + r) * HEAD_CH + lane]; acc[r] = 0.f; }
+        s1 = 0.f; s2 = 0.f;
+        rez = a.z == nullptr;
+        zsc = rez ? a.scale[(size_t)b * CP + h * HEAD_CH + lane] : 0.f;
+        zsh = rez ? a.shift[(size_t)b * CP + h * HEAD_CH + lane] : 0.f;
+        xp = a.x + p0 * CP + h * HEAD_CH + lane;
+        zp = rez ? xp : a.z + p0 * CP + h * HEAD_CH + lane;
+        dp = MODE == 1 ? nullptr : a.d + p0 * CP + h * HEAD_CH + lane;
+        cp = cq = cr = 0.f;
+        if (MODE == 2) {
+            const float4 cf = reinterpret_cast<const float4 *>(a.coef)[(size_t)b * CP + h * HEAD_CH + lane];
+            cp = cf.x; cq = cf.y; cr = cf.z;
+        }
+    }
+    __device__ __forceinline__ void one(const float *gsh, int i, size_t gp, float zv, float xv) {
+        const float *g = gsh + i * NR;          // the head's NR raw-gradient rows of pixel i (LDS broadcast)
         float dh = 0.f;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const float gv = g[r];
-            acc[r] = fmaf(gv, zv, acc[r]);
+            if (MODE != 2) acc[r] = fmaf(gv, zv, acc[r]);
             dh = fmaf(gv, w[r], dh);
         }
         const float dv = zv > 0.f ? dh : 0.f;
-        s1 += dv;
-        s2 = fmaf(dv, xv, s2);
-        dp[(size_t)i * CP] = dv;
-    };
-    constexpr int U = 8;                              // x loads in flight
-    int i = 0;
-    for (; i + U <= n; i += U) {
-        float zv[U], xv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            xv[u] = xp[(size_t)(i + u) * CP];
-            if (!rez) zv[u] = zp[(size_t)(i + u) * CP];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            one(i + u, rez ? fmaxf(fmaf(xv[u], zsc, zsh), 0.f) : zv[u], xv[u]);
-            if (NR > 8) __builtin_amdgcn_sched_barrier(0);      // keep the wide heads from hoisting 8 pixels x NR row values into registers
+        if (MODE == 2) {
+            const float o = fmaf(cp, dv, fmaf(cq, xv, cr));      // (affine_bwd_kernel's expression)
+            s1 += o;
+            s2 = fmaxf(s2, fabsf(o));
+            dp[gp * CP] = o;
+        } else {
+            s1 += dv;
+            s2 = fmaf(dv, xv, s2);
+            if (MODE == 0) dp[gp * CP] = dv;
         }
     }
-    for (; i < n; ++i) {
-        const float xv1 = xp[(size_t)i * CP];
-        one(i, rez ? fmaxf(fmaf(xv1, zsc, zsh), 0.f) : zp[(size_t)i * CP], xv1);
-    }
-}
-template <int RB, int NR>
-__device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, float (*gsh)[HB_LD], int h, int lane, size_t p0, int np, int blk,
-                                              int b) {
-    constexpr int CP = NUM_HEADS * HEAD_CH;
-    constexpr int NT = NUM_HEADS * 64, F4 = HB_PX * HB_LD / 4, NL = (F4 + NT - 1) / NT;      // float4 loads per thread and block
-    float w[NR], acc[NR];
+    // this part's pixels of the staged block [px0, px0 + n)
+    __device__ __forceinline__ void block(const float *gsh, int px0, int n) {
+        constexpr int U = NR > 8 ? 4 : 8;                 // x loads in flight (a wave sees 16 pixels of a staged block)
+        const int cnt = n > sub ? (n - sub + nsub - 1) / nsub : 0;
+        int k = 0;
+        for (; k + U <= cnt; k += U) {
+            float zv[U], xv[U];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) { w[r] = a.w1[(RB + r) * HEAD_CH + lane]; acc[r] = 0.f; }
-    float s1 = 0.f, s2 = 0.f;
-    const bool rez = a.z == nullptr;
-    const float zsc = rez ? a.scale[(size_t)b * CP + h * HEAD_CH + lane] : 0.f, zsh = rez ? a.shift[(size_t)b * CP + h * HEAD_CH + lane] : 0.f;
-    const float *xp = a.x + p0 * CP + h * HEAD_CH + lane, *zp = rez ? xp : a.z + p0 * CP + h * HEAD_CH + lane;
-    float *dp = a.d + p0 * CP + h * HEAD_CH + lane;
+            for (int u = 0; u < U; ++u) {
+                const size_t gp = (size_t)(px0 + sub + (k + u) * nsub);
+                xv[u] = xp[gp * CP];
+                if (!rez) zv[u] = zp[gp * CP];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = sub + (k + u) * nsub;
+                one(gsh, i, (size_t)(px0 + i), rez ? fmaxf(fmaf(xv[u], zsc, zsh), 0.f) : zv[u], xv[u]);
+                if (NR > 8) __builtin_amdgcn_sched_barrier(0);      // keep the wide heads from hoisting 8 pixels x NR row values into registers
+            }
+        }
+        for (; k < cnt; ++k) {
+            const int i = sub + k * nsub;
+            const size_t gp = (size_t)(px0 + i);
+            const float xv1 = xp[gp * CP];
+            one(gsh, i, gp, rez ? fmaxf(fmaf(xv1, zsc, zsh), 0.f) : zp[gp * CP], xv1);
+        }
+    }
+    // parts 1 .. n-1 of a shared head park their sums in LDS ...
+    __device__ __forceinline__ void spill(float *red, int lane) const {
+        if (nsub == 1 || sub == 0) return;
+        float *q = red + (size_t)(sub - 1) * (NR + 2) * 64 + lane;
+        if (MODE != 2) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) q[r * 64] = acc[r];
+        }
+        q[NR * 64] = s1;
+        q[(NR + 1) * 64] = s2;
+    }
+    // ... part 0 adds them in part order and writes the workgroup's partials
+    __device__ __forceinline__ void finish(const HeadBwdArgs &a, const float *red, int blk, int lane) {
+        if (MODE == 2 && a.amax) amax_update_wave(a.amax, s2);      // (a maximum: every part commits its own)
+        if (sub != 0) return;
+        for (int k = 1; k < nsub; ++k) {
+            const float *q = red + (size_t)(k - 1) * (NR + 2) * 64 + lane;
+            if (MODE != 2) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[r] += q[r * 64];
+                s2 += q[(NR + 1) * 64];
+            }
+            s1 += q[NR * 64];
+        }
+        if (MODE == 2) {
+            a.csum[((size_t)blk * CP + h * HEAD_CH + lane) * 2] = s1;      // colsum_final_kernel's partial format
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) a.dw_partial[((size_t)blk * NUM_OUT_ROWS + RB + r) * HEAD_CH + lane] = acc[r];
+        float *rp = a.red_partial + ((size_t)blk * CP + h * HEAD_CH + lane) * 2;
+        rp[0] = s1;
+        rp[1] = s2;
+    }
+};
+
+// One head of one pixel block: the head's NR columns of the raw-gradient rows are staged HB_PX pixels at a time (fetched one
+// block ahead into registers), every wave reads them as LDS broadcasts.
+template <int RB, int NR, int MODE>
+__device__ __forceinline__ void head_bwd_one(const HeadBwdArgs &a, float *gsh, float *red, int h, int wv, int lane, size_t p0, int np,
+                                             int blk, int b) {
+    HeadPart<RB, NR, MODE> P;
+    P.init(a, h, lane, p0, b, wv, HB_WAVES);
+    constexpr int NE = HB_PX * NR, NL = (NE + HB_NT - 1) / HB_NT;      // staged floats per block, loads per thread
     const int tid = threadIdx.x;
-    // rows of draw: pixel-major, a.ld == HB_LD floats per pixel -> a block of HB_PX pixels is one contiguous run
-    const float4 *gsrc = reinterpret_cast<const float4 *>(a.draw + p0 * a.ld);
-    float4 pre[NL];
+    const float *gsrc = a.draw + p0 * a.ld + RB;
+    float pre[NL];
     auto fetch = [&](int px0) {
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
-            const int e = tid + k * NT;
-            const bool ok = e < F4 && px0 + e / (HB_LD / 4) < np;
-            pre[k] = ok ? gsrc[(size_t)px0 * (HB_LD / 4) + e] : float4{0.f, 0.f, 0.f, 0.f};
+            const int e = tid + k * HB_NT, px = e / NR, r = e % NR;
+            pre[k] = (e < NE && px0 + px < np) ? gsrc[(size_t)(px0 + px) * a.ld + r] : 0.f;
         }
     };
     fetch(0);
@@ -145,58 +224,93 @@ __device__ __forceinline__ void head_bwd_rows(const HeadBwdArgs &a, float (*gsh)
         __syncthreads();                              // the previous block's rows are no longer read
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
-            const int e = tid + k * NT;
-            if (e < F4) reinterpret_cast<float4 *>(&gsh[0][0])[e] = pre[k];
+            const int e = tid + k * HB_NT;
+            if (e < NE) gsh[e] = pre[k];
         }
         __syncthreads();
         if (px0 + HB_PX < np) fetch(px0 + HB_PX);     // next block's rows travel while this one is processed
-        const int n = min(HB_PX, np - px0);
-        head_bwd_block<RB, NR>(a, gsh, lane, n, xp + (size_t)px0 * CP, zp + (size_t)px0 * CP, dp + (size_t)px0 * CP, rez, zsc, zsh, w, acc,
-                               s1, s2);
+        P.block(gsh, px0, min(HB_PX, np - px0));
     }
-#pragma unroll
-    for (int r = 0; r < NR; ++r) a.dw_partial[((size_t)blk * NUM_OUT_ROWS + RB + r) * HEAD_CH + lane] = acc[r];
-    float *rp = a.red_partial + ((size_t)blk * CP + h * HEAD_CH + lane) * 2;
-    rp[0] = s1;
-    rp[1] = s2;
+    P.spill(red, lane);
+    __syncthreads();
+    P.finish(a, red, blk, lane);
 }
-__global__ __launch_bounds__(NUM_HEADS * 64) void head_bwd_kernel(const HeadBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float gsh[HB_PX][HB_LD];
+// WIDE = false: the six heads of two or three rows (every one of them a pure stream over x: few registers, many waves in
+// flight); true: the heads of 9, 18 and 24 rows.  Two launches, so that the narrow heads do not inherit the wide heads' registers.
+template <int MODE, bool WIDE>
+__global__ __launch_bounds__(HB_NT) void head_bwd_kernel(const HeadBwdArgs a) {
+    __shared__ float gsh[HB_PX * (WIDE ? HB_MAXR : 3)];
+    __shared__ float red[(HB_WAVES - 1) * ((WIDE ? HB_MAXR : 3) + 2) * 64];
     const int lane = threadIdx.x & 63;
-    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int blk = blockIdx.x;
     const int b = blk / a.blocks_per_img, rb = blk % a.blocks_per_img;
     const int r0 = rb * a.rows_per_block;
     const int np = min(a.HW, r0 + a.rows_per_block) - r0;
     const size_t p0 = (size_t)b * a.HW + r0;
-    switch (h) {   // (first row, row count) of each head in HeadRow order
-        case 0: head_bwd_rows<0, 3>(a, gsh, h, lane, p0, np, blk, b); break;
-        case 1: head_bwd_rows<3, 2>(a, gsh, h, lane, p0, np, blk, b); break;
-        case 2: head_bwd_rows<5, 2>(a, gsh, h, lane, p0, np, blk, b); break;
-        case 3: head_bwd_rows<7, 18>(a, gsh, h, lane, p0, np, blk, b); break;
-        case 4: head_bwd_rows<25, 9>(a, gsh, h, lane, p0, np, blk, b); break;
-        case 5: head_bwd_rows<34, 2>(a, gsh, h, lane, p0, np, blk, b); break;
-        case 6: head_bwd_rows<36, 3>(a, gsh, h, lane, p0, np, blk, b); break;
-        case 7: head_bwd_rows<39, 2>(a, gsh, h, lane, p0, np, blk, b); break;
-        default: head_bwd_rows<41, 24>(a, gsh, h, lane, p0, np, blk, b); break;
+    // (first row, row count) of each head in HeadRow order: 0:(0,3) 1:(3,2) 2:(5,2) 3:(7,18) 4:(25,9) 5:(34,2) 6:(36,3) 7:(39,2) 8:(41,24)
+    if (WIDE) {
+        switch (blockIdx.y) {
+            case 0: head_bwd_one<41, 24, MODE>(a, gsh, red, 8, wv, lane, p0, np, blk, b); break;
+            case 1: head_bwd_one<7, 18, MODE>(a, gsh, red, 3, wv, lane, p0, np, blk, b); break;
+            default: head_bwd_one<25, 9, MODE>(a, gsh, red, 4, wv, lane, p0, np, blk, b); break;
+        }
+    } else {
+        switch (blockIdx.y) {
+            case 0: head_bwd_one<0, 3, MODE>(a, gsh, red, 0, wv, lane, p0, np, blk, b); break;
+            case 1: head_bwd_one<3, 2, MODE>(a, gsh, red, 1, wv, lane, p0, np, blk, b); break;
+            case 2: head_bwd_one<5, 2, MODE>(a, gsh, red, 2, wv, lane, p0, np, blk, b); break;
+            case 3: head_bwd_one<34, 2, MODE>(a, gsh, red, 5, wv, lane, p0, np, blk, b); break;
+            case 4: head_bwd_one<36, 3, MODE>(a, gsh, red, 6, wv, lane, p0, np, blk, b); break;
+            default: head_bwd_one<39, 2, MODE>(a, gsh, red, 7, wv, lane, p0, np, blk, b); break;
+        }
     }
 }
+template <int MODE>
+static void head_bwd_launch(const HeadBwdArgs &a, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL((head_bwd_kernel<MODE, true>), dim3(blocks, 3), dim3(HB_NT), 0, st, a);
+    hipLaunchKernelGGL((head_bwd_kernel<MODE, false>), dim3(blocks, 6), dim3(HB_NT), 0, st, a);
+}
 // blocks = chan_reduce_blocks(B, HW); rows_per_block = that partition's row count (kernels_train.hip)
-hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const float *x, const float *w1, int B, int HW,
-                           int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st, const float *scale,
-                           const float *shift) {
+static hipError_t head_bwd_args(HeadBwdArgs &a, const float *draw, int ld, const float *z, const float *x, const float *w1, int B,
+                                int HW, int blocks, const float *scale, const float *shift) {
     const int *rbeg = head_row_begin();
     static const int RB[NUM_HEADS + 1] = {0, 3, 5, 7, 25, 34, 36, 39, 41, 65};
     for (int i = 0; i <= NUM_HEADS; ++i)
         if (rbeg[i] != RB[i]) return hipErrorInvalidValue;      // the switch above hard-codes the HeadRow table
-    if (blocks % B || ld != HB_LD || (reinterpret_cast<uintptr_t>(draw) & 15)) return hipErrorInvalidValue;
-    HeadBwdArgs a;
+    if (blocks % B || ld != HB_LD) return hipErrorInvalidValue;
     if (!z && (!scale || !shift)) return hipErrorInvalidValue;
-    a.draw = draw; a.ld = ld; a.z = z; a.x = x; a.w1 = w1; a.d = d; a.dw_partial = dw_partial; a.red_partial = red_partial;
+    a = HeadBwdArgs{};
+    a.draw = draw; a.ld = ld; a.z = z; a.x = x; a.w1 = w1;
     a.scale = scale; a.shift = shift;
     a.HW = HW; a.blocks_per_img = blocks / B; a.rows_per_block = (HW + a.blocks_per_img - 1) / a.blocks_per_img;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(NUM_HEADS * 64), 0, st, a);
+    return hipSuccess;
+}
+// d == nullptr: the masked gradient is not stored (launch_head_dx forms it again)
+hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const float *x, const float *w1, int B, int HW,
+                           int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st, const float *scale,
+                           const float *shift) {
+    HeadBwdArgs a;
+    hipError_t e = head_bwd_args(a, draw, ld, z, x, w1, B, HW, blocks, scale, shift);
+    if (e != hipSuccess) return e;
+    a.d = d; a.dw_partial = dw_partial; a.red_partial = red_partial;
+    if (d) head_bwd_launch<0>(a, blocks, st);
+    else head_bwd_launch<1>(a, blocks, st);
     return hipGetLastError();
+}
+// The AttnBN backward dx = P*d + Q*x + R (coef: [B][CP] float4, attn_train_bwd_kernel) from (draw, x) instead of a stored d:
+// same partition and per-pixel arithmetic as head_bwd_kernel, so d is the value that kernel reduced.  csum: [blocks][CP][2]
+// workspace; csum_out [CP]: column sums of dx (bias gradients of the fused 3x3 convs); amax: slot of max |dx| (or null).
+hipError_t launch_head_dx(const float *draw, int ld, const float *x, const float *w1, const float *coef, int B, int HW, int blocks,
+                          float *dx, float *csum, float *csum_out, unsigned *amax, hipStream_t st, const float *scale,
+                          const float *shift) {
+    if (!coef || !dx || !csum || !csum_out) return hipErrorInvalidValue;
+    HeadBwdArgs a;
+    hipError_t e = head_bwd_args(a, draw, ld, nullptr, x, w1, B, HW, blocks, scale, shift);
+    if (e != hipSuccess) return e;
+    a.d = dx; a.coef = coef; a.csum = csum; a.amax = amax;
+    head_bwd_launch<2>(a, blocks, st);
+    return launch_colsum_final(csum, blocks, NUM_HEADS * HEAD_CH, csum_out, st);
 }
 
 

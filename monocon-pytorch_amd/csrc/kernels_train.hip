@@ -502,6 +502,10 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restri
     __syncthreads();
     if (threadIdx.x == 0) out[c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
+hipError_t launch_colsum_final(const float *partial, int nb, int C, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(C), dim3(256), 0, st, partial, nb, C, out);
+    return hipGetLastError();
+}
 size_t colsum_partial_floats(size_t rows, int ld) { return (size_t)chan_reduce_blocks(1, (int)rows) * ld * 2; }
 hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st) {
     hipError_t e = launch_chan_reduce(x, nullptr, nullptr, nullptr, 1, (int)rows, ld, 0, 0, partial, ld, st);

@@ -763,6 +763,10 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         // the nine 1x1 convs backwards in one pass (head_bwd_kernel): weight-gradient partials, the ReLU-masked
         // data gradient d, and the (sum d, sum d*x) partials of the AttnBN backward
         const int nbr = chan_reduce_blocks(B, HW), rb_per_img = nbr / B;
+        // MONOCON_HIP_HEAD_DX_FUSE=0: round 4's passes (head_bwd_kernel stores the masked gradient d, affine_bwd_kernel reads it
+        // back).  Default: d is never stored -- the AttnBN backward forms it again from the 65 raw-gradient rows
+        // (launch_head_dx; 7 fma per element on average against 4.3 GB less traffic per step at B = 32)
+        const bool dx_fuse = [] { const char *e = std::getenv("MONOCON_HIP_HEAD_DX_FUSE"); return !e || std::atoi(e) != 0; }();
         float *dh = b.alloc(xh.numel());
         float *dw1p = b.alloc((size_t)nbr * NUM_OUT_ROWS * HEAD_CH);
         float *partial = b.alloc((size_t)nbr * CP * 2), *coef = b.alloc((size_t)B * CP * 4);
@@ -784,24 +788,27 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         {
             const float *xp = xh.p, *w1 = h->head_w1, *zsc = at.scale, *zsh = at.shift;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_head_bwd(draw, LD, nullptr, xp, w1, B, HW, nbr, dh, dw1p, partial, st, zsc, zsh));
+                HIPCHK(hh, launch_head_bwd(draw, LD, nullptr, xp, w1, B, HW, nbr, dx_fuse ? nullptr : dh, dw1p, partial, st, zsc, zsh));
                 HIPCHK(hh, launch_splitk_reduce(dw1p, nbr, 1, NUM_OUT_ROWS, HEAD_CH, dw1, st));
                 HIPCHK(hh, launch_copy_batch(segcb, st));
                 return 0;
             });
         }
         float *db3 = b.alloc(CP), *dw3 = b.alloc((size_t)CP * 64 * 9);
-        float *cs3 = b.alloc((size_t)affine_bwd_blocks(B, (size_t)HW, CP) * CP * 2);
+        float *cs3 = b.alloc((size_t)std::max(affine_bwd_blocks(B, (size_t)HW, CP), nbr) * CP * 2);
         Tensor dxT = xh; dxT.p = dx; dxT.amax = b.slot();
         unsigned *dxmax = dxT.amax;
         {
-            const float *xp = xh.p;
+            const float *xp = xh.p, *w1h = h->head_w1, *zsc2 = at.scale, *zsh2 = at.shift;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 // d is already masked: the AttnBN backward is the plain per-(image, channel) affine map; the same pass
                 // leaves the column sums of dx (the 3x3 convs' bias gradients) instead of a second read of dx
                 HIPCHK(hh, launch_attn_train_bwd(at, partial, rb_per_img, gp, coef, st));
-                HIPCHK(hh, launch_affine_bwd(dh, nullptr, xp, coef, B, (size_t)HW, CP, 1, 0, dx, nullptr, 0, st, nullptr, nullptr, cs3, db3,
-                                             dxmax));
+                if (dx_fuse)
+                    HIPCHK(hh, launch_head_dx(draw, LD, xp, w1h, coef, B, HW, nbr, dx, cs3, db3, dxmax, st, zsc2, zsh2));
+                else
+                    HIPCHK(hh, launch_affine_bwd(dh, nullptr, xp, coef, B, (size_t)HW, CP, 1, 0, dx, nullptr, 0, st, nullptr, nullptr, cs3, db3,
+                                                 dxmax));
                 return 0;
             });
         }

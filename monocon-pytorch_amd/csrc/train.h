@@ -124,6 +124,7 @@ int affine_bwd_blocks(int B, size_t rows_per_img, int C);
 hipError_t launch_add(float *a, const float *b, size_t n, hipStream_t st);
 size_t colsum_partial_floats(size_t rows, int ld);
 hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st);
+hipError_t launch_colsum_final(const float *partial, int nb, int C, float *out, hipStream_t st);   // partial [nb][C][2] -> out[C]
 hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
                                hipStream_t st);
 hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C, const float *wpk, float *din,
@@ -161,6 +162,9 @@ hipError_t launch_attn_train_bwd(const AttnTrainArgs &a, const float *partial, i
 hipError_t launch_head_bwd(const float *draw, int ld, const float *z, const float *x, const float *w1, int B, int HW,
                            int blocks, float *d, float *dw_partial, float *red_partial, hipStream_t st,
                            const float *scale = nullptr, const float *shift = nullptr);
+hipError_t launch_head_dx(const float *draw, int ld, const float *x, const float *w1, const float *coef, int B, int HW, int blocks,
+                          float *dx, float *csum, float *csum_out, unsigned *amax, hipStream_t st, const float *scale,
+                          const float *shift);
 hipError_t launch_splitk_reduce(const float *partial, int ksplit, int T, int Cout, int Cin, float *dw, hipStream_t st);
 int stem_wgrad_blocks(int B, int H, int W);
 // img_amax / dy_amax (mode 3): max-|x| slots of the image and of dY -> the fp16-pipe kernel (stem_f16.hip)

@@ -280,6 +280,36 @@ def test_train_step_is_independent_of_the_conv_tiling(golden_sd):
 
 
 
+@pytest.mark.parametrize("precision", ("fp32", "f16x2"))
+def test_head_backward_without_the_stored_gradient_is_bit_identical(golden_sd, precision, monkeypatch):
+    """the AttnBN backward of the heads forms the ReLU-masked gradient of the nine 1x1 convs again from the raw prediction
+    gradients (launch_head_dx, the default) instead of reading what head_bwd_kernel stored (MONOCON_HIP_HEAD_DX_FUSE=0):
+    the same fma chain per element, so every gradient is bit-identical -- except the biases of the heads' 3x3 convs, whose
+    column sums are folded over a different partition (monocon_heads.py:114-131, attentive_norm.py:79-91 under autograd)"""
+    from model import MonoConDetector
+    batch = to_cuda(synth.make_batch(GOLDEN_SEED + 11, 3, 96, 224))
+    res = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("MONOCON_HIP_HEAD_DX_FUSE", fuse)      # read when the train plan is built
+        m = MonoConDetector(34, pretrained_backbone=False)
+        m.load_state_dict(golden_sd, strict=True)
+        m = m.cuda().train().set_precision(precision)
+        _, loss = m(batch)
+        sum(loss.values()).backward()
+        torch.cuda.synchronize()
+        res.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    stored, fused = res
+    assert stored.keys() == fused.keys()
+    n_bias = 0
+    for n in stored:
+        if n.startswith("head.") and n.endswith(".0.bias"):
+            n_bias += 1
+            assert rel_err(fused[n].cpu(), stored[n].cpu()) < 1e-4, n      # (sums of 10^5 terms that cancel to ~1e-5 of their magnitude)
+        else:
+            assert torch.equal(stored[n], fused[n]), n
+    assert n_bias >= 9            # the nine 3x3 convs (dir_cls / dir_reg: their 1x1 convs are called ".0" too and are bit-identical)
+
+
 def test_full_size_train_step_is_deterministic(golden_sd):
     """size-independent property at the full 384x1280 resolution: the same state and batch give bit-identical losses,
     gradients and BN buffers twice in a row (fixed accumulation orders everywhere, two streams included)."""
