@@ -364,25 +364,37 @@ __device__ __forceinline__ void group_reduce2(double &s1, double &s2, double (*s
     for (int g = 0; g < 16; ++g) { s1 += sh[g][c][0]; s2 += sh[g][c][1]; }
 }
 
-// per-(image, channel) sums of the conv epilogue's per-patch partials, fp64, four interleaved quarters combined in a
-// fixed order (same scheme as head_attn_kernel)
-__global__ __launch_bounds__(256) void inst_stats_kernel(const float *__restrict__ stats, int chunks, int stat_ld,
-                                                         double *__restrict__ out) {
-    const int b = blockIdx.x, ch = blockIdx.y * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+// per-(image, channel) sums of per-patch (or per-row-block) partials, fp64: sixteen interleaved parts, each with four loads
+// in flight, combined in a fixed order.  (Round 5: four parts and one load in flight took 140 us for the head conv's 135 MB --
+// 1 TB/s, every load a full round trip; it also serves the backward now, where nine workgroups used to walk the partials
+// of all images one after the other.)
+__global__ __launch_bounds__(1024) void inst_stats_kernel(const float *__restrict__ stats, int chunks, int stat_ld,
+                                                          double *__restrict__ out) {
+    const int b = blockIdx.x, c = threadIdx.x & 63, ch = blockIdx.y * 64 + c, part = threadIdx.x >> 6;
+    const float2 *q = reinterpret_cast<const float2 *>(stats) + (size_t)b * chunks * stat_ld + ch;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = part; k < chunks; k += 4) {
-        const float *q = stats + (((size_t)b * chunks + k) * stat_ld + ch) * 2;
-        s1 += (double)q[0];
-        s2 += (double)q[1];
+    int k = part;
+    for (; k + 48 < chunks; k += 64) {
+        const float2 v0 = q[(size_t)k * stat_ld], v1 = q[(size_t)(k + 16) * stat_ld], v2 = q[(size_t)(k + 32) * stat_ld],
+                     v3 = q[(size_t)(k + 48) * stat_ld];
+        s1 += (double)v0.x; s2 += (double)v0.y;
+        s1 += (double)v1.x; s2 += (double)v1.y;
+        s1 += (double)v2.x; s2 += (double)v2.y;
+        s1 += (double)v3.x; s2 += (double)v3.y;
     }
-    __shared__ double red[2][4][64];
-    const int c = threadIdx.x & 63;
+    for (; k < chunks; k += 16) {
+        const float2 v = q[(size_t)k * stat_ld];
+        s1 += (double)v.x; s2 += (double)v.y;
+    }
+    __shared__ double red[2][16][64];
     red[0][part][c] = s1;
     red[1][part][c] = s2;
     __syncthreads();
-    if (part == 0) {
-        out[((size_t)b * stat_ld + ch) * 2] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-        out[((size_t)b * stat_ld + ch) * 2 + 1] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    if (part < 2) {        // wave 0 folds the sums, wave 1 the sums of squares: parts in order
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[part][g][c];
+        out[((size_t)b * stat_ld + ch) * 2 + part] = t;
     }
 }
 
@@ -392,13 +404,36 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArg
     const int CP = NUM_HEADS * HEAD_CH, ch = h * HEAD_CH + c;
     const double HW = (double)a.HW, n = HW * a.B;
     __shared__ float att[64][NUM_AFFINE];          // a[b][k] then y[b][k]   (B <= 64)
+    // the B x 10 attention inputs are 64-term dot products over the channels: one per thread from these two tables.  (As
+    // 320 wave reductions in a row on one wave -- six dependent cross-lane steps each -- they were most of this kernel's time.)
+    __shared__ float svl[64][HEAD_CH], awl[NUM_AFFINE][HEAD_CH];
     const float shift0 = a.rm[h][c];                // statistics were accumulated around the old running mean
     double S1 = 0, S2 = 0;
+    double pre1[8], pre2[8];                    // (stats64: eight images' sums requested together, not one round trip per image)
+    // every small operand used further down is requested here, together (fetched where it is used, each is a full memory
+    // round trip in a kernel of nine workgroups with nothing to hide it behind)
+    float aw[NUM_AFFINE], wk_[NUM_AFFINE], bk_[NUM_AFFINE];
+#pragma unroll
+    for (int k = 0; k < NUM_AFFINE; ++k) {
+        aw[k] = a.att_w[h][k * HEAD_CH + c]; wk_[k] = a.weight_[h][k * HEAD_CH + c]; bk_[k] = a.bias_[h][k * HEAD_CH + c];
+    }
+    const int ck = c < NUM_AFFINE ? c : 0;
+    const float att_g_c = a.att_g[h][ck], att_b_c = a.att_b[h][ck], att_rm_c = a.att_rm[h][ck], att_rv_c = a.att_rv[h][ck];
+    const float rv_c = a.rv[h][c];
     for (int b = 0; b < a.B; ++b) {
         double s1 = 0, s2 = 0;
         if (a.stats64) {                        // pre-reduced by inst_stats_kernel (B x 9 workgroups instead of 9)
-            s1 = a.stats64[((size_t)b * a.stat_ld + ch) * 2];
-            s2 = a.stats64[((size_t)b * a.stat_ld + ch) * 2 + 1];
+            if ((b & 7) == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int bb = b + u < a.B ? b + u : a.B - 1;
+                    const double2 v = *reinterpret_cast<const double2 *>(a.stats64 + ((size_t)bb * a.stat_ld + ch) * 2);
+                    pre1[u] = v.x; pre2[u] = v.y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if ((b & 7) == u) { s1 = pre1[u]; s2 = pre2[u]; }
         } else {
             for (int k = grp; k < a.chunks; k += 16) {
                 const float *q = a.stats + (((size_t)b * a.chunks + k) * a.stat_ld + ch) * 2;
@@ -414,10 +449,19 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArg
         a.sv_inst[((size_t)b * CP + ch) * 3 + 0] = sv;
         a.sv_inst[((size_t)b * CP + ch) * 3 + 1] = (float)mean;
         a.sv_inst[((size_t)b * CP + ch) * 3 + 2] = (float)var;
-        for (int k = 0; k < NUM_AFFINE; ++k) {
-            const float v = wave_sum(sv * a.att_w[h][k * HEAD_CH + c]);
-            if (c == 0) att[b][k] = v;
-        }
+        svl[b][c] = sv;
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < NUM_AFFINE; ++k) awl[k][c] = aw[k];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < a.B * NUM_AFFINE; e += 1024) {
+        const int b = e / NUM_AFFINE, k = e % NUM_AFFINE;
+        float v = 0.f;
+#pragma unroll 8
+        for (int cc = 0; cc < HEAD_CH; ++cc) v = fmaf(svl[b][cc], awl[k][cc], v);
+        att[b][k] = v;
     }
     const double m0 = S1 / n;
     const double mu = shift0 + m0;
@@ -427,8 +471,8 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArg
     if (grp == 0) {
         a.mu_r[ch * 2 + 0] = (float)mu;
         a.mu_r[ch * 2 + 1] = r;
-        a.rm[h][c] = (1.f - 0.03f) * a.rm[h][c] + 0.03f * (float)mu;
-        a.rv[h][c] = (1.f - 0.03f) * a.rv[h][c] + 0.03f * (float)(var * n / (n - 1.0));
+        a.rm[h][c] = (1.f - 0.03f) * shift0 + 0.03f * (float)mu;          // (shift0 = the old running mean)
+        a.rv[h][c] = (1.f - 0.03f) * rv_c + 0.03f * (float)(var * n / (n - 1.0));
         if (c == 0) *a.nbt[h] += 1;
     }
     __syncthreads();
@@ -442,13 +486,13 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArg
         const float rk = (float)(1.0 / sqrt(av + 1e-5));
         a.bn10[(h * NUM_AFFINE + c) * 2 + 0] = (float)am;
         a.bn10[(h * NUM_AFFINE + c) * 2 + 1] = rk;
-        a.att_rm[h][c] = 0.9f * a.att_rm[h][c] + 0.1f * (float)am;
-        a.att_rv[h][c] = 0.9f * a.att_rv[h][c] + 0.1f * (float)(av * a.B / (a.B - 1.0));
+        a.att_rm[h][c] = 0.9f * att_rm_c + 0.1f * (float)am;
+        a.att_rv[h][c] = 0.9f * att_rv_c + 0.1f * (float)(av * a.B / (a.B - 1.0));
         if (c == 0) *a.att_nbt[h] += 1;
         for (int b = 0; b < a.B; ++b) {
             const float that = (att[b][c] - (float)am) * rk;
             a.that[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + c] = that;
-            const float t = that * a.att_g[h][c] + a.att_b[h][c];
+            const float t = that * att_g_c + att_b_c;
             att[b][c] = fminf(fmaxf(t + 3.f, 0.f), 6.f) / 6.f;
         }
     }
@@ -457,8 +501,8 @@ __global__ __launch_bounds__(1024) void attn_train_fwd_kernel(const AttnTrainArg
         float gam = 0.f, bet = 0.f;
 #pragma unroll
         for (int k = 0; k < NUM_AFFINE; ++k) {
-            gam = fmaf(att[b][k], a.weight_[h][k * HEAD_CH + c], gam);
-            bet = fmaf(att[b][k], a.bias_[h][k * HEAD_CH + c], bet);
+            gam = fmaf(att[b][k], wk_[k], gam);
+            bet = fmaf(att[b][k], bk_[k], bet);
         }
         const size_t o = (size_t)b * CP + ch;
         a.gamma_p[o] = gam;
@@ -472,7 +516,7 @@ hipError_t launch_attn_train_fwd(const AttnTrainArgs &a, hipStream_t st) {
     if (a.B > 64 || a.B < 2) return hipErrorInvalidValue;
     if (a.stats64) {
         if (a.stat_ld % 64) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(inst_stats_kernel, dim3(a.B, a.stat_ld / 64), dim3(256), 0, st, a.stats, a.chunks, a.stat_ld, a.stats64);
+        hipLaunchKernelGGL(inst_stats_kernel, dim3(a.B, a.stat_ld / 64), dim3(1024), 0, st, a.stats, a.chunks, a.stat_ld, a.stats64);
     }
     hipLaunchKernelGGL(attn_train_fwd_kernel, dim3(NUM_HEADS), dim3(1024), 0, st, a);
     return hipGetLastError();
@@ -481,7 +525,8 @@ hipError_t launch_attn_train_fwd(const AttnTrainArgs &a, hipStream_t st) {
 // ------------------------------------------------------------------ AttnBN train backward (one WG per head)
 // partial: [B*rb][576][2] = per row-block (sum dout, sum dout*x), dout = dh*[h>0]
 __global__ __launch_bounds__(1024) void attn_train_bwd_kernel(const AttnTrainArgs a, const float *__restrict__ partial,
-                                                              int rb_per_img, AttnGradPtrs gp, float *__restrict__ coef) {
+                                                              int rb_per_img, AttnGradPtrs gp, float *__restrict__ coef,
+                                                              const double *__restrict__ d64 /*[B][CP][2] pre-reduced, or null*/) {
     __shared__ double shred[16][64][2];
     const int h = blockIdx.x, c = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int CP = NUM_HEADS * HEAD_CH, ch = h * HEAD_CH + c;
@@ -489,44 +534,87 @@ __global__ __launch_bounds__(1024) void attn_train_bwd_kernel(const AttnTrainArg
     const float mu = a.mu_r[ch * 2], r = a.mu_r[ch * 2 + 1];
     __shared__ float dgam[64][HEAD_CH], dbet[64][HEAD_CH];      // [b][c]
     __shared__ float dyk[64][NUM_AFFINE], dak[64][NUM_AFFINE];
+    __shared__ float yat[64][NUM_AFFINE], tht[64][NUM_AFFINE];       // this head's y[b][k] and t_hat[b][k] of the forward
+    __shared__ float wl[NUM_AFFINE][HEAD_CH], bl[NUM_AFFINE][HEAD_CH];   // weight_ / bias_ of the head (for the dot products below)
+    for (int e = threadIdx.x; e < a.B * NUM_AFFINE; e += 1024) {
+        const int b = e / NUM_AFFINE, k = e % NUM_AFFINE;
+        yat[b][k] = a.yatt[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + k];
+        tht[b][k] = a.that[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + k];
+    }
+    // every small operand of the single-wave sections below is requested here, together: fetched where it is used, each was
+    // a full memory round trip on the critical path of the backward (nine workgroups, nothing else to hide it behind)
+    float wk_[NUM_AFFINE], bk_[NUM_AFFINE], aw[NUM_AFFINE];
+#pragma unroll
+    for (int k = 0; k < NUM_AFFINE; ++k) {
+        wk_[k] = a.weight_[h][k * HEAD_CH + c]; bk_[k] = a.bias_[h][k * HEAD_CH + c]; aw[k] = a.att_w[h][k * HEAD_CH + c];
+    }
+    const int ck = c < NUM_AFFINE ? c : 0;
+    const float att_g_c = a.att_g[h][ck], att_b_c = a.att_b[h][ck], bn10_rk = a.bn10[(h * NUM_AFFINE + ck) * 2 + 1];
     double M1 = 0, M2 = 0;
+    double2 pd[8];          // (eight images' operands requested together, not one round trip per image)
+    float pg[8];
     for (int b = 0; b < a.B; ++b) {
         double d1 = 0, d2 = 0;
-        for (int k = grp; k < rb_per_img; k += 16) {
-            const float *q = partial + (((size_t)b * rb_per_img + k) * CP + ch) * 2;
-            d1 += q[0]; d2 += q[1];
+        if ((b & 7) == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bb = b + u < a.B ? b + u : a.B - 1;
+                if (d64) pd[u] = *reinterpret_cast<const double2 *>(d64 + ((size_t)bb * CP + ch) * 2);
+                pg[u] = a.gamma_p[(size_t)bb * CP + ch];
+            }
         }
-        group_reduce2(d1, d2, shred, grp, c);
+        float gp_ = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if ((b & 7) == u) { gp_ = pg[u]; if (d64) { d1 = pd[u].x; d2 = pd[u].y; } }
+        if (d64) {
+        } else {
+            for (int k = grp; k < rb_per_img; k += 16) {
+                const float *q = partial + (((size_t)b * rb_per_img + k) * CP + ch) * 2;
+                d1 += q[0]; d2 += q[1];
+            }
+            group_reduce2(d1, d2, shred, grp, c);
+        }
         const float db = (float)d1, dg = (float)(r * (d2 - mu * d1));
         dbet[b][c] = db; dgam[b][c] = dg;
-        const float gp_ = a.gamma_p[(size_t)b * CP + ch];
         M1 += (double)gp_ * db; M2 += (double)gp_ * dg;
     }
     M1 /= n; M2 /= n;
+    if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < NUM_AFFINE; ++k) { wl[k][c] = wk_[k]; bl[k][c] = bk_[k]; }
+    }
+    __syncthreads();
+    // dy[b][k] = sum_c dgamma[b][c] * weight_[k][c] + dbeta[b][c] * bias_[k][c]: one 64-term dot product per thread (as 320 wave
+    // reductions in a row on one wave they were most of this kernel's time)
+    for (int e = threadIdx.x; e < a.B * NUM_AFFINE; e += 1024) {
+        const int b = e / NUM_AFFINE, k = e % NUM_AFFINE;
+        float v = 0.f;
+#pragma unroll 8
+        for (int cc = 0; cc < HEAD_CH; ++cc) v = fmaf(dgam[b][cc], wl[k][cc], fmaf(dbet[b][cc], bl[k][cc], v));
+        dyk[b][k] = v;
+    }
     __syncthreads();
     if (grp != 0) return;      // the rest is small: one wave (lane = channel); no block-wide barrier below is skipped
     // gradients of weight_ / bias_ and dy[b][k]
+#pragma unroll
     for (int k = 0; k < NUM_AFFINE; ++k) {
         float gw = 0.f, gb = 0.f;
         for (int b = 0; b < a.B; ++b) {
-            const float yv = a.yatt[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + k];
+            const float yv = yat[b][k];
             gw = fmaf(yv, dgam[b][c], gw);
             gb = fmaf(yv, dbet[b][c], gb);
         }
         gp.d_weight_[h][k * HEAD_CH + c] = gw;
         gp.d_bias_[h][k * HEAD_CH + c] = gb;
-        for (int b = 0; b < a.B; ++b) {
-            const float v = wave_sum(dgam[b][c] * a.weight_[h][k * HEAD_CH + c] + dbet[b][c] * a.bias_[h][k * HEAD_CH + c]);
-            if (c == 0) dyk[b][k] = v;
-        }
     }
     __syncthreads();
     // hard-sigmoid + BN(10) backward over the batch: lane k owns attention channel k
     if (c < NUM_AFFINE) {
-        const float g = a.att_g[h][c], be = a.att_b[h][c], rk = a.bn10[(h * NUM_AFFINE + c) * 2 + 1];
+        const float g = att_g_c, be = att_b_c, rk = bn10_rk;
         double s_dt = 0, s_dtt = 0;
         for (int b = 0; b < a.B; ++b) {
-            const float that = a.that[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + c];
+            const float that = tht[b][c];
             const float t = that * g + be;
             const float dt = (t + 3.f > 0.f && t + 3.f < 6.f) ? dyk[b][c] / 6.f : 0.f;
             dyk[b][c] = dt;
@@ -535,7 +623,7 @@ __global__ __launch_bounds__(1024) void attn_train_bwd_kernel(const AttnTrainArg
         gp.d_att_g[h][c] = (float)s_dtt;
         gp.d_att_b[h][c] = (float)s_dt;
         for (int b = 0; b < a.B; ++b) {
-            const float that = a.that[((size_t)b * NUM_HEADS + h) * NUM_AFFINE + c];
+            const float that = tht[b][c];
             dak[b][c] = g * rk * (dyk[b][c] - (float)(s_dt / a.B) - that * (float)(s_dtt / a.B));
         }
     }
@@ -543,18 +631,29 @@ __global__ __launch_bounds__(1024) void attn_train_bwd_kernel(const AttnTrainArg
     float gwa[NUM_AFFINE];
 #pragma unroll
     for (int k = 0; k < NUM_AFFINE; ++k) gwa[k] = 0.f;
+    float psv[8][3];
     for (int b = 0; b < a.B; ++b) {
         const size_t o = (size_t)b * CP + ch;
-        const float sv = a.sv_inst[o * 3], m = a.sv_inst[o * 3 + 1], v = a.sv_inst[o * 3 + 2];
+        if ((b & 7) == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t oo = (size_t)(b + u < a.B ? b + u : a.B - 1) * CP + ch;
+                psv[u][0] = a.sv_inst[oo * 3]; psv[u][1] = a.sv_inst[oo * 3 + 1]; psv[u][2] = a.sv_inst[oo * 3 + 2];
+                pg[u] = a.gamma_p[oo];
+            }
+        }
+        float sv = 0.f, m = 0.f, v = 0.f, gp_ = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if ((b & 7) == u) { sv = psv[u][0]; m = psv[u][1]; v = psv[u][2]; gp_ = pg[u]; }
         float ds = 0.f;
 #pragma unroll
         for (int k = 0; k < NUM_AFFINE; ++k) {
-            ds = fmaf(dak[b][k], a.att_w[h][k * HEAD_CH + c], ds);
+            ds = fmaf(dak[b][k], aw[k], ds);
             gwa[k] = fmaf(dak[b][k], sv, gwa[k]);
         }
         const double ve = (double)v + 1e-3;
         const double dm = ds / sqrt(ve), dv = (double)ds * m * (-0.5) / (ve * sqrt(ve));
-        const float gp_ = a.gamma_p[o];
         float *cf = coef + o * 4;
         cf[0] = r * gp_;
         cf[1] = (float)(-(double)r * r * M2 + 2.0 * dv / (HW - 1.0));
@@ -567,7 +666,15 @@ __global__ __launch_bounds__(1024) void attn_train_bwd_kernel(const AttnTrainArg
 hipError_t launch_attn_train_bwd(const AttnTrainArgs &a, const float *partial, int rb_per_img, const AttnGradPtrs &gp,
                                  float *coef, hipStream_t st) {
     if (a.B > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(NUM_HEADS), dim3(1024), 0, st, a, partial, rb_per_img, gp, coef);
+    // the forward's fp64 scratch ([B][stat_ld][2], stat_ld >= 576) is free again: the row-block partials of every image are
+    // summed there by B x 9 workgroups first
+    constexpr int CP = NUM_HEADS * HEAD_CH;
+    const double *d64 = nullptr;
+    if (a.stats64 && a.stat_ld >= CP) {
+        hipLaunchKernelGGL(inst_stats_kernel, dim3(a.B, CP / 64), dim3(1024), 0, st, partial, rb_per_img, CP, a.stats64);
+        d64 = a.stats64;
+    }
+    hipLaunchKernelGGL(attn_train_bwd_kernel, dim3(NUM_HEADS), dim3(1024), 0, st, a, partial, rb_per_img, gp, coef, d64);
     return hipGetLastError();
 }
 

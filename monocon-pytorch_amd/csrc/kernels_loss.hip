@@ -220,15 +220,24 @@ __device__ double block_sum(double v, double *sh) {
     return s;
 }
 
-__global__ __launch_bounds__(1024) void gathered_loss_kernel(const GatherLossArgs a, int mode) {
+// Three launches instead of one workgroup (round 5: one CU issuing all ~60 gathers of all B * max_objs label rows took 80 us,
+// twice per step): `phase` 0 = the twelve sums over this workgroup's rows -> a.partial[workgroup][12]; 1 = one wave adds the
+// workgroups' rows in order -> totals (kept behind the partials), and in mode 0 writes the losses; 2 = mode 1's gradient
+// scatter of this workgroup's rows, from the totals.
+constexpr int GL_MAXWG = 64, GL_NSUM = 12;
+__global__ __launch_bounds__(256) void gathered_loss_kernel(const GatherLossArgs a, int mode, int phase) {
     __shared__ double sh[16];
-    const int rows = a.B * a.max_objs, HW = a.HW;
+    const int rows_all = a.B * a.max_objs, HW = a.HW;
     const int tid = threadIdx.x, nthr = blockDim.x;
+    const int rows_per_wg = (rows_all + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int row0 = phase == 1 ? 0 : (int)blockIdx.x * rows_per_wg;
+    const int rows = phase == 1 ? 0 : min(rows_all, row0 + rows_per_wg);       // this workgroup's rows: [row0, rows)
+    double *totals = a.partial + GL_MAXWG * GL_NSUM;
     auto P = [&](int p, int nch, int b, int ch, long long ind) -> size_t { (void)p; return ((size_t)b * nch + ch) * HW + ind; };
     // ---- pass 1: sums
     double s_n = 0, s_wh = 0, s_off = 0, s_l1dim = 0, s_ldim = 0, s_dep = 0, s_c2k = 0, s_mc2k = 0, s_kho = 0, s_mkho = 0,
            s_bce = 0, s_areg = 0;
-    for (int r = tid; r < rows; r += nthr) {
+    for (int r = row0 + tid; phase == 0 && r < rows; r += nthr) {
         if (!a.mask_target[r]) continue;
         const int b = r / a.max_objs;
         const long long ind = a.indices[r];
@@ -261,11 +270,26 @@ __global__ __launch_bounds__(1024) void gathered_loss_kernel(const GatherLossArg
         }
         s_areg += fabsf(a.pred[9][P(9, 12, b, cls, ind)] - a.alpha_offset[r]);
     }
-    const double n = block_sum(s_n, sh);
-    const double wh = block_sum(s_wh, sh), off = block_sum(s_off, sh), l1dim = block_sum(s_l1dim, sh);
-    const double ldim = block_sum(s_ldim, sh), dep = block_sum(s_dep, sh), c2k = block_sum(s_c2k, sh);
-    const double mc2k = block_sum(s_mc2k, sh), kho = block_sum(s_kho, sh), mkho = block_sum(s_mkho, sh);
-    const double bce = block_sum(s_bce, sh), areg = block_sum(s_areg, sh);
+    if (phase == 0) {
+        const double v[GL_NSUM] = {block_sum(s_n, sh), block_sum(s_wh, sh), block_sum(s_off, sh), block_sum(s_l1dim, sh),
+                                   block_sum(s_ldim, sh), block_sum(s_dep, sh), block_sum(s_c2k, sh), block_sum(s_mc2k, sh),
+                                   block_sum(s_kho, sh), block_sum(s_mkho, sh), block_sum(s_bce, sh), block_sum(s_areg, sh)};
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < GL_NSUM; ++i) a.partial[(size_t)blockIdx.x * GL_NSUM + i] = v[i];
+        }
+        return;
+    }
+    if (phase == 1) {      // (launched with one workgroup; a.nwg = the workgroups of phase 0)
+        if (tid < GL_NSUM) {
+            double t = 0;
+            for (int g = 0; g < a.nwg; ++g) t += a.partial[(size_t)g * GL_NSUM + tid];
+            totals[tid] = t;
+        }
+        __syncthreads();
+    }
+    const double n = totals[0], wh = totals[1], off = totals[2], l1dim = totals[3], ldim = totals[4], dep = totals[5],
+                 c2k = totals[6], mc2k = totals[7], kho = totals[8], mkho = totals[9], bce = totals[10], areg = totals[11];
     if (mode == 0) {
         if (tid == 0) {
             float *L = a.losses;   // LOSS order: 0 center_heatmap 1 wh 2 offset 3 dim 4 c2k 5 kpt_heatmap 6 kho 7 alpha_cls 8 alpha_reg 9 depth
@@ -285,13 +309,13 @@ __global__ __launch_bounds__(1024) void gathered_loss_kernel(const GatherLossArg
         return;
     }
     // ---- pass 2: gradients, scattered with atomics (two objects may share a pixel)
-    if (n <= 0) return;
+    if (phase != 2 || n <= 0) return;
     const float g_wh = a.gscale[1] * 0.1f / (float)(2 * n), g_off = a.gscale[2] / (float)(2 * n);
     const float comp = (float)((l1dim / (3 * n)) / (ldim / (3 * n)));
     const float g_dim = a.gscale[3] * comp / (float)(3 * n);
     const float g_c2k = a.gscale[4] / (float)(mc2k + 1e-12), g_kho = a.gscale[6] / (float)(mkho + 1e-12);
     const float g_bce = a.gscale[7] / (float)(12 * n), g_areg = a.gscale[8] / (float)n, g_dep = a.gscale[9] / (float)n;
-    for (int r = tid; r < rows; r += nthr) {
+    for (int r = row0 + tid; r < rows; r += nthr) {
         if (!a.mask_target[r]) continue;
         const int b = r / a.max_objs;
         const long long ind = a.indices[r];
@@ -330,8 +354,16 @@ __global__ __launch_bounds__(1024) void gathered_loss_kernel(const GatherLossArg
     }
 }
 
-hipError_t launch_gathered_losses(const GatherLossArgs &a, int mode, hipStream_t st) {
-    hipLaunchKernelGGL(gathered_loss_kernel, dim3(1), dim3(1024), 0, st, a, mode);
+size_t gathered_loss_ws_doubles() { return (size_t)GL_MAXWG * GL_NSUM + GL_NSUM; }
+hipError_t launch_gathered_losses(const GatherLossArgs &a_in, int mode, hipStream_t st) {
+    if (!a_in.partial) return hipErrorInvalidValue;
+    GatherLossArgs a = a_in;
+    const int rows = a.B * a.max_objs;
+    a.nwg = rows < 64 * GL_MAXWG ? (rows + 63) / 64 : GL_MAXWG;       // 64 label rows per workgroup up to the table's size
+    if (a.nwg < 1) a.nwg = 1;
+    hipLaunchKernelGGL(gathered_loss_kernel, dim3(a.nwg), dim3(256), 0, st, a, mode, 0);
+    hipLaunchKernelGGL(gathered_loss_kernel, dim3(1), dim3(64), 0, st, a, mode, 1);
+    if (mode == 1) hipLaunchKernelGGL(gathered_loss_kernel, dim3(a.nwg), dim3(256), 0, st, a, mode, 2);
     return hipGetLastError();
 }
 

@@ -71,7 +71,8 @@ int mc_make_targets(mc_handle *h, const mc_labels *lab, int B, int max_objs, int
 static int ensure_loss_ws(mc_handle *h) {
     if (h->loss_ws) return 0;
     void *q = nullptr;
-    const size_t n = (size_t)2 * mc::focal_partial_floats() + 64;
+    // focal partials (2 x npf), 64 floats of small results (aux, scratch losses), then the gathered losses' fp64 workspace
+    const size_t n = (size_t)2 * mc::focal_partial_floats() + 64 + 2 * mc::gathered_loss_ws_doubles() + 2;
     HIPCHK(h, hipMalloc(&q, n * sizeof(float)));
     h->loss_ws = static_cast<float *>(q);
     return 0;
@@ -88,6 +89,10 @@ static void fill_gather_args(mc::GatherLossArgs &g, const float *const preds[10]
     g.alpha_offset = t->alpha_offset_target; g.depth = t->depth_target; g.c2k = t->center2kpt_offset_target;
     g.kho = t->kpt_heatmap_offset_target; g.mask_c2k = t->mask_center2kpt_offset; g.mask_kho = t->mask_kpt_heatmap_offset;
     g.B = B; g.max_objs = max_objs; g.HW = HW; g.losses = losses; g.aux = aux; g.gscale = gscale;
+}
+static double *gather_ws(mc_handle *h) {       // 8-byte aligned, behind the float part of the loss workspace
+    uintptr_t p = reinterpret_cast<uintptr_t>(h->loss_ws + 2 * mc::focal_partial_floats() + 64);
+    return reinterpret_cast<double *>((p + 7) & ~(uintptr_t)7);
 }
 
 int mc_losses(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_targets *t, int B, int max_objs, int fh,
@@ -107,6 +112,7 @@ int mc_losses(mc_handle *h, const float *const preds[MC_NUM_PREDS], const mc_tar
     HIPCHK(h, mc::launch_focal(preds[1], t->kpt_heatmap_target, (size_t)B * 9 * HW, h->loss_ws + npf, losses + 5, aux + 1, st));
     mc::GatherLossArgs g{};
     fill_gather_args(g, preds, nullptr, t, B, max_objs, (int)HW, losses, aux + 2, nullptr);
+    g.partial = gather_ws(h);
     HIPCHK(h, mc::launch_gathered_losses(g, 0, st));
     return 0;
 }
@@ -140,6 +146,7 @@ static int losses_backward_impl(mc_handle *h, const float *const preds[MC_NUM_PR
     mc::GatherLossArgs g{};
     fill_gather_args(g, preds, dpreds, t, B, max_objs, (int)HW, scratch_losses, aux + 2, grad_losses);
     g.wrt_pred = wrt_pred;
+    g.partial = gather_ws(h);
     HIPCHK(h, mc::launch_gathered_losses(g, 1, st));
     return 0;
 }

@@ -41,7 +41,10 @@ struct GatherLossArgs {
     float *aux;                  // [1] number of valid objects
     const float *gscale;         // [10] upstream gradient of each loss (mode 1)
     int wrt_pred;                // mode 1: 0 = gradient wrt the raw 1x1 outputs, 1 = wrt the prediction maps themselves
+    double *partial;             // workspace of gathered_loss_ws_doubles() doubles (per-workgroup sums, then the totals)
+    int nwg;                     // (set by the launcher)
 };
+size_t gathered_loss_ws_doubles();
 hipError_t launch_gathered_losses(const GatherLossArgs &a, int mode, hipStream_t st);
 
 // ---- batched weight packing / BatchNorm folding (pack_batch.hip)

@@ -21,7 +21,7 @@ for r in csv.DictReader(open(os.path.join(out, "trace", "t_kernel_trace.csv"))):
 tot = sum(v[1] for v in agg.values())
 with open(os.path.join(out, "by_grid.txt"), "w") as f:
     f.write("%-64s %8s %6s %11s %9s %6s\n" % ("kernel", "blocks", "calls", "total_us", "avg_us", "pct"))
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:140]:
         f.write("%-64s %8d %6d %11.1f %9.1f %6.2f\n" % (k[0][:64], k[1], v[0], v[1], v[1] / v[0], 100 * v[1] / tot))
 PY
 rm -rf "$OUT/trace"
