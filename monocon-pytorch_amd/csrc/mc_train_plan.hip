@@ -547,9 +547,10 @@ struct TB {   // train plan builder
         }
         const int nb = chan_reduce_blocks(B, rows);
         float *partial = alloc((size_t)nb * C * 2);
+        double *fold2 = fold_scratch(nb, C);      // (61 440 partial rows at full resolution: 16 workgroups walking them took 87 us)
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
             HIPCHK(hh, launch_chan_reduce(yp, gz, zp, nullptr, B, rows, C, 1, relu, partial, C, st, fa, fb));
-            HIPCHK(hh, launch_bn_bwd_finalize(partial, nb, C, n, C, gamma, mean, rstd, dg, db, coef, st));
+            HIPCHK(hh, launch_bn_bwd_finalize(partial, nb, C, n, C, gamma, mean, rstd, dg, db, coef, st, fold2));
             HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, relu, dyp, gres, gmode, st, fa, fb, nullptr, nullptr,
                                              dymax));
             return 0;
