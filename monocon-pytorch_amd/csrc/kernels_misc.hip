@@ -452,9 +452,12 @@ __device__ __forceinline__ constexpr int row_epi(int r) {
     return (H == 0 || H == 4) ? 1 : ((H == 7 && r == 0) ? 2 : 0);
 }
 
-template <int H>
+// The 64 channels of a tile pass through LDS in two halves of 32 (`stage(half)` writes [64 px][33] and synchronises): half the
+// LDS per wave, twice the workgroups per CU -- with one tile per wave and no loads in flight during the dot products, the
+// memory pipe is kept busy by the OTHER waves (round 5: 3 workgroups per CU by LDS, 3.7 TB/s).  Same fma order as before.
+template <int H, class Stage>
 __device__ __forceinline__ void head_rows_compute(const HeadApplyArgs &a, const float *hl, int lane, int b, int hw,
-                                                  bool ok) {
+                                                  bool ok, Stage stage) {
     constexpr int NR = HeadMap<H>::NR, RB = HeadMap<H>::RB;
     float acc[NR];
 #pragma unroll
@@ -463,11 +466,15 @@ __device__ __forceinline__ void head_rows_compute(const HeadApplyArgs &a, const 
     // address space so the wave-uniform loads go down the scalar path (s_load) instead of VMEM.
     typedef const float __attribute__((address_space(4))) cfloat;
     cfloat *w = (cfloat *)(uintptr_t)(a.w + RB);
-#pragma unroll 4
-    for (int c = 0; c < HEAD_CH; ++c) {
-        const float v = hl[lane * 65 + c];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] = fmaf(v, w[c * NUM_OUT_ROWS + r], acc[r]);
+    for (int half = 0; half < 2; ++half) {
+        stage(half);
+#pragma unroll 4
+        for (int c = 0; c < HEAD_CH / 2; ++c) {
+            const float v = hl[lane * 33 + c];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[r] = fmaf(v, w[(half * (HEAD_CH / 2) + c) * NUM_OUT_ROWS + r], acc[r]);
+        }
     }
     if (!ok) return;
 #pragma unroll
@@ -487,7 +494,7 @@ __device__ __forceinline__ void head_rows_compute(const HeadApplyArgs &a, const 
 }
 
 __global__ __launch_bounds__(192) void head_apply_kernel(const HeadApplyArgs a) {
-    __shared__ float hlds[3][64 * 65];
+    __shared__ float hlds[3][64 * 33];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = blockIdx.y * 3 + wave;
@@ -510,25 +517,36 @@ __global__ __launch_bounds__(192) void head_apply_kernel(const HeadApplyArgs a) 
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int px = it * 4 + (lane >> 4);
-        f32x4 zv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hl[px * 65 + c4 * 4 + j] = zv[j] = fmaxf(fmaf(v[it][j], sc[j], sh[j]), 0.f);
+        for (int j = 0; j < 4; ++j) v[it][j] = fmaxf(fmaf(v[it][j], sc[j], sh[j]), 0.f);
         if (a.z_out && hw0 + px < a.HW)
-            *reinterpret_cast<f32x4 *>(a.z_out + ((size_t)b * a.HW + hw0 + px) * (NUM_HEADS * HEAD_CH) + h * HEAD_CH + c4 * 4) = zv;
+            *reinterpret_cast<f32x4 *>(a.z_out + ((size_t)b * a.HW + hw0 + px) * (NUM_HEADS * HEAD_CH) + h * HEAD_CH + c4 * 4) = v[it];
     }
-    __syncthreads();
+    // channel half `half` of the normalised tile -> LDS: the lanes holding it are c4 in [8 * half, 8 * half + 8)
+    auto stage = [&](int half) {
+        if (half) __syncthreads();             // the first half is no longer read
+        if ((c4 >> 3) == half) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int px = it * 4 + (lane >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hl[px * 33 + (c4 & 7) * 4 + j] = v[it][j];
+            }
+        }
+        __syncthreads();
+    };
     const int hw = hw0 + lane;
     const bool ok = hw < a.HW;
     switch (h) {
-        case 0: head_rows_compute<0>(a, hl, lane, b, hw, ok); break;
-        case 1: head_rows_compute<1>(a, hl, lane, b, hw, ok); break;
-        case 2: head_rows_compute<2>(a, hl, lane, b, hw, ok); break;
-        case 3: head_rows_compute<3>(a, hl, lane, b, hw, ok); break;
-        case 4: head_rows_compute<4>(a, hl, lane, b, hw, ok); break;
-        case 5: head_rows_compute<5>(a, hl, lane, b, hw, ok); break;
-        case 6: head_rows_compute<6>(a, hl, lane, b, hw, ok); break;
-        case 7: head_rows_compute<7>(a, hl, lane, b, hw, ok); break;
-        default: head_rows_compute<8>(a, hl, lane, b, hw, ok); break;
+        case 0: head_rows_compute<0>(a, hl, lane, b, hw, ok, stage); break;
+        case 1: head_rows_compute<1>(a, hl, lane, b, hw, ok, stage); break;
+        case 2: head_rows_compute<2>(a, hl, lane, b, hw, ok, stage); break;
+        case 3: head_rows_compute<3>(a, hl, lane, b, hw, ok, stage); break;
+        case 4: head_rows_compute<4>(a, hl, lane, b, hw, ok, stage); break;
+        case 5: head_rows_compute<5>(a, hl, lane, b, hw, ok, stage); break;
+        case 6: head_rows_compute<6>(a, hl, lane, b, hw, ok, stage); break;
+        case 7: head_rows_compute<7>(a, hl, lane, b, hw, ok, stage); break;
+        default: head_rows_compute<8>(a, hl, lane, b, hw, ok, stage); break;
     }
 }
 
