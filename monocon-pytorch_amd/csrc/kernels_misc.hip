@@ -207,15 +207,17 @@ hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *o
 
 // depthwise ConvTranspose2d(k=4, s=2, p=1): out[oy,ox] = sum over the <=2x2 inputs with
 // oy = 2*iy - 1 + ky (reference model/backbone/dla_neck.py:58-65)
-__global__ void deconv4_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4,
-                               const f32x4 *__restrict__ wpk, f32x4 *__restrict__ out, unsigned *__restrict__ amax) {
-    const int Ho = 2 * H, Wo = 2 * W;
-    const size_t total = (size_t)B * Ho * Wo * C4;
+// grid = (ceil(Wo * C4 / 256), ceil(Ho / 4), B): the rows and the image come from the block index, the column / channel quad from one
+// 32-bit division (round 5: as a flat grid-stride loop every output paid four 64-bit divisions -- 3.3 TB/s)
+__global__ __launch_bounds__(256) void deconv4_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4,
+                                                      const f32x4 *__restrict__ wpk, f32x4 *__restrict__ out,
+                                                      unsigned *__restrict__ amax) {
+    const int Wo = 2 * W;
     float vmax = 0.f;          // max |out| of this thread (amax != null, see ConvArgs::amax_in)
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int c = e % C4;
-        const size_t p = e / C4;
-        const int ox = p % Wo, oy = (p / Wo) % Ho, b = p / ((size_t)Wo * Ho);
+    const unsigned ex = blockIdx.x * 256u + threadIdx.x;
+    const int b = blockIdx.z;
+    const int c = (int)(ex % (unsigned)C4), ox = (int)(ex / (unsigned)C4);
+    for (int oy = blockIdx.y * 4; oy < min(2 * H, (int)blockIdx.y * 4 + 4) && ex < (unsigned)(Wo * C4); ++oy) {      // four output rows per block
         const int iy1 = (oy + 1) >> 1, ky1 = oy + 1 - 2 * iy1;   // ky1 in {0,1}
         const int ix1 = (ox + 1) >> 1, kx1 = ox + 1 - 2 * ix1;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -233,7 +235,7 @@ __global__ void deconv4_kernel(const f32x4 *__restrict__ in, int B, int H, int W
                 for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], w[j], acc[j]);
             }
         }
-        out[e] = acc;
+        out[(((size_t)b * (2 * H) + oy) * Wo) * C4 + ex] = acc;
 #pragma unroll
         for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(acc[j]));
     }
@@ -241,8 +243,8 @@ __global__ void deconv4_kernel(const f32x4 *__restrict__ in, int B, int H, int W
 }
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out, hipStream_t st,
                           unsigned *amax) {
-    const size_t total = (size_t)B * 4 * H * W * (C / 4);
-    hipLaunchKernelGGL(deconv4_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st,
+    if (B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(deconv4_kernel, dim3((unsigned)((2 * W * (C / 4) + 255) / 256), (unsigned)((2 * H + 3) / 4), (unsigned)B), dim3(256), 0, st,
                        reinterpret_cast<const f32x4 *>(in), B, H, W, C / 4, reinterpret_cast<const f32x4 *>(wpk),
                        reinterpret_cast<f32x4 *>(out), amax);
     return hipGetLastError();
