@@ -295,6 +295,155 @@ hipError_t launch_conv_thin(const ConvArgs &a, hipStream_t st) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ stride-2 data gradient
+// dX of the 16 -> 32 stride-2 3x3 layer (DLA level1, model/backbone/dla.py:280-298 under autograd), mode 3:
+//   dX[2i + py][2j + px][c] = sum over the (1 + py)(1 + px) taps of the parity class of dY[i + dr][j + ds][0..31] . W[.][c][r][s],
+//   r = 1 (py = 0) or 2 - 2 dr (py = 1), s likewise.
+// The plan used to run the four parity classes as four launches of the generic tiled kernel (K = 32 per tap, 16 of its 32
+// output columns padding, every launch writing every second pixel of the 1 GB map): 0.51 + 0.25 + 0.22 + 0.20 ms per step
+// (rocprofv3, round 5) for 0.5 GB read and 1 GB written.  Here ONE pass: a workgroup stages a 5 x 33 pixel halo tile of dY
+// (split once into its fp16 pieces, four 8-channel planes per piece), a wave owns one dY row = two output rows, a
+// v_mfma_f32_16x16x32_f16 has M = 16 output pixels of one parity class, N = the 16 channels, K = the 32 channels of one tap;
+// the filter (9 taps x 2 pieces) lives in registers.  Output pixels of both column parities are written by the same wave back to
+// back: whole 128-byte lines.
+struct DgradS2Args {
+    const float *dy;            // (B, H, W, 32)
+    const float *w;             // master weight OIHW (32, CinTotal, 3, 3); this launch: input channels [c_off, c_off + 16)
+    float *out;                 // (B, 2H, 2W, 16)
+    int B, H, W, CinTotal, c_off, accumulate;
+    const unsigned *amax_dy, *amax_w;
+};
+namespace {
+constexpr int DR = 4, DW = 32;                   // dY rows / pixels per tile strip (8 x 64 outputs)
+constexpr int DIR_ = DR + 1, DIP = DW + 1;       // halo tile
+constexpr int DPLANE = DIR_ * DIP * 16;          // bytes of one [row][pixel] plane of 8 channels
+constexpr int DITEMS = DIR_ * DIP * 8;           // staged float4 items per strip (8 channel quads per pixel)
+constexpr int DNI = (DITEMS + 255) / 256;
+}  // namespace
+__global__ __launch_bounds__(256, 2) void dgrad_s2_thin_kernel(const DgradS2Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[8 * DPLANE];       // [piece][channel octet][row][pixel] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int ex = f16_scale_exp(amax_read(a.amax_dy)), ew = f16_scale_exp(*a.amax_w);
+    const float x_scale = exp2i(ex), w_scale = exp2i(ew), omul = exp2i(-ex) * exp2i(-ew);
+    // filter: bw[tap][piece] = W[n = 8 kq .. 8 kq + 7][c = li][r][s] * 2^ew, split (B operand: K = n, N = c)
+    f16x8 bw[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        f16x8 h8, l8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float ws = a.w[((size_t)(8 * kq + q) * a.CinTotal + a.c_off + li) * 9 + tap] * w_scale;
+            const _Float16 hh = (_Float16)ws;
+            h8[q] = hh;
+            l8[q] = (_Float16)(ws - (float)hh);
+        }
+        bw[tap][0] = h8; bw[tap][1] = l8;
+    }
+    int s_off[DNI], s_dst[DNI];          // staging plan: item = (row, pixel, channel quad), quad fastest; s_dst < 0: none
+#pragma unroll
+    for (int i = 0; i < DNI; ++i) {
+        const int e = tid + 256 * i;
+        const int c4 = e & 7, px = (e >> 3) % DIP, row = (e >> 3) / DIP;
+        s_off[i] = ((row * a.W + px) * 32 + c4 * 4) * 4;
+        s_dst[i] = e < DITEMS ? (c4 >> 1) * DPLANE + (row * DIP + px) * 16 + (c4 & 1) * 8 : -1;
+    }
+    const int tiles_per_img = (a.H + DR - 1) / DR, nstrips = (a.W + DW - 1) / DW;
+    const int Ho = 2 * a.H, Wo = 2 * a.W;
+    for (int tile = xcd_order(blockIdx.x, gridDim.x); tile < a.B * tiles_per_img; tile += gridDim.x) {
+        const int img = tile / tiles_per_img, i0 = (tile - img * tiles_per_img) * DR;
+        // rows below the image fall outside the descriptor (-> zeros); columns are tested
+        const __amdgpu_buffer_rsrc_t r_x = make_rsrc(a.dy + (size_t)img * a.H * a.W * 32, (unsigned)(a.H * a.W * 32) * 4u);
+        const int i = i0 + wave;                       // this wave's dY row
+        __amdgpu_buffer_rsrc_t r_out[2];
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const bool ok = i < a.H;
+            r_out[py] = make_rsrc(a.out + ((size_t)img * Ho + (ok ? 2 * i + py : 0)) * Wo * 16, ok ? (unsigned)(Wo * 16) * 4u : 0u);
+        }
+        f32x4 pre[DNI];
+        auto fetch = [&](int strip) {
+            const int j0 = strip * DW, so = (i0 * a.W + j0) * 32 * 4;
+#pragma unroll
+            for (int k = 0; k < DNI; ++k) {
+                const int px = ((s_dst[k] % DPLANE) >> 4) % DIP;
+                const bool ok = s_dst[k] >= 0 && j0 + px < a.W;
+                pre[k] = buf_load4(r_x, ok ? s_off[k] + so : BUF_OOB, 0);
+            }
+        };
+        fetch(0);
+        for (int strip = 0; strip < nstrips; ++strip) {
+            __syncthreads();            // the fragment reads of the previous strip are done
+#pragma unroll
+            for (int k = 0; k < DNI; ++k) {
+                if (256 * (k + 1) > DITEMS && s_dst[k] < 0) continue;
+                f16x4 h4, l4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xs = pre[k][q] * x_scale;
+                    const _Float16 hh = (_Float16)xs;
+                    h4[q] = hh;
+                    l4[q] = (_Float16)(xs - (float)hh);
+                }
+                *reinterpret_cast<f16x4 *>(lds + s_dst[k]) = h4;
+                *reinterpret_cast<f16x4 *>(lds + 4 * DPLANE + s_dst[k]) = l4;
+            }
+            __syncthreads();
+            if (strip + 1 < nstrips) fetch(strip + 1);
+            const int j0 = strip * DW;
+#pragma unroll
+            for (int mt = 0; mt < DW / 16; ++mt) {
+                if (j0 + mt * 16 >= a.W) break;
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        f32x4v acc = {0.f, 0.f, 0.f, 0.f}, accm = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int dr = 0; dr <= py; ++dr) {
+#pragma unroll
+                            for (int ds = 0; ds <= px; ++ds) {
+                                const int r = py ? 2 - 2 * dr : 1, sx = px ? 2 - 2 * ds : 1, tap = r * 3 + sx;
+                                const unsigned char *p = lds + kq * DPLANE + ((wave + dr) * DIP + mt * 16 + li + ds) * 16;
+                                const f16x8 ah = *reinterpret_cast<const f16x8 *>(p), al = *reinterpret_cast<const f16x8 *>(p + 4 * DPLANE);
+                                accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bw[tap][0], accm, 0, 0, 0);
+                                accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bw[tap][1], accm, 0, 0, 0);
+                                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bw[tap][0], acc, 0, 0, 0);
+                            }
+                        }
+                        // D: column (c) = lane & 15, row (pixel m) = 4 * (lane >> 4) + e -> output pixel 2 (j0 + 16 mt + m) + px
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = j0 + mt * 16 + 4 * kq + e;
+                            const int voff = j < a.W ? ((2 * j + px) * 16 + li) * 4 : BUF_OOB;
+                            float v = (accm[e] + acc[e]) * omul;
+                            if (a.accumulate) v += buf_load1(r_out[py], voff, 0);
+                            buf_store1(v, r_out[py], voff, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+bool dgrad_s2_thin_ok(int prec, int ks, int stride, int dyC, int srcC, int CinTotal, int c_off, const unsigned *amax_dy,
+                      const unsigned *amax_w, int H, int W) {
+    return prec == 3 && ks == 3 && stride == 2 && dyC == 32 && srcC == 16 && c_off >= 0 && c_off + 16 <= CinTotal && amax_dy && amax_w &&
+           (size_t)H * W * 32 * 4 < (1ull << 31) && (size_t)4 * W * 16 * 4 < (1ull << 31);
+}
+hipError_t launch_dgrad_s2_thin(const float *dy, int B, int H, int W, const float *w_master, int CinTotal, int c_off, float *out,
+                                int accumulate, const unsigned *amax_dy, const unsigned *amax_w, hipStream_t st) {
+    DgradS2Args a;
+    a.dy = dy; a.w = w_master; a.out = out; a.B = B; a.H = H; a.W = W; a.CinTotal = CinTotal; a.c_off = c_off;
+    a.accumulate = accumulate; a.amax_dy = amax_dy; a.amax_w = amax_w;
+    const int tiles = B * ((H + DR - 1) / DR);
+    // (mc_profile_train: a data gradient -- 9 tap-MACs per output quad, dY read once, the map written once (+ read when accumulating))
+    prof_last = {1, 2.0 * B * H * W * 32.0 * 16.0 * 9.0, 4.0 * ((double)B * H * W * 32 + (double)B * 4 * H * W * 16 * (accumulate ? 2 : 1))};
+    hipLaunchKernelGGL(dgrad_s2_thin_kernel, dim3(tiles < 4096 ? tiles : 4096), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[n][c][r][s] = sum over pixels of dY[pixel][n] * X[pixel + (r - 1, s - 1)][c] of the same 16 -> 16 layer, mode 3, on
 // v_mfma_f32_16x16x32_f16 (K = 32 consecutive pixels of a row).  Replaces wgrad_small_kernel<1, 1> (wgrad_mfma.hip: fp32

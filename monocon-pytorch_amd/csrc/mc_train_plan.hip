@@ -401,6 +401,22 @@ struct TB {   // train plan builder
             // four output-parity classes, each a small stride-1 window conv over dY that scatters to every
             // second pixel of g_src (no zero-dilated copy of dY, 9 instead of 36 tap-MACs per output quad)
             if (2 * dy.H != sn.t.H || 2 * dy.W != sn.t.W) { ts->ok = false; h->err = "train plan: stride-2 dgrad shape mismatch"; }
+            // the 32 -> 16 layer at full resolution (level1): all four classes in one pass of its own kernel (conv_thin.hip;
+            // MONOCON_HIP_DGRAD_S2_THIN=0: the four launches below)
+            const bool s2_thin = [] { const char *e = std::getenv("MONOCON_HIP_DGRAD_S2_THIN"); return !e || std::atoi(e) != 0; }();
+            if (s2_thin && ts->ok && dgrad_s2_thin_ok(h->prec, ks, stride, dy.C, sn.t.C, CinTotal, c_off, dy.amax, w_slot(w_master), dy.H, dy.W)) {
+                const float *dyp = dy.p;
+                float *gp = sn.g;
+                const int B = dy.B, Hd = dy.H, Wd = dy.W, acc = sn.ginit ? 1 : 0;
+                const unsigned *dmax = dy.amax, *wmax = w_slot(w_master);
+                ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
+                    HIPCHK(hh, launch_dgrad_s2_thin(dyp, B, Hd, Wd, w_master, CinTotal, c_off, gp, acc, dmax, wmax, st));
+                    return 0;
+                });
+                sn.ginit = true;
+                sn.last_conv = nullptr;
+                return;
+            }
             for (int cls = 0; cls < 4; ++cls) {
                 const int py = cls >> 1, px = cls & 1;
                 float *panel;

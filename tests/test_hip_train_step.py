@@ -310,6 +310,35 @@ def test_head_backward_without_the_stored_gradient_is_bit_identical(golden_sd, p
     assert n_bias >= 9            # the nine 3x3 convs (dir_cls / dir_reg: their 1x1 convs are called ".0" too and are bit-identical)
 
 
+def test_fused_stride2_thin_data_gradient_matches_the_four_class_launches(golden_sd, monkeypatch):
+    """level1's data gradient (32 -> 16 channels, stride 2, full resolution) as ONE pass of dgrad_s2_thin_kernel (the default)
+    against the four output-parity launches of the tiled kernel (MONOCON_HIP_DGRAD_S2_THIN=0): the same f16x2 products
+    accumulated in a different association -- only the gradients below level1 may differ, and only at rounding level
+    (model/backbone/dla.py:280-298 under autograd)"""
+    from model import MonoConDetector
+    batch = to_cuda(synth.make_batch(GOLDEN_SEED + 12, 3, 96, 224))        # 224: a half-filled last strip
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MONOCON_HIP_DGRAD_S2_THIN", flag)             # read when the train plan is built
+        m = MonoConDetector(34, pretrained_backbone=False)
+        m.load_state_dict(golden_sd, strict=True)
+        m = m.cuda().train().set_precision("f16x2")
+        _, loss = m(batch)
+        sum(loss.values()).backward()
+        torch.cuda.synchronize()
+        res.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    four, one = res
+    below = 0
+    for n in four:
+        if n.startswith("backbone.base_layer") or n.startswith("backbone.level0"):
+            below += 1
+            assert not torch.equal(four[n], one[n]) or n.endswith(".bias")      # (it IS the other kernel)
+            assert rel_err(one[n].cpu(), four[n].cpu()) < 1e-6, n
+        else:
+            assert torch.equal(four[n], one[n]), n
+    assert below == 6
+
+
 def test_full_size_train_step_is_deterministic(golden_sd):
     """size-independent property at the full 384x1280 resolution: the same state and batch give bit-identical losses,
     gradients and BN buffers twice in a row (fixed accumulation orders everywhere, two streams included)."""
