@@ -763,10 +763,10 @@ hipError_t launch_conv_wres(const ConvArgs &a, int ks, int stride, hipStream_t s
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st);
 bool conv_thin_ok(const ConvArgs &a, int ks, int stride);            // conv_thin.hip
 hipError_t launch_conv_thin(const ConvArgs &a, hipStream_t st);
-// the four parity classes of the 32 -> 16 stride-2 data gradient in one pass (conv_thin.hip)
+// the four parity classes of a thin stride-2 data gradient (dY 32 -> 16 or 64 -> 32 channels) in one pass (conv_thin.hip)
 bool dgrad_s2_thin_ok(int prec, int ks, int stride, int dyC, int srcC, int CinTotal, int c_off, const unsigned *amax_dy,
                       const unsigned *amax_w, int H, int W);
-hipError_t launch_dgrad_s2_thin(const float *dy, int B, int H, int W, const float *w_master, int CinTotal, int c_off, float *out,
+hipError_t launch_dgrad_s2_thin(const float *dy, int B, int H, int W, int dyC, const float *w_master, int CinTotal, int c_off, float *out,
                                 int accumulate, const unsigned *amax_dy, const unsigned *amax_w, hipStream_t st);
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);

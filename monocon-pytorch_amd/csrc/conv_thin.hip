@@ -307,9 +307,9 @@ hipError_t launch_conv_thin(const ConvArgs &a, hipStream_t st) {
 // the filter (9 taps x 2 pieces) lives in registers.  Output pixels of both column parities are written by the same wave back to
 // back: whole 128-byte lines.
 struct DgradS2Args {
-    const float *dy;            // (B, H, W, 32)
-    const float *w;             // master weight OIHW (32, CinTotal, 3, 3); this launch: input channels [c_off, c_off + 16)
-    float *out;                 // (B, 2H, 2W, 16)
+    const float *dy;            // (B, H, W, 32 * KS)
+    const float *w;             // master weight OIHW (32 * KS, CinTotal, 3, 3); this launch: input channels [c_off, c_off + 16 * NT)
+    float *out;                 // (B, 2H, 2W, 16 * NT)
     int B, H, W, CinTotal, c_off, accumulate;
     const unsigned *amax_dy, *amax_w;
 };
@@ -317,36 +317,44 @@ namespace {
 constexpr int DR = 4, DW = 32;                   // dY rows / pixels per tile strip (8 x 64 outputs)
 constexpr int DIR_ = DR + 1, DIP = DW + 1;       // halo tile
 constexpr int DPLANE = DIR_ * DIP * 16;          // bytes of one [row][pixel] plane of 8 channels
-constexpr int DITEMS = DIR_ * DIP * 8;           // staged float4 items per strip (8 channel quads per pixel)
-constexpr int DNI = (DITEMS + 255) / 256;
 }  // namespace
-__global__ __launch_bounds__(256, 2) void dgrad_s2_thin_kernel(const DgradS2Args a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[8 * DPLANE];       // [piece][channel octet][row][pixel] x 16 B
+// KS = K-steps per tap (dY channels / 32), NT = 16-channel groups of dX.  (1, 1): level1, a wave = one dY row -- the only shape
+// the plan sends here.  (2, 2) -- level2's first conv, dY 64 ch at 96x320 -> dX 32 ch at 192x640, a wave = one channel group of
+// two dY rows -- was built and measured (round 5): its filter (9 taps x 2 steps x 2 pieces = 144 registers) leaves one
+// workgroup per CU, and the step did not move (one-session A/B 49.99 vs 49.66 ms with level1 alone); not instantiated.
+template <int KS, int NT>
+__global__ __launch_bounds__(256, KS == 1 ? 2 : 1) void dgrad_s2_thin_kernel(const DgradS2Args a) {
+    constexpr int CY = 32 * KS, CX = 16 * NT, NOCT = 4 * KS;
+    constexpr int DITEMS = DIR_ * DIP * (CY / 4), DNI = (DITEMS + 255) / 256;    // staged float4 items per strip
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NOCT * DPLANE];       // [piece][channel octet][row][pixel] x 16 B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
+    const int nt = wave % NT, row0 = (wave / NT) * NT;       // this wave's channel group and first dY row of the tile
     const int ex = f16_scale_exp(amax_read(a.amax_dy)), ew = f16_scale_exp(*a.amax_w);
     const float x_scale = exp2i(ex), w_scale = exp2i(ew), omul = exp2i(-ex) * exp2i(-ew);
-    // filter: bw[tap][piece] = W[n = 8 kq .. 8 kq + 7][c = li][r][s] * 2^ew, split (B operand: K = n, N = c)
-    f16x8 bw[9][2];
+    // filter: bw[tap][step][piece] = W[n = 32 step + 8 kq .. + 7][c = 16 nt + li][r][s] * 2^ew, split (B operand: K = n, N = c)
+    f16x8 bw[9][KS][2];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        f16x8 h8, l8;
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float ws = a.w[((size_t)(8 * kq + q) * a.CinTotal + a.c_off + li) * 9 + tap] * w_scale;
-            const _Float16 hh = (_Float16)ws;
-            h8[q] = hh;
-            l8[q] = (_Float16)(ws - (float)hh);
+        for (int ks = 0; ks < KS; ++ks) {
+            f16x8 h8, l8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float ws = a.w[((size_t)(32 * ks + 8 * kq + q) * a.CinTotal + a.c_off + 16 * nt + li) * 9 + tap] * w_scale;
+                const _Float16 hh = (_Float16)ws;
+                h8[q] = hh;
+                l8[q] = (_Float16)(ws - (float)hh);
+            }
+            bw[tap][ks][0] = h8; bw[tap][ks][1] = l8;
         }
-        bw[tap][0] = h8; bw[tap][1] = l8;
-    }
     int s_off[DNI], s_dst[DNI];          // staging plan: item = (row, pixel, channel quad), quad fastest; s_dst < 0: none
 #pragma unroll
     for (int i = 0; i < DNI; ++i) {
         const int e = tid + 256 * i;
-        const int c4 = e & 7, px = (e >> 3) % DIP, row = (e >> 3) / DIP;
-        s_off[i] = ((row * a.W + px) * 32 + c4 * 4) * 4;
+        const int c4 = e % (CY / 4), px = (e / (CY / 4)) % DIP, row = (e / (CY / 4)) / DIP;
+        s_off[i] = ((row * a.W + px) * CY + c4 * 4) * 4;
         s_dst[i] = e < DITEMS ? (c4 >> 1) * DPLANE + (row * DIP + px) * 16 + (c4 & 1) * 8 : -1;
     }
     const int tiles_per_img = (a.H + DR - 1) / DR, nstrips = (a.W + DW - 1) / DW;
@@ -354,17 +362,19 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_thin_kernel(const DgradS2Args
     for (int tile = xcd_order(blockIdx.x, gridDim.x); tile < a.B * tiles_per_img; tile += gridDim.x) {
         const int img = tile / tiles_per_img, i0 = (tile - img * tiles_per_img) * DR;
         // rows below the image fall outside the descriptor (-> zeros); columns are tested
-        const __amdgpu_buffer_rsrc_t r_x = make_rsrc(a.dy + (size_t)img * a.H * a.W * 32, (unsigned)(a.H * a.W * 32) * 4u);
-        const int i = i0 + wave;                       // this wave's dY row
-        __amdgpu_buffer_rsrc_t r_out[2];
+        const __amdgpu_buffer_rsrc_t r_x = make_rsrc(a.dy + (size_t)img * a.H * a.W * CY, (unsigned)(a.H * a.W * CY) * 4u);
+        __amdgpu_buffer_rsrc_t r_out[NT][2];
 #pragma unroll
-        for (int py = 0; py < 2; ++py) {
-            const bool ok = i < a.H;
-            r_out[py] = make_rsrc(a.out + ((size_t)img * Ho + (ok ? 2 * i + py : 0)) * Wo * 16, ok ? (unsigned)(Wo * 16) * 4u : 0u);
-        }
+        for (int rr = 0; rr < NT; ++rr)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int i = i0 + row0 + rr;
+                const bool ok = i < a.H;
+                r_out[rr][py] = make_rsrc(a.out + ((size_t)img * Ho + (ok ? 2 * i + py : 0)) * Wo * CX, ok ? (unsigned)(Wo * CX) * 4u : 0u);
+            }
         f32x4 pre[DNI];
         auto fetch = [&](int strip) {
-            const int j0 = strip * DW, so = (i0 * a.W + j0) * 32 * 4;
+            const int j0 = strip * DW, so = (i0 * a.W + j0) * CY * 4;
 #pragma unroll
             for (int k = 0; k < DNI; ++k) {
                 const int px = ((s_dst[k] % DPLANE) >> 4) % DIP;
@@ -387,39 +397,45 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_thin_kernel(const DgradS2Args
                     l4[q] = (_Float16)(xs - (float)hh);
                 }
                 *reinterpret_cast<f16x4 *>(lds + s_dst[k]) = h4;
-                *reinterpret_cast<f16x4 *>(lds + 4 * DPLANE + s_dst[k]) = l4;
+                *reinterpret_cast<f16x4 *>(lds + NOCT * DPLANE + s_dst[k]) = l4;
             }
             __syncthreads();
             if (strip + 1 < nstrips) fetch(strip + 1);
             const int j0 = strip * DW;
 #pragma unroll
-            for (int mt = 0; mt < DW / 16; ++mt) {
-                if (j0 + mt * 16 >= a.W) break;
+            for (int rr = 0; rr < NT; ++rr) {
 #pragma unroll
-                for (int py = 0; py < 2; ++py) {
+                for (int mt = 0; mt < DW / 16; ++mt) {
+                    if (j0 + mt * 16 >= a.W) break;
 #pragma unroll
-                    for (int px = 0; px < 2; ++px) {
-                        f32x4v acc = {0.f, 0.f, 0.f, 0.f}, accm = {0.f, 0.f, 0.f, 0.f};
+                    for (int py = 0; py < 2; ++py) {
 #pragma unroll
-                        for (int dr = 0; dr <= py; ++dr) {
+                        for (int px = 0; px < 2; ++px) {
+                            f32x4v acc = {0.f, 0.f, 0.f, 0.f}, accm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int ds = 0; ds <= px; ++ds) {
-                                const int r = py ? 2 - 2 * dr : 1, sx = px ? 2 - 2 * ds : 1, tap = r * 3 + sx;
-                                const unsigned char *p = lds + kq * DPLANE + ((wave + dr) * DIP + mt * 16 + li + ds) * 16;
-                                const f16x8 ah = *reinterpret_cast<const f16x8 *>(p), al = *reinterpret_cast<const f16x8 *>(p + 4 * DPLANE);
-                                accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bw[tap][0], accm, 0, 0, 0);
-                                accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bw[tap][1], accm, 0, 0, 0);
-                                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bw[tap][0], acc, 0, 0, 0);
+                            for (int dr = 0; dr <= py; ++dr) {
+#pragma unroll
+                                for (int ds = 0; ds <= px; ++ds) {
+                                    const int r = py ? 2 - 2 * dr : 1, sx = px ? 2 - 2 * ds : 1, tap = r * 3 + sx;
+#pragma unroll
+                                    for (int ks = 0; ks < KS; ++ks) {
+                                        const unsigned char *p = lds + (ks * 4 + kq) * DPLANE + ((row0 + rr + dr) * DIP + mt * 16 + li + ds) * 16;
+                                        const f16x8 ah = *reinterpret_cast<const f16x8 *>(p), al = *reinterpret_cast<const f16x8 *>(p + NOCT * DPLANE);
+                                        accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bw[tap][ks][0], accm, 0, 0, 0);
+                                        accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bw[tap][ks][1], accm, 0, 0, 0);
+                                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bw[tap][ks][0], acc, 0, 0, 0);
+                                    }
+                                }
                             }
-                        }
-                        // D: column (c) = lane & 15, row (pixel m) = 4 * (lane >> 4) + e -> output pixel 2 (j0 + 16 mt + m) + px
+                            // D: column (c) = lane & 15, row (pixel m) = 4 * (lane >> 4) + e -> output pixel 2 (j0 + 16 mt + m) + px
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int j = j0 + mt * 16 + 4 * kq + e;
-                            const int voff = j < a.W ? ((2 * j + px) * 16 + li) * 4 : BUF_OOB;
-                            float v = (accm[e] + acc[e]) * omul;
-                            if (a.accumulate) v += buf_load1(r_out[py], voff, 0);
-                            buf_store1(v, r_out[py], voff, 0);
+                            for (int e = 0; e < 4; ++e) {
+                                const int j = j0 + mt * 16 + 4 * kq + e;
+                                const int voff = j < a.W ? ((2 * j + px) * CX + 16 * nt + li) * 4 : BUF_OOB;
+                                float v = (accm[e] + acc[e]) * omul;
+                                if (a.accumulate) v += buf_load1(r_out[rr][py], voff, 0);
+                                buf_store1(v, r_out[rr][py], voff, 0);
+                            }
                         }
                     }
                 }
@@ -429,18 +445,21 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_thin_kernel(const DgradS2Args
 }
 bool dgrad_s2_thin_ok(int prec, int ks, int stride, int dyC, int srcC, int CinTotal, int c_off, const unsigned *amax_dy,
                       const unsigned *amax_w, int H, int W) {
-    return prec == 3 && ks == 3 && stride == 2 && dyC == 32 && srcC == 16 && c_off >= 0 && c_off + 16 <= CinTotal && amax_dy && amax_w &&
-           (size_t)H * W * 32 * 4 < (1ull << 31) && (size_t)4 * W * 16 * 4 < (1ull << 31);
+    const bool shape = dyC == 32 && srcC == 16;
+    return prec == 3 && ks == 3 && stride == 2 && shape && c_off >= 0 && c_off + srcC <= CinTotal && amax_dy && amax_w &&
+           (size_t)H * W * dyC * 4 < (1ull << 31) && (size_t)4 * W * srcC * 4 < (1ull << 31);
 }
-hipError_t launch_dgrad_s2_thin(const float *dy, int B, int H, int W, const float *w_master, int CinTotal, int c_off, float *out,
+hipError_t launch_dgrad_s2_thin(const float *dy, int B, int H, int W, int dyC, const float *w_master, int CinTotal, int c_off, float *out,
                                 int accumulate, const unsigned *amax_dy, const unsigned *amax_w, hipStream_t st) {
     DgradS2Args a;
     a.dy = dy; a.w = w_master; a.out = out; a.B = B; a.H = H; a.W = W; a.CinTotal = CinTotal; a.c_off = c_off;
     a.accumulate = accumulate; a.amax_dy = amax_dy; a.amax_w = amax_w;
     const int tiles = B * ((H + DR - 1) / DR);
+    const int srcC = dyC / 2;
     // (mc_profile_train: a data gradient -- 9 tap-MACs per output quad, dY read once, the map written once (+ read when accumulating))
-    prof_last = {1, 2.0 * B * H * W * 32.0 * 16.0 * 9.0, 4.0 * ((double)B * H * W * 32 + (double)B * 4 * H * W * 16 * (accumulate ? 2 : 1))};
-    hipLaunchKernelGGL(dgrad_s2_thin_kernel, dim3(tiles < 4096 ? tiles : 4096), dim3(256), 0, st, a);
+    prof_last = {1, 2.0 * B * H * W * (double)dyC * srcC * 9.0, 4.0 * ((double)B * H * W * dyC + (double)B * 4 * H * W * srcC * (accumulate ? 2 : 1))};
+    if (dyC != 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((dgrad_s2_thin_kernel<1, 1>), dim3(tiles < 4096 ? tiles : 4096), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

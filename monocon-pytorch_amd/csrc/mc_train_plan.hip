@@ -407,10 +407,10 @@ struct TB {   // train plan builder
             if (s2_thin && ts->ok && dgrad_s2_thin_ok(h->prec, ks, stride, dy.C, sn.t.C, CinTotal, c_off, dy.amax, w_slot(w_master), dy.H, dy.W)) {
                 const float *dyp = dy.p;
                 float *gp = sn.g;
-                const int B = dy.B, Hd = dy.H, Wd = dy.W, acc = sn.ginit ? 1 : 0;
+                const int B = dy.B, Hd = dy.H, Wd = dy.W, Cd = dy.C, acc = sn.ginit ? 1 : 0;
                 const unsigned *dmax = dy.amax, *wmax = w_slot(w_master);
                 ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                    HIPCHK(hh, launch_dgrad_s2_thin(dyp, B, Hd, Wd, w_master, CinTotal, c_off, gp, acc, dmax, wmax, st));
+                    HIPCHK(hh, launch_dgrad_s2_thin(dyp, B, Hd, Wd, Cd, w_master, CinTotal, c_off, gp, acc, dmax, wmax, st));
                     return 0;
                 });
                 sn.ginit = true;
