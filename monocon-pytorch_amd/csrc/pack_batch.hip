@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackJobDesc *__re
         // forward panel: [tap][CinPanel/4][CoutP][4] fp32, [piece][tap][CinPanel/8][CoutP][8] bf16
         const size_t total = (size_t)j.Cout * j.Cin * kk;
         const size_t plane = (size_t)kk * j.CinTotal * j.CoutP;
-        if (j.Cin % 8 == 0 && j.c_off % 8 == 0 && (kk == 9 || kk == 1)) {
+        if (j.Cin % 8 == 0 && j.c_off % 8 == 0 && (kk == 9 || kk == 1) && (reinterpret_cast<uintptr_t>(j.w) & 15) == 0) {      // (16-byte loads of the master)
             const int items = j.Cout * (j.Cin >> 3);
             auto run = [&](auto kkc) {
                 constexpr int KK = decltype(kkc)::value;
