@@ -234,7 +234,12 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     __amdgpu_buffer_rsrc_t e_out = make_rsrc(a.out, 0u), e_res = e_out, e_y = e_out, e_z = e_out;
     int e_sout = 0, e_sres = 0, e_patch = 0, e_img = 0;
     float ssum = 0.f, ssq = 0.f;
-    float rvr[4], yvr[4], zvr[4];      // operands of the rows in flight (requested three K-steps ahead)
+    // operands of the rows in flight: requested LEAD K-steps before their row is finished.  Three steps (~400 cycles) cover an
+    // L2 hit; the residual of the eval forward's two BasicBlock launches comes from HBM (1-2 us under load): with a lead of
+    // three they took 314 us against 188 for the same layer without residual.  The backward-statistics variants keep three
+    // (their rings would need 2-3 x 11 registers the kernel does not have).
+    constexpr int LEAD = (RES && !BM) ? 10 : 3, RING = LEAD + 1;
+    float rvr[RING], yvr[RING], zvr[RING];
     auto epi_setup = [&](const Cursor &c) {
         const int oy0 = c.ty * 4, ox0 = c.tx * 16 + 8 * wp;
         e_img = c.img;
@@ -248,17 +253,17 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         ssum = 0.f; ssq = 0.f;
     };
     auto epi_load = [&](int r) {
-        if constexpr (RES) rvr[r & 3] = buf_load1(e_res, v_res, e_sres + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
-        if constexpr (BM) yvr[r & 3] = buf_load1(e_y, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
-        if constexpr (BM && ZMASK) zvr[r & 3] = buf_load1(e_z, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+        if constexpr (RES) rvr[r % RING] = buf_load1(e_res, v_res, e_sres + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
+        if constexpr (BM) yvr[r % RING] = buf_load1(e_y, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+        if constexpr (BM && ZMASK) zvr[r % RING] = buf_load1(e_z, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
     };
     // a row in three parts, one per MFMA gap of its K-step: (1) value + mask, (2) statistics, ReLU, max |v|, (3) the store
     float e_v = 0.f;
     auto epi_row_a1 = [&](int r) {
         float v = __builtin_fmaf(Y[r], sc, bi);
-        if constexpr (RES) v += rvr[r & 3];
+        if constexpr (RES) v += rvr[r % RING];
         if constexpr (BM) {
-            const bool on = ZMASK ? zvr[r & 3] > 0.f : (bm_relu == 0 || __builtin_fmaf(yvr[r & 3], ma, mb) > 0.f);
+            const bool on = ZMASK ? zvr[r % RING] > 0.f : (bm_relu == 0 || __builtin_fmaf(yvr[r % RING], ma, mb) > 0.f);
             v = on ? v : 0.f;
         }
         e_v = v;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         float v = e_v;
         if constexpr (BM) {
             ssum += v;
-            ssq = __builtin_fmaf(v, yvr[r & 3], ssq);
+            ssq = __builtin_fmaf(v, yvr[r % RING], ssq);
         } else if constexpr (STATS) {
             const float d = v - sh;
             ssum += d;
@@ -322,14 +327,14 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
             if constexpr (EXP & 1) asm volatile("" : "+v"(accm) : "v"(al), "v"(breg[s][0]));
             else accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, breg[s][0], accm, 0, 0, 0);      // l * h
             __builtin_amdgcn_sched_barrier(0);
-            if (EPI && s >= 3 && s < 19) epi_row_a1(s - 3);
+            if (EPI && s >= LEAD && s < LEAD + 16) epi_row_a1(s - LEAD);
             if (s >= S0 && s < S0 + NIT) stage_a(s - S0);
             if (s == S0 + NIT) fetch_setup(cn);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (EXP & 1) asm volatile("" : "+v"(acc) : "v"(ah), "v"(breg[s][0]));
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, breg[s][0], acc, 0, 0, 0);        // h * h
             __builtin_amdgcn_sched_barrier(0);
-            if (EPI && s >= 3 && s < 19) epi_row_a2(s - 3);
+            if (EPI && s >= LEAD && s < LEAD + 16) epi_row_a2(s - LEAD);
             if (s >= S0 && s < S0 + NIT) stage_b(s - S0, nxt);
             if (s >= S0 + NIT && s < S0 + 2 * NIT) fetch_addr(s - S0 - NIT);
             __builtin_amdgcn_sched_barrier(0);
@@ -337,9 +342,9 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
             if constexpr (EXP & 1) asm volatile("" : "+a"(accm) : "v"(ah), "a"(breg[s][1]));
             else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(accm) : "v"(ah), "a"(breg[s][1]));
             __builtin_amdgcn_sched_barrier(0);
-            if (EPI && s >= 3 && s < 19) epi_row_b(s - 3);
-            if (EPI && s < 16) epi_load(s);          // operands of row s, due in three K-steps
-            if (EPI && s == 19) epi_finish();
+            if (EPI && s >= LEAD && s < LEAD + 16) epi_row_b(s - LEAD);
+            if (EPI && s < 16) epi_load(s);          // operands of row s, due in LEAD K-steps
+            if (EPI && s == LEAD + 16) epi_finish();
         }
         // (the last MFMA is inline asm: hipcc does not pad its result hazard -- 8 passes: 12 wait states before a VALU read)
         asm volatile("s_nop 15" : "+a"(accm));
