@@ -268,3 +268,46 @@ def make_conditioned_batch(seed, batch, height, width, as_torch=True):
         d["img"] = torch.from_numpy(d["img"])
         d["label"] = {k: torch.from_numpy(v) for k, v in d["label"].items()}
     return d
+
+
+# ---- KITTI annotation dicts for the AP evaluator (tests/test_kitti_eval.py, tests/golden/make_f4_golden.py)
+KITTI_NAMES = ("Car", "Pedestrian", "Cyclist", "Van", "Person_sitting", "DontCare", "Truck")
+
+
+def random_kitti_annos(seed, frames=10):
+    """seeded KITTI-format ground-truth / detection annotation dicts (the evaluator's input, reference
+    engine/kitti_eval/eval.py:347-453): mixed classes incl. DontCare, jittered detections, false positives"""
+    rng = np.random.default_rng(seed)
+    gts, dts = [], []
+    for f in range(frames):
+        n = int(rng.integers(0, 9)) if f else 6
+        names = rng.choice(KITTI_NAMES, n, p=[0.4, 0.2, 0.12, 0.08, 0.05, 0.1, 0.05])
+        loc = np.stack([rng.uniform(-15, 15, n), rng.uniform(1.2, 2.0, n), rng.uniform(6, 55, n)], 1)
+        dims = np.stack([rng.uniform(0.6, 4.5, n), rng.uniform(1.3, 2.0, n), rng.uniform(0.5, 2.0, n)], 1)      # l, h, w
+        ry = rng.uniform(-math.pi, math.pi, n)
+        x1, y1 = rng.uniform(0, 1000, n), rng.uniform(100, 250, n)
+        bbox = np.stack([x1, y1, x1 + rng.uniform(20, 200, n), y1 + rng.uniform(15, 120, n)], 1)
+        gt = {"name": names, "truncated": np.round(rng.uniform(0, 0.6, n), 2), "occluded": rng.integers(0, 4, n).astype(np.float64),
+              "alpha": rng.uniform(-math.pi, math.pi, n), "bbox": bbox, "dimensions": dims, "location": loc, "rotation_y": ry,
+              "score": np.zeros(n)}
+        for i in range(n):
+            if names[i] == "DontCare":
+                gt["truncated"][i], gt["occluded"][i], gt["alpha"][i] = -1, -1, -10
+                dims[i], loc[i], ry[i] = -1, -1000, -10
+        gts.append(gt)
+        real = [i for i in range(n) if names[i] != "DontCare"]
+        keep = [i for i in real if rng.uniform() < 0.8]
+        m_fp = int(rng.integers(0, 4))
+        dn = [names[i] if rng.uniform() < 0.9 else "Car" for i in keep] + list(rng.choice(KITTI_NAMES[:3], m_fp))
+        jit = lambda a, s: a + rng.normal(0, s, a.shape)       # noqa: E731
+        dloc = np.concatenate([jit(loc[keep], 0.15), np.stack([rng.uniform(-15, 15, m_fp), rng.uniform(1.2, 2, m_fp), rng.uniform(6, 55, m_fp)], 1)])
+        ddim = np.concatenate([np.abs(jit(dims[keep], 0.08)) + 0.05, np.stack([rng.uniform(0.6, 4.5, m_fp), rng.uniform(1.3, 2, m_fp), rng.uniform(0.5, 2, m_fp)], 1)])
+        dry = np.concatenate([jit(ry[keep], 0.1), rng.uniform(-3, 3, m_fp)])
+        fx1, fy1 = rng.uniform(0, 1000, m_fp), rng.uniform(100, 250, m_fp)
+        dbox = np.concatenate([jit(bbox[keep], 3.0), np.stack([fx1, fy1, fx1 + rng.uniform(20, 200, m_fp), fy1 + rng.uniform(15, 120, m_fp)], 1)])
+        k = len(keep) + m_fp
+        dts.append({"name": np.array(dn, dtype=object).reshape(-1), "truncated": np.zeros(k), "occluded": np.zeros(k),
+                    "alpha": np.concatenate([jit(gt["alpha"][keep], 0.2), rng.uniform(-3, 3, m_fp)]), "bbox": dbox.reshape(-1, 4),
+                    "dimensions": ddim.reshape(-1, 3), "location": dloc.reshape(-1, 3), "rotation_y": dry,
+                    "score": np.round(rng.uniform(0.05, 1.0, k), 3), "sample_idx": np.full(k, f)})
+    return gts, dts

@@ -2,8 +2,8 @@
 (transforms/default_transforms.py:375-452; dataset/monocon_dataset.py:32-33,39-40) -- on the host, plus
 ``GpuNormalizePad`` which does all three on the device through ``mc_preprocess``.
 
-The random training augmentations live in transforms/augmentations.py.  Parity of this file is unpinned (the reference module imports cv2, absent here); the arithmetic is
-restated by reading: ``(uint8 -> float32 - mean(float64)) / std(float64)`` is a float64 image, zero-padded to a
+The random training augmentations live in transforms/augmentations.py.  Pinned (round 6) to the reference's own output
+(tests/golden/f4_transforms.npz, tests/test_f4_reference_golden.py: bit-equal); the arithmetic: ``(uint8 -> float32 - mean(float64)) / std(float64)`` is a float64 image, zero-padded to a
 multiple of ``size_divisor`` and rounded ONCE to float32 by ``torch.Tensor(...)``.
 """
 from numbers import Number

@@ -490,8 +490,9 @@ def preprocess(img_hwc, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.3
     dataset/monocon_dataset.py:32-33,39-40): ``img.astype(float32)``, ``(img - mean) / std`` with float64
     mean / std arrays (numpy promotes to float64), zero canvas rounded up to ``size_divisor``,
     ``torch.Tensor(...)`` (-> float32) and HWC -> CHW.  Returns (tensor (3,Hp,Wp), (Hp, Wp)).
-    parity unpinned for this function: the reference module imports cv2, which this image lacks, so it
-    cannot be imported to record a golden; the restatement follows the source line by line."""
+    Pinned (round 6): bit-equal to the reference's own Normalize -> Pad -> ToTensor on uint8 and float32 frames of five
+    sizes (tests/golden/f4_transforms.npz, recorded by make_f4_golden.py with the reference module imported under an inert
+    cv2 placeholder that none of these three transforms touches; tests/test_f4_reference_golden.py)."""
     img = np.asarray(img_hwc).astype(np.float32)
     norm = (img - np.array(mean).reshape(1, 1, -1)) / np.array(std).reshape(1, 1, -1)
     h, w = norm.shape[:2]

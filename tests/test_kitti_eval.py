@@ -1,9 +1,11 @@
 """SURVEY 8f-4, last row: the KITTI AP evaluator (engine/kitti_eval) -- HIP rotated-overlap kernels + native matching
 behind the C-ABI -- against oracle/kitti_eval_oracle.py.
 
-The oracle is PARITY UNPINNED against the reference (its evaluator needs numba / numba.cuda, absent here, and ships no
-test vectors); it is pinned instead by closed-form answers and by an independent float64 polygon-clipping implementation
-(``clip_area`` below: Sutherland-Hodgman, shares nothing with the vertex-collection / angle-sort formulation)."""
+The oracle's host logic (ignore rules, matching, recall sampling, AP) is pinned to the reference's own functions in
+tests/test_f4_reference_golden.py (round 6).  Its rotated-overlap arithmetic stays PARITY UNPINNED (a float32 numba.cuda
+kernel upstream, not executable here) and is held by what this file does: closed-form answers and an independent float64
+polygon-clipping implementation (``clip_area`` below: Sutherland-Hodgman, shares nothing with the vertex-collection /
+angle-sort formulation)."""
 import math
 import os
 
@@ -134,44 +136,7 @@ def test_oracle_matching_by_hand():
 
 
 # ------------------------------------------------------------------------------------------------ synthetic annotations
-NAMES = ("Car", "Pedestrian", "Cyclist", "Van", "Person_sitting", "DontCare", "Truck")
-
-
-def random_annos(seed, frames=10):
-    rng = np.random.default_rng(seed)
-    gts, dts = [], []
-    for f in range(frames):
-        n = int(rng.integers(0, 9)) if f else 6
-        names = rng.choice(NAMES, n, p=[0.4, 0.2, 0.12, 0.08, 0.05, 0.1, 0.05])
-        loc = np.stack([rng.uniform(-15, 15, n), rng.uniform(1.2, 2.0, n), rng.uniform(6, 55, n)], 1)
-        dims = np.stack([rng.uniform(0.6, 4.5, n), rng.uniform(1.3, 2.0, n), rng.uniform(0.5, 2.0, n)], 1)      # l, h, w
-        ry = rng.uniform(-math.pi, math.pi, n)
-        x1, y1 = rng.uniform(0, 1000, n), rng.uniform(100, 250, n)
-        bbox = np.stack([x1, y1, x1 + rng.uniform(20, 200, n), y1 + rng.uniform(15, 120, n)], 1)
-        gt = {"name": names, "truncated": np.round(rng.uniform(0, 0.6, n), 2), "occluded": rng.integers(0, 4, n).astype(np.float64),
-              "alpha": rng.uniform(-math.pi, math.pi, n), "bbox": bbox, "dimensions": dims, "location": loc, "rotation_y": ry,
-              "score": np.zeros(n)}
-        for i in range(n):
-            if names[i] == "DontCare":
-                gt["truncated"][i], gt["occluded"][i], gt["alpha"][i] = -1, -1, -10
-                dims[i], loc[i], ry[i] = -1, -1000, -10
-        gts.append(gt)
-        real = [i for i in range(n) if names[i] != "DontCare"]
-        keep = [i for i in real if rng.uniform() < 0.8]
-        m_fp = int(rng.integers(0, 4))
-        dn = [names[i] if rng.uniform() < 0.9 else "Car" for i in keep] + list(rng.choice(NAMES[:3], m_fp))
-        jit = lambda a, s: a + rng.normal(0, s, a.shape)       # noqa: E731
-        dloc = np.concatenate([jit(loc[keep], 0.15), np.stack([rng.uniform(-15, 15, m_fp), rng.uniform(1.2, 2, m_fp), rng.uniform(6, 55, m_fp)], 1)])
-        ddim = np.concatenate([np.abs(jit(dims[keep], 0.08)) + 0.05, np.stack([rng.uniform(0.6, 4.5, m_fp), rng.uniform(1.3, 2, m_fp), rng.uniform(0.5, 2, m_fp)], 1)])
-        dry = np.concatenate([jit(ry[keep], 0.1), rng.uniform(-3, 3, m_fp)])
-        fx1, fy1 = rng.uniform(0, 1000, m_fp), rng.uniform(100, 250, m_fp)
-        dbox = np.concatenate([jit(bbox[keep], 3.0), np.stack([fx1, fy1, fx1 + rng.uniform(20, 200, m_fp), fy1 + rng.uniform(15, 120, m_fp)], 1)])
-        k = len(keep) + m_fp
-        dts.append({"name": np.array(dn, dtype=object).reshape(-1), "truncated": np.zeros(k), "occluded": np.zeros(k),
-                    "alpha": np.concatenate([jit(gt["alpha"][keep], 0.2), rng.uniform(-3, 3, m_fp)]), "bbox": dbox.reshape(-1, 4),
-                    "dimensions": ddim.reshape(-1, 3), "location": dloc.reshape(-1, 3), "rotation_y": dry,
-                    "score": np.round(rng.uniform(0.05, 1.0, k), 3), "sample_idx": np.full(k, f)})
-    return gts, dts
+from hipmonocon.synth import KITTI_NAMES as NAMES, random_kitti_annos as random_annos      # noqa: E402
 
 
 def test_host_library_matches_the_oracle_on_random_frames():
