@@ -73,8 +73,11 @@ struct ConvCfgB16 {
     static constexpr size_t LDS_BYTES = TILE_BYTES + PB * 16;
 };
 
-template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
+// LZ: the launch has lazy sources (ConvSrc::la) -- its own instantiation, so that every other launch keeps its registers
+// (the coefficients cost ~10 of them, which pushed the 128 x 64 tilings into scratch) and its instruction stream
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false, bool LZ = false>
 __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kernel(const ConvArgs a) {
+    static_assert(!LZ || (SPL == 2 && !BM), "lazy sources: forward launches of the fp16-split mode");
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
     typedef typename Piece<SPL>::T pc_t;
     typedef typename Piece<SPL>::V8 pc8;
@@ -226,6 +229,31 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
     int voff[NIT], sdst[NIT];
     int si = 0, c0 = 0, kc = 0;
     int Cs = a.src[0].C;
+    // Lazy sources (LZ): the chunk being staged holds the producer's raw conv output y; its value max(fma(y, la, lb), 0) is
+    // formed in stage_one, with the operand scale folded into the coefficients.  A thread stages ONE channel quad (c4) of
+    // every pixel, so a chunk's coefficients are two float4 per thread: requested (lazy_fetch) right after the previous
+    // chunk has been staged -- ahead of that chunk's MFMA phase -- and scaled (lazy_advance) when their chunk is staged.
+    // Padding must stay 0 (not relu(lb)): voff[i] == BUF_OOB.
+    f32x4 lzA = {0.f, 0.f, 0.f, 0.f}, lzB = lzA;
+    bool lz_cur = false, lz_next = false;
+    auto lazy_fetch = [&](int s_idx, int cc0) {       // coefficients of chunk (source s_idx, first channel cc0)
+        if constexpr (LZ) {
+            lz_next = a.src[s_idx].la != nullptr;
+            if (lz_next) {
+                lzA = reinterpret_cast<const f32x4 *>(a.src[s_idx].la + cc0)[c4];
+                lzB = reinterpret_cast<const f32x4 *>(a.src[s_idx].lb + cc0)[c4];
+            }
+        }
+    };
+    auto lazy_advance = [&] {
+        if constexpr (LZ) {
+            lz_cur = lz_next;
+            if (lz_cur) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { lzA[j] *= a_scale; lzB[j] *= a_scale; }
+            }
+        }
+    };
     __amdgpu_buffer_rsrc_t r_in = make_rsrc(a.src[0].p + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
     auto lane_offsets = [&](int cs) {
 #pragma unroll
@@ -247,12 +275,16 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
         }
     };
     auto stage_load = [&](__amdgpu_buffer_rsrc_t r, int vo, int so) -> f32x4 { return buf_load4(r, vo, so); };
-    auto stage_one = [&](const f32x4 &v, int i) {       // split one float4 into its pieces and write them to the LDS planes
+    // split one float4 into its pieces and write them to the LDS planes.  LZ (a type: the caller branches ONCE per chunk on the
+    // wave-uniform lz_cur, so a launch with mixed sources keeps the plain path for its materialised ones): the chunk is lazy
+    auto stage_one = [&](const f32x4 &v, int i, auto lz_c) {
+        constexpr bool LZC = decltype(lz_c)::value;
         if (i < NIT && (NT * (i + 1) <= TOTAL || tid + NT * i < TOTAL)) {
             pc4 q[SPL];
+            [[maybe_unused]] const float cap = voff[i] != BUF_OOB ? __builtin_inff() : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float r = SPL == 2 ? v[j] * a_scale : v[j];
+                float r = SPL == 2 ? (LZC ? lazy_act(v[j], lzA[j], lzB[j], cap) : v[j] * a_scale) : v[j];
 #pragma unroll
                 for (int pz = 0; pz < SPL; ++pz) {   // h = rnd(x), m = rnd(x - h), l = rnd(x - h - m)
                     q[pz][j] = (pc_t)r;
@@ -271,6 +303,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
 #define TP_NOW() 0ull
 #endif
     lane_offsets(Cs);
+    lazy_fetch(0, 0);
     if (PF) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) pv[i] = stage_load(r_in, voff[i], 0);
@@ -281,19 +314,28 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
         [[maybe_unused]] unsigned long long tp_a = TP_NOW();
         if (!first) __syncthreads();
         [[maybe_unused]] unsigned long long tp_b = TP_NOW();
-        if (PF) {
+        lazy_advance();
+        auto stage_chunk = [&](auto lz_c) {
+            if (PF) {
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) stage_one(pv[i], i);
-        } else {
+                for (int i = 0; i < NIT; ++i) stage_one(pv[i], i, lz_c);
+            } else {
 #pragma unroll
-            for (int i0 = 0; i0 < NIT; i0 += UB) {
-                f32x4 v[UB];
+                for (int i0 = 0; i0 < NIT; i0 += UB) {
+                    f32x4 v[UB];
 #pragma unroll
-                for (int u = 0; u < UB; ++u)
-                    if (i0 + u < NIT) v[u] = stage_load(r_in, voff[i0 + u], c0 * 4);
+                    for (int u = 0; u < UB; ++u)
+                        if (i0 + u < NIT) v[u] = stage_load(r_in, voff[i0 + u], c0 * 4);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) stage_one(v[u], i0 + u);
+                    for (int u = 0; u < UB; ++u) stage_one(v[u], i0 + u, lz_c);
+                }
             }
+        };
+        if constexpr (LZ) {
+            if (lz_cur) stage_chunk(std::true_type{});
+            else stage_chunk(std::false_type{});
+        } else {
+            stage_chunk(std::false_type{});
         }
         [[maybe_unused]] unsigned long long tp_c = TP_NOW();
         __syncthreads();
@@ -308,6 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN, SPL == 1 ? 3 : 2) void conv_bf16_kern
             r_in = make_rsrc(a.src[nsi].p + (size_t)img * a.Hin * a.Win * Cs, (unsigned)(a.Hin * a.Win * Cs) * 4u);
             lane_offsets(Cs);
         }
+        if (more) lazy_fetch(nsi, nc0);
         if (PF && more) {
 #pragma unroll
             for (int i = 0; i < NIT; ++i) pv[i] = stage_load(r_in, voff[i], nc0 * 4);
@@ -457,9 +500,21 @@ hipError_t launch_pack_conv_w_dgrad_bf16(const float *w, int Cout, int CinTotal,
 }
 
 // ---- dispatch
-template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false>
+template <int KS, int S, int WM, int WN, int WTM, int WTN, int SPL, bool BM = false, bool LZ = false>
 static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     using Cfg = ConvCfgB16<KS, S, WM, WN, WTM, WTN, SPL>;
+    if constexpr (!LZ) {
+        bool lazy = false;
+        for (int i = 0; i < a.nsrc; ++i) lazy |= a.src[i].la != nullptr;
+        if (lazy) {      // lazy sources: forward launches of the fp16-split mode (3x3 stride 1 / 2 and 1x1), never a data gradient
+            if constexpr (SPL == 2 && !BM && (KS == 3 || KS == 1)) {
+                if (a.bm_y) return hipErrorInvalidValue;
+                return launch_b16_one<KS, S, WM, WN, WTM, WTN, SPL, false, true>(a, st, resolved);
+            } else {
+                return hipErrorInvalidValue;
+            }
+        }
+    }
     if constexpr (!BM && S == 1 && (KS == 3 || KS == 1)) {      // backward-statistics epilogue: own instantiation
         if (a.bm_y) return launch_b16_one<KS, S, WM, WN, WTM, WTN, SPL, true>(a, st, resolved);
     } else if constexpr (!BM) {
@@ -472,7 +527,7 @@ static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved)
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
     static bool attr_set = false;
-    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL, BM>;
+    auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL, BM, LZ>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);

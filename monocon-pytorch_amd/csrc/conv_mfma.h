@@ -42,7 +42,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvSrc {
     const float *p;
     int C;
+    // "Lazy" activation (train plans of precision mode 3, round 6): p holds the RAW conv output y of the producing layer and
+    // the tensor's value is max(fma(y, la[c], lb[c]), 0) -- train-mode BatchNorm apply + ReLU, formed by the CONSUMER
+    // while it stages the operand (one fma + one v_med3 on top of the scale-and-split it pays anyway), so the activation is
+    // never written to HBM.  Zero padding stays zero (not relu(lb)): lazy_act()'s `cap`.  null: p holds the values.
+    // Scaling by a power of two commutes with the fma's rounding, so the staged pieces are bit-identical to those of the
+    // stored activation under the same operand scale (the scale itself comes from a sound BOUND of max |z| in this case,
+    // written by bn_finalize_kernel; the stored activation's slot holds its exact maximum).
+    const float *la, *lb;
 };
+// one lazy element: a = la[c] * 2^e, b = lb[c] * 2^e (the operand scale folded into the coefficients), cap = +inf inside the
+// image, 0 on padding.  v_med3_f32(t, 0, cap) = min(max(t, 0), cap) is the ReLU and the padding mask in one instruction.
+__device__ __forceinline__ float lazy_act(float y, float a, float b, float cap) {
+    return __builtin_amdgcn_fmed3f(__builtin_fmaf(y, a, b), 0.f, cap);
+}
 
 struct ConvArgs {
     ConvSrc src[4];
@@ -770,6 +783,10 @@ hipError_t launch_dgrad_s2_thin(const float *dy, int B, int H, int W, int dyC, c
                                 int accumulate, const unsigned *amax_dy, const unsigned *amax_w, hipStream_t st);
 
 hipError_t launch_conv(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved = nullptr);
+// lazy sources (ConvSrc::la): does launch_conv() have a kernel for these arguments that forms them on load?  (The fp16-pipe
+// kernels of mode 3: conv_thin16, conv_bf16<SPL = 2> for 3x3 stride 1 / 2 and 1x1, conv_wres; a launch with lazy sources
+// that reaches any other kernel fails.)  Independent of ConvArgs::cfg among the tilings of conv_bf16 / conv_wres.
+bool conv_lazy_capable(const ConvArgs &a, int ks, int stride);
 
 // Measurement aid (mc_profile_train): the last launch_conv / launch_wgrad on this host thread notes
 // its kernel family (1 = fused conv incl. dgrad, 2 = wgrad) and algorithmic FLOPs here.

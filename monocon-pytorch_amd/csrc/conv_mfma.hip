@@ -102,8 +102,16 @@ int conv_pick_cfg(int Cout, int CoutP, int ks, int stride, int B, int Hout, int 
     return CFG_128x32;
 }
 
+bool conv_lazy_capable(const ConvArgs &a, int ks, int stride) {
+    if (a.prec != 3 || a.bm_y) return false;
+    if (conv_thin_ok(a, ks, stride)) return true;
+    return conv_bf16_ok(a, ks, stride) && (ks == 3 || ks == 1);
+}
+
 hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st, ConvArgs *resolved) {
     ConvArgs a = a_in;
+    bool lazy = false;
+    for (int i = 0; i < a.nsrc; ++i) lazy |= a.src[i].la != nullptr;
     const bool dense_out = a.o_px == 0;
     if (dense_out) { a.o_px = a.out_ld; a.o_row = a.Wout * a.out_ld; a.o_img = a.Hout * a.Wout * a.out_ld; }
     if (a.r_px == 0) { a.r_px = a.res_ld; a.r_row = a.Wout * a.res_ld; a.r_img = a.Hout * a.Wout * a.res_ld; }
@@ -115,6 +123,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
         if (sc[i] % ck) return hipErrorInvalidValue;
     if (a.cfg == CFG_SMALL) {
         if (!conv_small_ok(a, ks, stride)) return hipErrorInvalidValue;
+        if (lazy && !conv_thin_ok(a, ks, stride)) return hipErrorInvalidValue;      // (the fp32 row kernel does not form lazy sources)
         a.ppr = (a.Wout + 7) / 8;
         a.ppi = a.ppr * ((a.Hout + 3) / 4);
         a.chunks = a.Hout;
@@ -131,6 +140,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
         a.cfg &= ~CFG_WRES;
     }
     if (a.prec >= 1 && conv_bf16_ok(a, ks, stride)) return launch_conv_bf16(a, ks, stride, st, resolved);
+    if (lazy) return hipErrorInvalidValue;      // (nor do the fp32 MFMA kernels)
     if (ks == 3 && stride == 1) {
         return ck == 32 ? launch_shape<3, 1, 32>(a, st, resolved) : launch_shape<3, 1, 16>(a, st, resolved);
     } else if (ks == 3 && stride == 2) {

@@ -55,6 +55,18 @@ __global__ __launch_bounds__(256, THIN_OCC) void conv_thin16_kernel(const ConvAr
     const int ex = f16_scale_exp(amax_read(a.amax_in[0])), ew = f16_scale_exp(*a.amax_w);
     const float x_scale = exp2i(ex), w_scale = exp2i(ew);
     const float omul = exp2i(-ex) * exp2i(-ew);
+    // lazy source (ConvSrc::la): the tile holds the producer's raw conv output; BatchNorm apply + ReLU happen in store()
+    // below, with the operand scale folded into the coefficients.  A thread's items all belong to channel quad tid & 3.
+    const bool lazy = a.src[0].la != nullptr;
+    f32x4 lzA = {0.f, 0.f, 0.f, 0.f}, lzB = lzA;
+    if (lazy) {
+        lzA = reinterpret_cast<const f32x4 *>(a.src[0].la)[tid & 3];
+        lzB = reinterpret_cast<const f32x4 *>(a.src[0].lb)[tid & 3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lzA[j] *= x_scale; lzB[j] *= x_scale; }
+    }
+    const unsigned x_bytes = (unsigned)(a.Hin * a.Win * CIN) * 4u;      // one image: an offset below this is inside it
+    unsigned okm = 0u;          // lazy: bit i = staged item i lies inside the image (padding must stay 0, not relu(b))
 
     // ---- the filter: bw[step][piece][nt] = W[n = nt*16 + li][channels 8*half .. +7][tap 2*step + tsel] * 2^ew, split
     f16x8 bw[5][2][NTN];
@@ -142,15 +154,22 @@ __global__ __launch_bounds__(256, THIN_OCC) void conv_thin16_kernel(const ConvAr
         const int band_off = ((oy0 - 1) * a.Win - 1) * CIN * 4;      // (row oy0 - 1, column -1) of this image
         auto fetch = [&](int strip) {
             const int x0 = strip * TW - 1, so = band_off + strip * TW * CIN * 4;
+            okm = 0u;
             if (strip > 0 && x0 + IP <= a.Win) {          // interior strip: every column is inside the image
 #pragma unroll
-                for (int i = 0; i < NI; ++i) pre[i] = buf_load4(r_x, s_dst[i] >= 0 ? s_off[i] + so : BUF_OOB, 0);
+                for (int i = 0; i < NI; ++i) {
+                    const int vo = s_dst[i] >= 0 ? s_off[i] + so : BUF_OOB;
+                    pre[i] = buf_load4(r_x, vo, 0);
+                    if (lazy) okm |= ((unsigned)vo < x_bytes ? 1u : 0u) << i;      // (columns are inside: in range <=> row inside)
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int px = ((s_dst[i] % PLANE) >> 4) % IP;      // (recomputed: not worth 11 registers for 2 strips of 20)
                     const bool ok = s_dst[i] >= 0 && (unsigned)(x0 + px) < (unsigned)a.Win;
-                    pre[i] = buf_load4(r_x, ok ? s_off[i] + so : BUF_OOB, 0);
+                    const int vo = ok ? s_off[i] + so : BUF_OOB;
+                    pre[i] = buf_load4(r_x, vo, 0);
+                    if (lazy) okm |= ((unsigned)vo < x_bytes ? 1u : 0u) << i;
                 }
             }
         };
@@ -159,9 +178,10 @@ __global__ __launch_bounds__(256, THIN_OCC) void conv_thin16_kernel(const ConvAr
             for (int i = 0; i < NI; ++i) {
                 if (256 * (i + 1) > ITEMS && s_dst[i] < 0) continue;
                 f16x4 h4, l4;
+                const float cap = ((okm >> i) & 1u) ? __builtin_inff() : 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float xs = pre[i][j] * x_scale;
+                    const float xs = lazy ? lazy_act(pre[i][j], lzA[j], lzB[j], cap) : pre[i][j] * x_scale;
                     const _Float16 hh = (_Float16)xs;
                     h4[j] = hh;
                     l4[j] = (_Float16)(xs - (float)hh);
@@ -491,6 +511,17 @@ __global__ __launch_bounds__(256) void wgrad_thin16_kernel(const WgradArgs a) {
     const int ex = f16_scale_exp(amax_read(a.amax_x[0])), ed = f16_scale_exp(amax_read(a.amax_dy));
     const float x_scale = exp2i(ex), d_scale = exp2i(ed), omul = exp2i(-ex) * exp2i(-ed);
     const int H = a.Hout, W = a.Wout;
+    // lazy X (ConvSrc::la in conv_mfma.h): raw conv output + BatchNorm coefficients; a thread's items are channel quad tid & 3
+    const bool lazy = a.src[0].la != nullptr;
+    f32x4 lzA = {0.f, 0.f, 0.f, 0.f}, lzB = lzA;
+    if (lazy) {
+        lzA = reinterpret_cast<const f32x4 *>(a.src[0].la)[tid & 3];
+        lzB = reinterpret_cast<const f32x4 *>(a.src[0].lb)[tid & 3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lzA[q] *= x_scale; lzB[q] *= x_scale; }
+    }
+    const unsigned x_bytes = (unsigned)(a.Hin * a.Win * 16) * 4u;
+    unsigned okm = 0u;          // lazy: bits 2i, 2i + 1 = the two pixels of item i lie inside the image
 
     f32x4v acc[9], accm[9];
 #pragma unroll
@@ -516,12 +547,16 @@ __global__ __launch_bounds__(256) void wgrad_thin16_kernel(const WgradArgs a) {
         const __amdgpu_buffer_rsrc_t r_x = make_rsrc(a.src[0].p + (size_t)b * a.Hin * a.Win * 16, (unsigned)(a.Hin * a.Win * 16) * 4u);
         const int so = ((y0 - 1) * a.Win + x0 - 1) * 64;        // window origin (row y0 - 1, column x0 - 1); rows outside the
                                                                  // image fall out of the descriptor, columns are tested
+        okm = 0u;
 #pragma unroll
         for (int i = 0; i < NIW; ++i) {
             const int col = x0 - 1 + ((w_dst[i] >> 1) % WT_P);
             const bool live = w_dst[i] >= 0;
-            pv[i][0] = buf_load4(r_x, (live && col >= 0 && col < a.Win) ? w_off[i] + so : BUF_OOB, 0);
-            pv[i][1] = buf_load4(r_x, (live && col + 1 >= 0 && col + 1 < a.Win) ? w_off[i] + so + 64 : BUF_OOB, 0);
+            const int vo0 = (live && col >= 0 && col < a.Win) ? w_off[i] + so : BUF_OOB;
+            const int vo1 = (live && col + 1 >= 0 && col + 1 < a.Win) ? w_off[i] + so + 64 : BUF_OOB;
+            pv[i][0] = buf_load4(r_x, vo0, 0);
+            pv[i][1] = buf_load4(r_x, vo1, 0);
+            if (lazy) okm |= (((unsigned)vo0 < x_bytes ? 1u : 0u) | ((unsigned)vo1 < x_bytes ? 2u : 0u)) << (2 * i);
         }
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -532,9 +567,11 @@ __global__ __launch_bounds__(256) void wgrad_thin16_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NIW; ++i) {
             if (w_dst[i] < 0) continue;
+            const float cap0 = ((okm >> (2 * i)) & 1u) ? __builtin_inff() : 0.f, cap1 = ((okm >> (2 * i + 1)) & 1u) ? __builtin_inff() : 0.f;
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
-                const float s0 = pv[i][0][ch] * x_scale, s1 = pv[i][1][ch] * x_scale;
+                const float s0 = lazy ? lazy_act(pv[i][0][ch], lzA[ch], lzB[ch], cap0) : pv[i][0][ch] * x_scale;
+                const float s1 = lazy ? lazy_act(pv[i][1][ch], lzA[ch], lzB[ch], cap1) : pv[i][1][ch] * x_scale;
                 const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
                 const f16x2 hp = {h0, h1}, lp = {(_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1)};
                 const int off = w_dst[i] + ch * WT_ROWS * WT_P * 2;

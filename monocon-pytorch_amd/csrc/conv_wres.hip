@@ -81,7 +81,8 @@ __device__ __forceinline__ void wres_split_pair(float x0, float x1, float s, uns
 // partials), ZMASK its ReLU mask from the stored activation (bm_relu == 1).
 // EXP (measurement builds only, -DMC_WRES_EXP + MONOCON_WRES_EXP=bits; results WRONG by construction): 1 no MFMAs, 2 no
 // conversion / LDS writes, 4 no global loads, 8 no epilogue, 16 no fragment reads
-template <bool BM, bool RES, bool STATS, bool ZMASK, int EXP = 0>
+// LZ: the source is a lazy tensor (ConvSrc::la in conv_mfma.h: raw conv output + BatchNorm coefficients) -- forward launches only
+template <bool BM, bool RES, bool STATS, bool ZMASK, int EXP = 0, bool LZ = false>
 __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, const int tiles_per_row, const int tiles_per_img,
                                                            const int total_tiles, const int tiles_per_wg, const int ngroups) {
 #pragma clang fp contract(off)
@@ -184,15 +185,31 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         else pv[i] = buf_load4(f_rsrc, f_voff[i], 0);
     };
     float a_scale = 1.f, omul = 1.f;
+    // LZ: max(fma(y, la, lb), 0) of the thread's channel quad, the operand scale folded into the coefficients (set with
+    // a_scale below); padding stays 0: f_voff[i] == BUF_OOB.  The split then runs with scale 1 -- the same bits as the split
+    // of the stored activation (conv_mfma.h, ConvSrc).
+    static_assert(!LZ || !BM, "lazy sources: forward launches");
+    f32x4 lzA = {0.f, 0.f, 0.f, 0.f}, lzB = lzA;
+    if constexpr (LZ) {
+        lzA = reinterpret_cast<const f32x4 *>(a.src[0].la)[c4];
+        lzB = reinterpret_cast<const f32x4 *>(a.src[0].lb)[c4];
+    }
+    float lz_cap = 0.f;
     // conversion of item i (in pv) into image buffer `buf`, in two halves (each slotted behind one MFMA)
     unsigned st_h01 = 0, st_l01 = 0;
     auto stage_a = [&](int i) {
         if constexpr (EXP & 2) asm volatile("" ::"v"(pv[i]));
-        else wres_split_pair(pv[i][0], pv[i][1], a_scale, st_h01, st_l01);
+        else if constexpr (LZ) {
+            lz_cap = f_voff[i] != BUF_OOB ? __builtin_inff() : 0.f;
+            wres_split_pair(lazy_act(pv[i][0], lzA[0], lzB[0], lz_cap), lazy_act(pv[i][1], lzA[1], lzB[1], lz_cap), 1.f, st_h01, st_l01);
+        } else wres_split_pair(pv[i][0], pv[i][1], a_scale, st_h01, st_l01);
     };
     auto stage_b = [&](int i, int buf) {
         if constexpr (EXP & 2) return;
         unsigned h23, l23;
+        if constexpr (LZ)
+            wres_split_pair(lazy_act(pv[i][2], lzA[2], lzB[2], lz_cap), lazy_act(pv[i][3], lzA[3], lzB[3], lz_cap), 1.f, h23, l23);
+        else
         wres_split_pair(pv[i][2], pv[i][3], a_scale, h23, l23);
         unsigned char *dst = lds_raw + buf * TILE + sdst[i];
         u32x2_t hv, lv;
@@ -214,6 +231,10 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         const int ew = f16_scale_exp(*a.amax_w);
         a_scale = exp2i(ea);
         omul = exp2i(-ea) * exp2i(-ew);
+        if constexpr (LZ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { lzA[j] *= a_scale; lzB[j] *= a_scale; }
+        }
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) { stage_a(i); stage_b(i, t_begin & 1); }
@@ -420,9 +441,9 @@ bool conv_wres_ok(const ConvArgs &a, int ks, int stride) {
     return true;
 }
 
-template <bool BM, bool RES, bool STATS, bool ZMASK, int EXP = 0>
+template <bool BM, bool RES, bool STATS, bool ZMASK, int EXP = 0, bool LZ = false>
 static hipError_t launch_wres_one(const ConvArgs &a, int tpr, int tpi, int total, int per_wg, int ngroups, int nwg, hipStream_t st) {
-    auto kern = conv_wres_kernel<BM, RES, STATS, ZMASK, EXP>;
+    auto kern = conv_wres_kernel<BM, RES, STATS, ZMASK, EXP, LZ>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -464,6 +485,12 @@ hipError_t launch_conv_wres(const ConvArgs &a_in, int ks, int stride, hipStream_
     }
 #endif
     const bool res = a.res != nullptr, stats = a.stats != nullptr;
+    if (a.src[0].la) {       // lazy source: forward launches (no backward-statistics twin reads an activation)
+        if (a.bm_y || !a.src[0].lb) return hipErrorInvalidValue;
+#define WLZ(RES_, STATS_) launch_wres_one<false, RES_, STATS_, false, 0, true>(a, tpr, tpi, total, per_wg, ngroups, nwg, st)
+        return res ? (stats ? WLZ(true, true) : WLZ(true, false)) : (stats ? WLZ(false, true) : WLZ(false, false));
+#undef WLZ
+    }
     if (a.bm_y) {
         const bool zm = a.bm_relu == 1;
         return res ? (zm ? WL(true, true, true, true, 0) : WL(true, true, true, false, 0))

@@ -51,9 +51,12 @@ hipError_t launch_stem_wgrad_f16(const float *img, const float *dy, int B, int H
                                  const unsigned *img_amax, const unsigned *dy_amax, hipStream_t st, const float *y = nullptr,
                                  const float *coef = nullptr, const unsigned *y_amax = nullptr);
 bool stem_f16_enabled();       // false when compiled out (-DMC_NO_STEM_F16)
-hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st);
+// la / lb (both kernels): the input is a lazy tensor -- raw conv output + BatchNorm coefficients, ConvSrc::la in conv_mfma.h
+hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st, const float *la = nullptr,
+                           const float *lb = nullptr);
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out,
-                          hipStream_t st, unsigned *amax = nullptr);   // amax: max |out| folded into the slot (conv_mfma.h)
+                          hipStream_t st, unsigned *amax = nullptr,   // amax: max |out| folded into the slot (conv_mfma.h)
+                          const float *la = nullptr, const float *lb = nullptr);
 hipError_t launch_nchw_to_nhwc(const float *in, int B, int C, int H, int W, float *out, hipStream_t st);
 hipError_t launch_nhwc_to_nchw(const float *in, int B, int C, int H, int W, float *out, hipStream_t st);
 

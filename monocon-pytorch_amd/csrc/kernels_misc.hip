@@ -178,7 +178,9 @@ hipError_t launch_stem(const float *img, int B, int H, int W, const float *wpk, 
 }
 
 // ============================================================================ pool / deconv / layout
-__global__ void maxpool2_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4, f32x4 *__restrict__ out) {
+__global__ void maxpool2_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4, f32x4 *__restrict__ out,
+                                const f32x4 *__restrict__ la, const f32x4 *__restrict__ lb) {
+    // la / lb: lazy input (ConvSrc::la in conv_mfma.h) -- the window is pooled over max(fma(y, la, lb), 0)
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -187,7 +189,15 @@ __global__ void maxpool2_kernel(const f32x4 *__restrict__ in, int B, int H, int 
         const int x = p % Wo, y = (p / Wo) % Ho, b = p / ((size_t)Wo * Ho);
         const f32x4 *r0 = in + (((size_t)b * H + 2 * y) * W + 2 * x) * C4 + c;
         const f32x4 *r1 = r0 + (size_t)W * C4;
-        const f32x4 a = r0[0], bb = r0[C4], cc = r1[0], d = r1[C4];
+        f32x4 a = r0[0], bb = r0[C4], cc = r1[0], d = r1[C4];
+        if (la) {
+            const f32x4 av = la[c], bv = lb[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = fmaxf(fmaf(a[j], av[j], bv[j]), 0.f); bb[j] = fmaxf(fmaf(bb[j], av[j], bv[j]), 0.f);
+                cc[j] = fmaxf(fmaf(cc[j], av[j], bv[j]), 0.f); d[j] = fmaxf(fmaf(d[j], av[j], bv[j]), 0.f);
+            }
+        }
         f32x4 m;
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a[j], bb[j]), fmaxf(cc[j], d[j]));
@@ -198,10 +208,12 @@ static inline int grid_for(size_t total, int bs) {
     size_t g = (total + bs - 1) / bs;
     return (int)(g > 16384 ? 16384 : (g == 0 ? 1 : g));
 }
-hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st) {
+hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *out, hipStream_t st, const float *la,
+                           const float *lb) {
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st,
-                       reinterpret_cast<const f32x4 *>(in), B, H, W, C / 4, reinterpret_cast<f32x4 *>(out));
+                       reinterpret_cast<const f32x4 *>(in), B, H, W, C / 4, reinterpret_cast<f32x4 *>(out),
+                       reinterpret_cast<const f32x4 *>(la), reinterpret_cast<const f32x4 *>(lb));
     return hipGetLastError();
 }
 
@@ -211,12 +223,15 @@ hipError_t launch_maxpool2(const float *in, int B, int H, int W, int C, float *o
 // 32-bit division (round 5: as a flat grid-stride loop every output paid four 64-bit divisions -- 3.3 TB/s)
 __global__ __launch_bounds__(256) void deconv4_kernel(const f32x4 *__restrict__ in, int B, int H, int W, int C4,
                                                       const f32x4 *__restrict__ wpk, f32x4 *__restrict__ out,
-                                                      unsigned *__restrict__ amax) {
+                                                      unsigned *__restrict__ amax, const f32x4 *__restrict__ la,
+                                                      const f32x4 *__restrict__ lb) {
     const int Wo = 2 * W;
     float vmax = 0.f;          // max |out| of this thread (amax != null, see ConvArgs::amax_in)
     const unsigned ex = blockIdx.x * 256u + threadIdx.x;
     const int b = blockIdx.z;
     const int c = (int)(ex % (unsigned)C4), ox = (int)(ex / (unsigned)C4);
+    f32x4 lav = {1.f, 1.f, 1.f, 1.f}, lbv = {0.f, 0.f, 0.f, 0.f};       // lazy input (ConvSrc::la in conv_mfma.h)
+    if (la && ex < (unsigned)(Wo * C4)) { lav = la[c]; lbv = lb[c]; }
     for (int oy = blockIdx.y * 4; oy < min(2 * H, (int)blockIdx.y * 4 + 4) && ex < (unsigned)(Wo * C4); ++oy) {      // four output rows per block
         const int iy1 = (oy + 1) >> 1, ky1 = oy + 1 - 2 * iy1;   // ky1 in {0,1}
         const int ix1 = (ox + 1) >> 1, kx1 = ox + 1 - 2 * ix1;
@@ -229,7 +244,11 @@ __global__ __launch_bounds__(256) void deconv4_kernel(const f32x4 *__restrict__ 
             for (int dx = 0; dx < 2; ++dx) {
                 const int ix = ix1 - dx, kx = kx1 + 2 * dx;
                 if (ix < 0 || ix >= W) continue;
-                const f32x4 v = in[(((size_t)b * H + iy) * W + ix) * C4 + c];
+                f32x4 v = in[(((size_t)b * H + iy) * W + ix) * C4 + c];
+                if (la) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], lav[j], lbv[j]), 0.f);
+                }
                 const f32x4 w = wpk[(ky * 4 + kx) * C4 + c];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], w[j], acc[j]);
@@ -242,11 +261,11 @@ __global__ __launch_bounds__(256) void deconv4_kernel(const f32x4 *__restrict__ 
     if (amax) amax_update_block(amax, vmax);
 }
 hipError_t launch_deconv4(const float *in, int B, int H, int W, int C, const float *wpk, float *out, hipStream_t st,
-                          unsigned *amax) {
+                          unsigned *amax, const float *la, const float *lb) {
     if (B > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(deconv4_kernel, dim3((unsigned)((2 * W * (C / 4) + 255) / 256), (unsigned)((2 * H + 3) / 4), (unsigned)B), dim3(256), 0, st,
                        reinterpret_cast<const f32x4 *>(in), B, H, W, C / 4, reinterpret_cast<const f32x4 *>(wpk),
-                       reinterpret_cast<f32x4 *>(out), amax);
+                       reinterpret_cast<f32x4 *>(out), amax, reinterpret_cast<const f32x4 *>(la), reinterpret_cast<const f32x4 *>(lb));
     return hipGetLastError();
 }
 

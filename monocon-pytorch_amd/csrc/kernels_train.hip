@@ -193,7 +193,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const T *__restrict__
                                                           const float *shift, const float *gamma, const float *beta,
                                                           float eps, float momentum, float *running_mean,
                                                           float *running_var, long long *nbt, float *a_out, float *b_out,
-                                                          float *mean_out, float *rstd_out) {
+                                                          float *mean_out, float *rstd_out, const unsigned *ymax,
+                                                          unsigned *zmax, int zrelu) {
     const int c = blockIdx.x;
     double s1 = 0, s2 = 0;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) {
@@ -215,6 +216,20 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const T *__restrict__
         const float g = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
         const float a = g * rstd;
         if (a_out) { a_out[c] = a; b_out[c] = be - (float)mean * a; }
+        if (zmax && ymax) {
+            // the activation z = act(a * y + b) is never stored (a "lazy" tensor, ConvSrc::la): its consumers scale their
+            // fp16-split operand by a power of two derived from THIS bound of max |z| -- |a| * max |y| + b (ReLU: only the
+            // positive side counts) or + |b| -- from the exact max |y| the producing conv left in `ymax`.  A bound looser than
+            // the true maximum by a factor 2^L costs L of the split's 22 bits in absolute terms; measured L <= 1.
+            unsigned my = 0u;
+            for (int i = 0; i < AMAX_SUB; ++i) { const unsigned v = ymax[i * AMAX_STRIDE]; my = v > my ? v : my; }
+            const float b0 = be - (float)mean * a;
+            float zb = fabsf(a) * __builtin_bit_cast(float, my) + (zrelu ? b0 : fabsf(b0));
+            zb = fmaxf(zb, 0.f);
+            const unsigned bits = __builtin_bit_cast(unsigned, zb);
+            unsigned *q = zmax + (c % AMAX_SUB) * AMAX_STRIDE;
+            if (bits < 0x7f800000u && bits != 0u) atomicMax(q, bits);
+        }
         mean_out[c] = (float)mean;
         rstd_out[c] = rstd;
         if (running_mean) {
@@ -226,17 +241,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const T *__restrict__
 }
 hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
                               const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
-                              long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st, double *fold) {
+                              long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st, double *fold,
+                              const unsigned *ymax, unsigned *zmax, int zrelu) {
     if (dbg_skip("fin")) return hipSuccess;
     if (fold && nb >= FOLD_MIN_NB) {
         const int nb2 = (nb + FOLD_ROWS - 1) / FOLD_ROWS;
         if (!dbg_skip("fold")) hipLaunchKernelGGL(partial_fold_kernel, dim3(nb2), dim3(256), 0, st, partial, nb, Cstride, C, fold);
         hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(C), dim3(256), 0, st, fold, nb2, C, n, shift, gamma, beta, eps,
-                           momentum, rm, rv, nbt, a, b, mean, rstd);
+                           momentum, rm, rv, nbt, a, b, mean, rstd, ymax, zmax, zrelu);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(C), dim3(nb >= 2048 ? 1024 : 256), 0, st, partial, nb, Cstride, n, shift, gamma, beta, eps,
-                       momentum, rm, rv, nbt, a, b, mean, rstd);
+                       momentum, rm, rv, nbt, a, b, mean, rstd, ymax, zmax, zrelu);
     return hipGetLastError();
 }
 
@@ -265,7 +281,10 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
                                                          const float *__restrict__ bb, const f32x4 *__restrict__ res,
                                                          int C4, int RG, int rows_per_img, int blocks_per_img,
                                                          int rows_per_block, int per_sample, int relu,
-                                                         f32x4 *__restrict__ z, unsigned *__restrict__ amax) {
+                                                         f32x4 *__restrict__ z, unsigned *__restrict__ amax,
+                                                         const float *__restrict__ ra, const float *__restrict__ rbc, int rrelu) {
+    // ra / rb: the residual is a LAZY tensor (ConvSrc::la): res holds its producer's raw conv output, its value is
+    // act(ra * res + rb), formed here (a Tree's `project` branch, BatchNorm without ReLU: model/backbone/dla.py:181-185,198)
     const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
     const int b = blockIdx.x / blocks_per_img, rb = blockIdx.x % blocks_per_img;
     const int r0 = rb * rows_per_block, r1 = min(rows_per_img, r0 + rows_per_block);
@@ -273,6 +292,16 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
     float vmax = 0.f;            // max |z| of this thread (amax != null: the consumers' fp16-split operand scale)
     const f32x4 av = reinterpret_cast<const f32x4 *>(a)[ci], bv = reinterpret_cast<const f32x4 *>(bb)[ci];
     const float fl = relu ? 0.f : -__builtin_inff();
+    f32x4 rav = {1.f, 1.f, 1.f, 1.f}, rbv = {0.f, 0.f, 0.f, 0.f};
+    if (ra) { rav = reinterpret_cast<const f32x4 *>(ra)[c4]; rbv = reinterpret_cast<const f32x4 *>(rbc)[c4]; }
+    const float rfl = (ra && rrelu) ? 0.f : -__builtin_inff();
+    auto lazy_res = [&](f32x4 q) {
+        if (ra) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = fmaxf(fmaf(q[j], rav[j], rbv[j]), rfl);
+        }
+        return q;
+    };
     const unsigned base = ((unsigned)b * rows_per_img) * C4 + c4;
     const unsigned step = (unsigned)RG * C4;
     int r = r0 + rg;
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
         for (int u = 0; u < 4; ++u) v[u] = y[e + u * step];
         if (res) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = res[e + u * step];
+            for (int u = 0; u < 4; ++u) q[u] = lazy_res(res[e + u * step]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -300,10 +329,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
     for (; r < r1; r += RG) {
         const unsigned e = base + (unsigned)r * C4;
         f32x4 v = y[e];
+        f32x4 q1 = {0.f, 0.f, 0.f, 0.f};
+        if (res) q1 = lazy_res(res[e]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float t = fmaf(v[j], av[j], bv[j]);
-            if (res) t += res[e][j];
+            if (res) t += q1[j];
             v[j] = fmaxf(t, fl);
             vmax = fmaxf(vmax, fabsf(v[j]));
         }
@@ -312,13 +343,16 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
     if (amax) amax_update_block(amax, vmax);
 }
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
-                             int C, int per_sample, int relu, float *z, hipStream_t st, unsigned *amax) {
+                             int C, int per_sample, int relu, float *z, hipStream_t st, unsigned *amax, const float *res_a,
+                             const float *res_b, int res_relu) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
+    if ((res_a != nullptr) != (res_b != nullptr) || (res_a && !res)) return hipErrorInvalidValue;
     if (dbg_skip("aact")) return hipSuccess;
     const RowSplit rs = row_split(B, rows_per_img, C / 4);
     hipLaunchKernelGGL(affine_act_kernel, dim3(B * rs.blocks_per_img), dim3(rs.threads), 0, st,
                        reinterpret_cast<const f32x4 *>(y), a, b, reinterpret_cast<const f32x4 *>(res), C / 4, rs.rg,
-                       (int)rows_per_img, rs.blocks_per_img, rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(z), amax);
+                       (int)rows_per_img, rs.blocks_per_img, rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(z), amax,
+                       res_a, res_b, res_relu);
     return hipGetLastError();
 }
 
@@ -516,7 +550,9 @@ hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *part
 
 // 2x2/2 max-pool backward: gradient goes to the first maximum in window scan order (torch)
 __global__ void maxpool2_bwd_kernel(const f32x4 *__restrict__ x, const f32x4 *__restrict__ dout, int B, int H, int W,
-                                    int C4, f32x4 *__restrict__ dx, int accumulate) {
+                                    int C4, f32x4 *__restrict__ dx, int accumulate, const f32x4 *__restrict__ la,
+                                    const f32x4 *__restrict__ lb) {
+    // la / lb: x is a lazy tensor (ConvSrc::la) -- the window is compared on max(fma(y, la, lb), 0), the values the forward pooled
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -525,7 +561,16 @@ __global__ void maxpool2_bwd_kernel(const f32x4 *__restrict__ x, const f32x4 *__
         const int ox = p % Wo, oy = (p / Wo) % Ho;
         const size_t b = p / ((size_t)Wo * Ho);
         const size_t i00 = ((b * H + 2 * oy) * W + 2 * ox) * C4 + c, i01 = i00 + C4, i10 = i00 + (size_t)W * C4, i11 = i10 + C4;
-        const f32x4 v00 = x[i00], v01 = x[i01], v10 = x[i10], v11 = x[i11], g = dout[e];
+        f32x4 v00 = x[i00], v01 = x[i01], v10 = x[i10], v11 = x[i11];
+        const f32x4 g = dout[e];
+        if (la) {
+            const f32x4 av = la[c], bv = lb[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v00[j] = fmaxf(fmaf(v00[j], av[j], bv[j]), 0.f); v01[j] = fmaxf(fmaf(v01[j], av[j], bv[j]), 0.f);
+                v10[j] = fmaxf(fmaf(v10[j], av[j], bv[j]), 0.f); v11[j] = fmaxf(fmaf(v11[j], av[j], bv[j]), 0.f);
+            }
+        }
         f32x4 g00, g01, g10, g11;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -546,10 +591,11 @@ __global__ void maxpool2_bwd_kernel(const f32x4 *__restrict__ x, const f32x4 *__
     }
 }
 hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
-                               hipStream_t st) {
+                               hipStream_t st, const float *la, const float *lb) {
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(x),
-                       reinterpret_cast<const f32x4 *>(dout), B, H, W, C / 4, reinterpret_cast<f32x4 *>(dx), accumulate);
+                       reinterpret_cast<const f32x4 *>(dout), B, H, W, C / 4, reinterpret_cast<f32x4 *>(dx), accumulate,
+                       reinterpret_cast<const f32x4 *>(la), reinterpret_cast<const f32x4 *>(lb));
     return hipGetLastError();
 }
 
@@ -591,7 +637,8 @@ hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C
 // ... and wrt the (C,1,4,4) weights: dw[c,ky,kx] = sum_{b,iy,ix} in[b,iy,ix,c] * dout[b,2iy-1+ky,2ix-1+kx,c].
 // One workgroup per (image row-block); partial [blocks][16][C] then reduced by colsum-like pass.
 __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restrict__ in, const float *__restrict__ dout,
-                                                            int B, int H, int W, int C, float *__restrict__ partial) {
+                                                            int B, int H, int W, int C, float *__restrict__ partial,
+                                                            const float *__restrict__ la, const float *__restrict__ lb) {
     // one workgroup per (b, iy) input row; a thread owns 4 channels and every XG-th column, 16-byte
     // loads; the column groups are summed by wave shuffles + one LDS image (fixed order)
     __shared__ float red[16][256];
@@ -602,8 +649,14 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
     f32x4 acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 lav = {1.f, 1.f, 1.f, 1.f}, lbv = {0.f, 0.f, 0.f, 0.f};       // lazy input (ConvSrc::la)
+    if (la) { lav = reinterpret_cast<const f32x4 *>(la)[c4]; lbv = reinterpret_cast<const f32x4 *>(lb)[c4]; }
     for (int ix = xg; ix < W; ix += XG) {
-        const f32x4 v = in4[(((size_t)b * H + iy) * W + ix) * C4 + c4];
+        f32x4 v = in4[(((size_t)b * H + iy) * W + ix) * C4 + c4];
+        if (la) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], lav[j], lbv[j]), 0.f);
+        }
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
             const int oy = 2 * iy - 1 + ky;
@@ -653,9 +706,9 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_reduce_kernel(const float *
 }
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C) { return (size_t)B * H * 16 * C; }
 hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
-                                hipStream_t st) {
+                                hipStream_t st, const float *la, const float *lb) {
     if (C % 4 || C > 256 || 256 % (C / 4)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(deconv4_bwd_w_kernel, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial);
+    hipLaunchKernelGGL(deconv4_bwd_w_kernel, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb);
     hipLaunchKernelGGL(deconv4_bwd_w_reduce_kernel, dim3(C * 16), dim3(256), 0, st, partial, B * H, C, dw);
     return hipGetLastError();
 }

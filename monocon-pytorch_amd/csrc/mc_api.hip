@@ -312,8 +312,10 @@ int mc_choose_conv_cfg(mc_handle *h, const ConvArgs &a_in, int ks, int stride) {
     int heuristic = small_ok ? (int)CFG_SMALL : conv_pick_cfg(a_in.Cout, a_in.CoutP, ks, stride, a_in.B, a_in.Hout, a_in.Wout);
     if (!h->autotune) return heuristic;
     const bool b16 = a_in.prec >= 1 && conv_bf16_ok(a_in, ks, stride);
+    bool lazy = false;      // lazy sources (ConvSrc::la) stage differently: their own entry
+    for (int i = 0; i < a_in.nsrc; ++i) lazy |= a_in.src[i].la != nullptr;
     std::vector<int> key = {a_in.B, a_in.Hin, a_in.Win, ks, stride, a_in.Cout, a_in.CoutP, a_in.nsrc,
-                            (a_in.res ? 1 : 0) | (b16 ? 2 * a_in.prec : 0)};
+                            (a_in.res ? 1 : 0) | (b16 ? 2 * a_in.prec : 0) | (lazy ? 64 : 0)};
     for (int i = 0; i < a_in.nsrc; ++i) key.push_back(a_in.src[i].C);
     auto it = h->tuned.find(key);
     if (it != h->tuned.end()) return it->second;

@@ -26,6 +26,12 @@ struct TNode {
     // the launch that wrote g last, when that is a generic stride-1 data-gradient conv (else null): its epilogue
     // sees the COMPLETE gradient of this map and can take over the reductions of the BatchNorm backward
     ConvArgs *last_conv = nullptr;
+    // LAZY activation (round 6, precision mode 3): the post-BatchNorm map z = act(la[c] * y + lb[c]) is never written --
+    // t.p is the producing layer's raw conv output y, and every consumer forms z while it loads its operand (ConvSrc::la
+    // in conv_mfma.h; act = ReLU when lrelu).  null: t.p holds the values.  TB::materialise() turns a lazy node into a
+    // stored one (an affine_act pass appended to the forward) for a consumer that cannot form it.
+    const float *la = nullptr, *lb = nullptr;
+    bool lrelu = true;
 };
 
 struct PackJob {           // dgrad panel refreshed from the master weights before every forward
@@ -123,7 +129,7 @@ namespace {
 struct TB {   // train plan builder
     mc_handle *h;
     TrainState *ts;
-    std::map<const float *, int> pooled;
+    std::map<int, int> pooled;      // node -> its 2x2 max-pooled node
     void *last_panel16 = nullptr;   // bf16 twin of the panel the last pack_job() made
 
     static constexpr int AMAX_SLOTS = 1024;
@@ -218,10 +224,39 @@ struct TB {   // train plan builder
         for (char c : ts->bwd_side) k += c != 0;
         return k - 1;
     }
-    int node(int B, int H, int W, int C, bool needs_grad = true) {
+    // MONOCON_HIP_LAZY_Z (bit mask, default 15): which post-BatchNorm activations are never stored (TNode::la).  1: the
+    // BatchNorm + ReLU outputs without residual (stem, level0 / level1, BasicBlock conv1, Root, neck proj / node); 2: a
+    // Tree's `project` branch (BatchNorm without ReLU, consumed as the residual of the block beside it); 0: every
+    // activation is stored (rounds 1-5).  Outputs of a residual add are always stored.
+    int lazy_mask = [] { const char *e = std::getenv("MONOCON_HIP_LAZY_Z"); return e ? std::atoi(e) : 3; }();
+    int n_lazy = 0, n_materialised = 0;
+    // a consumer that cannot form a lazy activation on load: store it after all (one element-wise pass appended to the
+    // forward at this point of the build -- i.e. before the consumer's own launch -- and the node is an ordinary one from
+    // here on; earlier consumers keep reading y).  Its max-|z| slot already holds bn_finalize's bound.
+    void materialise(int node_i) {
+        TNode &n = ts->nodes[node_i];
+        if (!n.la) return;
+        float *z = alloc_map(n.t.numel());
+        const float *y = n.t.p, *la = n.la, *lb = n.lb;
+        const int B = n.t.B, C = n.t.C, rl = n.lrelu ? 1 : 0;
+        const size_t rows = (size_t)n.t.H * n.t.W;
+        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
+            HIPCHK(hh, launch_affine_act(y, la, lb, nullptr, B, rows, C, 0, rl, z, st, nullptr));
+            return 0;
+        });
+        if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
+            fprintf(stderr, "[plan] lazy node %d (%d ch %dx%d) materialised for a consumer that cannot form it on load\n", node_i, C, n.t.H, n.t.W);
+        n.t.p = z; n.la = n.lb = nullptr;
+        ++n_materialised;
+    }
+    void fill_src(ConvSrc &s, int node_i) {
+        const TNode &n = ts->nodes[node_i];
+        s.p = n.t.p; s.C = n.t.C; s.la = n.la; s.lb = n.lb;
+    }
+    int node(int B, int H, int W, int C, bool needs_grad = true, bool storage = true) {
         TNode n;
         n.t.B = B; n.t.H = H; n.t.W = W; n.t.C = C;
-        n.t.p = alloc_map(n.t.numel());
+        n.t.p = storage ? alloc_map(n.t.numel()) : nullptr;
         n.t.amax = slot();
         n.needs_grad = needs_grad;
         if (needs_grad && !pool_on) n.g = alloc(n.t.numel());
@@ -248,14 +283,16 @@ struct TB {   // train plan builder
 
     // ---------------------------------------------------------------- forward pieces
     void bn_train_ops(const Tensor &y, const float *stats, int nb, int cstride, const std::string &bn, float eps,
-                      float mom, float *a, float *b, float *mean, float *rstd) {
+                      float mom, float *a, float *b, float *mean, float *rstd, const unsigned *ymax = nullptr,
+                      unsigned *zmax = nullptr, int zrelu = 1) {
         float *g = P(bn + ".weight"), *be = P(bn + ".bias"), *rm = P(bn + ".running_mean"), *rv = P(bn + ".running_var");
         long long *nbt = NBT(bn + ".num_batches_tracked");
         const double n = (double)y.B * y.H * y.W;
         const int C = y.C;
         double *fold = fold_scratch(nb, C);
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_bn_finalize(stats, nb, cstride, n, C, rm, g, be, eps, mom, rm, rv, nbt, a, b, mean, rstd, st, fold));
+            HIPCHK(hh, launch_bn_finalize(stats, nb, cstride, n, C, rm, g, be, eps, mom, rm, rv, nbt, a, b, mean, rstd, st, fold,
+                                          ymax, zmax, zrelu));
             return 0;
         });
     }
@@ -268,13 +305,15 @@ struct TB {   // train plan builder
         r.kind = REC_CONV; r.L = &Lr; r.srcs = srcs; r.res = res; r.relu = relu; r.dead = dead; r.bn = Lr.bn;
         r.y.B = B; r.y.H = Ho; r.y.W = Wo; r.y.C = Lr.cout;
         r.y.p = alloc(r.y.numel());
-        r.z = dead ? -1 : node(B, Ho, Wo, Lr.cout);
+        // lazy output: BatchNorm (+ ReLU) without residual in mode 3 (the convs of every kernel family leave max |y|)
+        const bool lazy = !dead && res < 0 && h->prec == 3 && (lazy_mask & (relu ? 1 : 2)) != 0;
+        r.z = dead ? -1 : node(B, Ho, Wo, Lr.cout, true, !lazy);
         ConvArgs a{};
         a.nsrc = (int)srcs.size();
         int cin = 0;
         for (int i = 0; i < a.nsrc; ++i) {
-            a.src[i].p = ts->nodes[srcs[i]].t.p;
-            a.src[i].C = ts->nodes[srcs[i]].t.C;
+            if (ts->nodes[srcs[i]].la && !ts->nodes[srcs[i]].lrelu) materialise(srcs[i]);     // (a conv forms ReLU'd maps only)
+            fill_src(a.src[i], srcs[i]);
             cin += a.src[i].C;
         }
         if (cin != Lr.cin) { ts->ok = false; h->err = "train plan: channel mismatch at " + Lr.conv; }
@@ -285,6 +324,15 @@ struct TB {   // train plan builder
             for (int i = 0; i < a.nsrc; ++i) a.amax_in[i] = ts->nodes[srcs[i]].t.amax;
             a.amax_w = Lr.w_amax;
         }
+        {
+            bool any_lazy = false;
+            for (int i = 0; i < a.nsrc; ++i) any_lazy |= a.src[i].la != nullptr;
+            if (any_lazy && !conv_lazy_capable(a, Lr.ks, Lr.stride)) {
+                for (int i = 0; i < a.nsrc; ++i) { materialise(srcs[i]); fill_src(a.src[i], srcs[i]); }
+            }
+        }
+        unsigned *yslot = lazy ? slot() : nullptr;      // max |y|, left by the conv's epilogue: bn_finalize bounds max |z| with it
+        a.amax_out = yslot;
         a.cfg = ts->ok ? mc_choose_conv_cfg(h, a, Lr.ks, Lr.stride) : CFG_128x32;
         const int chunks = conv_chunks_per_image(a.cfg, Ho, Wo);
         float *stats = alloc((size_t)B * chunks * Lr.coutp * 2);
@@ -295,15 +343,23 @@ struct TB {   // train plan builder
         float *ca = alloc(Lr.cout), *cb = alloc(Lr.cout);
         r.ca = ca; r.cb = cb;
         r.mean = alloc(Lr.cout); r.rstd = alloc(Lr.cout);
-        bn_train_ops(r.y, stats, B * chunks, Lr.coutp, Lr.bn, 1e-5f, 0.1f, ca, cb, r.mean, r.rstd);
-        if (!dead) {
-            const float *yp = r.y.p, *rp = res >= 0 ? ts->nodes[res].t.p : nullptr;
+        bn_train_ops(r.y, stats, B * chunks, Lr.coutp, Lr.bn, 1e-5f, 0.1f, ca, cb, r.mean, r.rstd, yslot,
+                     lazy ? ts->nodes[r.z].t.amax : nullptr, relu ? 1 : 0);
+        if (lazy) {
+            TNode &zn = ts->nodes[r.z];
+            zn.t.p = r.y.p; zn.la = ca; zn.lb = cb; zn.lrelu = relu;
+            ++n_lazy;
+        } else if (!dead) {
+            const TNode &rn = ts->nodes[res >= 0 ? res : 0];
+            const float *yp = r.y.p, *rp = res >= 0 ? rn.t.p : nullptr;
+            const float *ra = res >= 0 ? rn.la : nullptr, *rb = res >= 0 ? rn.lb : nullptr;     // the residual may be lazy
+            const int rrelu = (res >= 0 && rn.lrelu) ? 1 : 0;
             float *zp = ts->nodes[r.z].t.p;
             unsigned *zmax = ts->nodes[r.z].t.amax;
             const size_t rows = (size_t)Ho * Wo;
             const int C = Lr.cout, rl = relu;
             ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_affine_act(yp, ca, cb, rp, B, rows, C, 0, rl, zp, st, zmax));
+                HIPCHK(hh, launch_affine_act(yp, ca, cb, rp, B, rows, C, 0, rl, zp, st, zmax, ra, rb, rrelu));
                 return 0;
             });
         }
@@ -313,33 +369,36 @@ struct TB {   // train plan builder
 
     int pool(int x) {
         const Tensor t = ts->nodes[x].t;           // by value (see conv_bn)
-        auto it = pooled.find(t.p);
+        auto it = pooled.find(x);
         if (it != pooled.end()) return it->second;
+        if (ts->nodes[x].la && !ts->nodes[x].lrelu) materialise(x);
+        const Tensor tx = ts->nodes[x].t;
         const int o = node(t.B, t.H / 2, t.W / 2, t.C, true);
         ts->nodes[o].t.amax = t.amax;          // max |pool(x)| <= max |x|: the input's slot serves
-        const float *ip = t.p;
+        const float *ip = tx.p, *la = ts->nodes[x].la, *lb = ts->nodes[x].lb;      // (lazy x: pooled over relu(la * y + lb))
         float *op = ts->nodes[o].t.p;
         const int B = t.B, H = t.H, W = t.W, C = t.C;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_maxpool2(ip, B, H, W, C, op, st));
+            HIPCHK(hh, launch_maxpool2(ip, B, H, W, C, op, st, la, lb));
             return 0;
         });
         Rec r;
         r.kind = REC_POOL; r.in = x; r.z = o;
         ts->recs.push_back(r);
-        pooled[t.p] = o;
+        pooled[x] = o;
         return o;
     }
 
     int deconv(DeconvLayer &D, int x) {
+        if (ts->nodes[x].la && !ts->nodes[x].lrelu) materialise(x);
         const Tensor t = ts->nodes[x].t;           // by value (see conv_bn)
         const int o = node(t.B, t.H * 2, t.W * 2, t.C, true);
-        const float *ip = t.p, *w = D.wpk;
+        const float *ip = t.p, *w = D.wpk, *la = ts->nodes[x].la, *lb = ts->nodes[x].lb;
         float *op = ts->nodes[o].t.p;
         unsigned *omax = ts->nodes[o].t.amax;
         const int B = t.B, H = t.H, W = t.W, C = t.C;
         ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_deconv4(ip, B, H, W, C, w, op, st, omax));
+            HIPCHK(hh, launch_deconv4(ip, B, H, W, C, w, op, st, omax, la, lb));
             return 0;
         });
         Rec r;
@@ -478,19 +537,30 @@ struct TB {   // train plan builder
     void emit_wgrad(const std::vector<int> &srcs, const Tensor &dy, int dy_ld, int Cout, int ks, int stride, float *dw) {
         WgradArgs a{};
         a.nsrc = (int)srcs.size();
-        int cin = 0;
-        for (int i = 0; i < a.nsrc; ++i) {
-            a.src[i].p = ts->nodes[srcs[i]].t.p;
-            a.src[i].C = ts->nodes[srcs[i]].t.C;
-            a.amax_x[i] = ts->nodes[srcs[i]].t.amax;
-            cin += a.src[i].C;
-        }
+        auto fill = [&] {
+            int cin = 0;
+            for (int i = 0; i < a.nsrc; ++i) {
+                fill_src(a.src[i], srcs[i]);
+                a.amax_x[i] = ts->nodes[srcs[i]].t.amax;
+                cin += a.src[i].C;
+            }
+            return cin;
+        };
+        for (int s_ : srcs)
+            if (ts->nodes[s_].la && !ts->nodes[s_].lrelu) materialise(s_);
+        int cin = fill();
         a.amax_dy = dy.amax;
         const Tensor &s0 = ts->nodes[srcs[0]].t;
         a.B = s0.B; a.Hin = s0.H; a.Win = s0.W; a.Hout = dy.H; a.Wout = dy.W; a.Cin = cin; a.Cout = Cout;
         a.dy = dy.p; a.dy_ld = dy_ld;
         a.prec = h->prec;
         wgrad_plan(a, ks, stride);
+        bool any_lazy = false;
+        for (int i = 0; i < a.nsrc; ++i) any_lazy |= a.src[i].la != nullptr;
+        if (any_lazy && !wgrad_lazy_capable(a, ks, stride)) {      // X is read by a kernel that cannot form it: store it after all
+            for (int s_ : srcs) materialise(s_);
+            fill();
+        }
         a.partial = alloc(wgrad_partial_floats(a, ks));
         ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_wgrad(a, ks, stride, dw, st)); return 0; });
     }
@@ -611,7 +681,9 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     stem.kind = REC_STEM; stem.bn = "backbone.base_layer.1"; stem.relu = true;
     stem.y.B = B; stem.y.H = H; stem.y.W = W; stem.y.C = 16;
     stem.y.p = b.alloc(stem.y.numel());
-    stem.z = b.node(B, H, W, 16);
+    // (mode 3 with the fp16-pipe stem, which leaves max |y|: the stem's activation is lazy like conv_bn's, TNode::la)
+    const bool stem_lazy = h->prec == 3 && stem_f16_enabled() && (b.lazy_mask & 1);
+    stem.z = b.node(B, H, W, 16, true, !stem_lazy);
     float *ones16 = b.alloc(16), *zeros16 = b.alloc(16);
     {
         std::vector<float> one(16, 1.f);
@@ -638,11 +710,19 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             }
             return 0;
         });
-        b.bn_train_ops(stem.y, partial, nb, 16, stem.bn, 1e-5f, 0.1f, ca, cb, stem.mean, stem.rstd);
-        ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-            HIPCHK(hh, launch_affine_act(yp, ca, cb, nullptr, B, (size_t)H * W, 16, 0, 1, zp, st, zmax));
-            return 0;
-        });
+        b.bn_train_ops(stem.y, partial, nb, 16, stem.bn, 1e-5f, 0.1f, ca, cb, stem.mean, stem.rstd, stem_lazy ? ymax : nullptr,
+                       stem_lazy ? zmax : nullptr, 1);
+        stem.ca = ca; stem.cb = cb;
+        if (stem_lazy) {
+            TNode &zn = ts->nodes[stem.z];
+            zn.t.p = yp; zn.la = ca; zn.lb = cb; zn.lrelu = true;
+            ++b.n_lazy;
+        } else {
+            ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
+                HIPCHK(hh, launch_affine_act(yp, ca, cb, nullptr, B, (size_t)H * W, 16, 0, 1, zp, st, zmax));
+                return 0;
+            });
+        }
         ts->recs.push_back(stem);
     }
     const int x0 = stem.z;
@@ -694,12 +774,17 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
     }
     ConvArgs c3{};
     {
+        c3.nsrc = 1;
+        b.fill_src(c3.src[0], feat);
         const TNode &fn = ts->nodes[feat];
-        c3.nsrc = 1; c3.src[0].p = fn.t.p; c3.src[0].C = 64;
         c3.B = B; c3.Hin = fh; c3.Win = fw; c3.Hout = fh; c3.Wout = fw; c3.Cin = 64; c3.Cout = CP; c3.CoutP = h->head3.coutp;
         c3.wpk = h->head3.wpk; c3.bias = h->head_bias; c3.out = xh.p; c3.out_ld = CP; c3.cfg = h->head3.cfg;
         c3.wpk16 = h->head3.wpk16; c3.prec = h->prec;
         if (h->prec == 3) { c3.amax_in[0] = fn.t.amax; c3.amax_w = h->head3.w_amax; }
+        if (c3.src[0].la && (!fn.lrelu || !conv_lazy_capable(c3, 3, 1))) {
+            b.materialise(feat);
+            b.fill_src(c3.src[0], feat);
+        }
         at.chunks = conv_chunks_per_image(c3.cfg, fh, fw);
         at.stat_ld = h->head3.coutp;
         float *stats = b.alloc((size_t)B * at.chunks * at.stat_ld * 2);
@@ -873,11 +958,11 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             TNode &in = ts->nodes[r.in];
             const TNode &o = ts->nodes[r.z];
             if (!o.ginit || !in.needs_grad) continue;
-            const float *xp = in.t.p, *go = o.g;
+            const float *xp = in.t.p, *go = o.g, *xla = in.la, *xlb = in.lb;      // (lazy x: its ReLU'd values are compared)
             float *gi = b.g_acquire(r.in);
             const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C, acc = in.ginit;
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_maxpool2_bwd(xp, go, Bq, Hq, Wq, Cq, gi, acc, st));
+                HIPCHK(hh, launch_maxpool2_bwd(xp, go, Bq, Hq, Wq, Cq, gi, acc, st, xla, xlb));
                 return 0;
             });
             in.ginit = true;
@@ -888,13 +973,13 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             const TNode &o = ts->nodes[r.z];
             if (!o.ginit) continue;
             if (in.ginit) { ts->ok = false; h->err = "train plan: deconv input has more than one consumer"; }
-            const float *xp = in.t.p, *go = o.g, *wp = r.D->wpk;
+            const float *xp = in.t.p, *go = o.g, *wp = r.D->wpk, *xla = in.la, *xlb = in.lb;
             float *gi = b.g_acquire(r.in), *dw = b.G(r.D->name + ".weight");
             const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C;
             float *part = b.alloc(deconv4_bwd_w_partial_floats(Bq, Hq, Cq));
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 HIPCHK(hh, launch_deconv4_bwd_data(go, Bq, Hq, Wq, Cq, wp, gi, st));
-                HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st));
+                HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st, xla, xlb));
                 return 0;
             });
             in.ginit = true;
@@ -944,6 +1029,9 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         });
     }
     if (!ts->ok) return nullptr;
+    if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
+        fprintf(stderr, "[plan] lazy activations: %d never stored, %d stored after all (lazy mask %d), %.2f GB\n", b.n_lazy - b.n_materialised,
+                b.n_materialised, b.lazy_mask, ts->bytes * 1e-9);
     if (h->dry_alloc) return tsp.release();   // mc_query_workspace: sizes only
     ts->bwd_side.resize(ts->bwd.size(), 0);
     if (const char *e = std::getenv("MONOCON_HIP_DUAL_STREAM")) ts->dual = std::atoi(e) != 0;
@@ -1096,6 +1184,15 @@ int mc_train_debug_node(mc_handle *h, int node, int which, float *out_nchw, int 
     const float *src = which ? n.g : n.t.p;
     if (!src) return fail(h, "mc_train_debug_node: node has no such buffer");
     hipStream_t dst_st = static_cast<hipStream_t>(stream);
+    if (!which && n.la) {       // a lazy activation exists nowhere in memory: form it for the caller
+        ScratchBuf tmp;
+        HIPCHK(h, tmp.alloc(n.t.numel() * sizeof(float)));
+        HIPCHK(h, launch_affine_act(n.t.p, n.la, n.lb, nullptr, n.t.B, (size_t)n.t.H * n.t.W, n.t.C, 0, n.lrelu ? 1 : 0, tmp.as<float>(),
+                                    dst_st, nullptr));
+        HIPCHK(h, launch_nhwc_to_nchw(tmp.as<float>(), n.t.B, n.t.C, n.t.H, n.t.W, out_nchw, dst_st));
+        HIPCHK(h, hipStreamSynchronize(dst_st));
+        return 0;
+    }
     HIPCHK(h, launch_nhwc_to_nchw(src, n.t.B, n.t.C, n.t.H, n.t.W, out_nchw, dst_st));
     return 0;
 }

@@ -111,10 +111,12 @@ hipError_t launch_chan_reduce(const float *y, const float *dz, const float *z, c
 hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *shift,
                               const float *gamma, const float *beta, float eps, float momentum, float *rm, float *rv,
                               long long *nbt, float *a, float *b, float *mean, float *rstd, hipStream_t st,
-                              double *fold = nullptr);
+                              double *fold = nullptr, const unsigned *ymax = nullptr, unsigned *zmax = nullptr, int zrelu = 1);
+// (ymax / zmax: a lazy activation's bound of max |z| from max |y| -- see bn_finalize_kernel)
 size_t partial_fold_doubles(int nb, int C);   // scratch for `fold` (0: the partial list is short, no pre-pass)
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
-                             int C, int per_sample, int relu, float *z, hipStream_t st, unsigned *amax = nullptr);
+                             int C, int per_sample, int relu, float *z, hipStream_t st, unsigned *amax = nullptr,
+                             const float *res_a = nullptr, const float *res_b = nullptr, int res_relu = 0);   // lazy residual
 hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
                                   const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
                                   hipStream_t st, double *fold = nullptr);
@@ -129,12 +131,12 @@ size_t colsum_partial_floats(size_t rows, int ld);
 hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st);
 hipError_t launch_colsum_final(const float *partial, int nb, int C, float *out, hipStream_t st);   // partial [nb][C][2] -> out[C]
 hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
-                               hipStream_t st);
+                               hipStream_t st, const float *la = nullptr, const float *lb = nullptr);   // la / lb: lazy x (ConvSrc::la)
 hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C, const float *wpk, float *din,
                                    hipStream_t st);
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C);
 hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
-                                hipStream_t st);
+                                hipStream_t st, const float *la = nullptr, const float *lb = nullptr);   // la / lb: lazy in
 
 // ---- head / stem train kernels (kernels_head_train.hip)
 hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
@@ -194,6 +196,9 @@ struct WgradArgs {
 void wgrad_plan(WgradArgs &a, int ks, int stride);            // fills the tiling fields
 size_t wgrad_partial_floats(const WgradArgs &a, int ks);
 hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st);
+// lazy X sources (ConvSrc::la in conv_mfma.h): does the kernel wgrad_plan() chose for `a` form them on load?  (mode 3:
+// wgrad_pipe_kernel's default tile, wgrad_bf16_kernel<SPL = 2>, wgrad_thin16_kernel; anything else fails such a launch)
+bool wgrad_lazy_capable(const WgradArgs &a, int ks, int stride);
 bool wgrad_bf16_ok(const WgradArgs &a, int ks, int stride);
 hipError_t launch_wgrad_bf16(const WgradArgs &a, int ks, int stride, int WN, int WC, hipStream_t st);
 int wgrad_bf16_patches(int prec);

@@ -84,7 +84,8 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __device__ int g_phase_delay = 0, g_phase_mode = 0;
 __device__ unsigned *g_lds_dbg = nullptr;
 #endif
-template <int KS, int S, int WN, int WC, int SPL>
+// LZ (SPL == 2): some source of X is a lazy tensor (ConvSrc::la in conv_mfma.h) -- see wgrad_pipe_kernel
+template <int KS, int S, int WN, int WC, int SPL, bool LZ = false>
 // stride 2 stages 2.7x the halo of stride 1 (6 instead of 2 float4 pairs per thread in flight across the MFMA phase): at
 // two workgroups per CU (256 registers) the kernel spills 17-23 registers; one workgroup per CU without spills is faster
 // (one-session A/B, weight-gradient bucket per step: fp32 kernel 14.6 ms, two per CU 14.0, one per CU 13.6)
@@ -185,6 +186,19 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
 #endif
     constexpr int PD = MC_WG16_PD;
     f32x4 xv[PD][PB][NIX][2], dv[PD][PB][NID][2];
+    // lazy X: the workgroup's c-tile lies in ONE source; the thread's channel quad keeps its coefficients (operand scale
+    // folded in); okm bit 2i + k = pixel k of item i lies inside the image (padding stays 0, not relu(lb))
+    static_assert(!LZ || SPL == 2, "lazy sources: the fp16-split mode");
+    const bool lz = LZ && a.src[si].la != nullptr;
+    f32x4 lzA = {0.f, 0.f, 0.f, 0.f}, lzB = lzA;
+    if (LZ && lz && xc_ok) {
+        lzA = *reinterpret_cast<const f32x4 *>(a.src[si].la + cs0 + xc4 * 4);
+        lzB = *reinterpret_cast<const f32x4 *>(a.src[si].lb + cs0 + xc4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lzA[j] *= x_scale; lzB[j] *= x_scale; }
+    }
+    [[maybe_unused]] const unsigned x_bytes = (unsigned)(a.Hin * a.Win * Cs) * 4u;
+    [[maybe_unused]] unsigned okm[PD][PB];
     auto fetch = [&](int gi, int p, int slot) {
         // (wave-uniform by construction; the integer division runs on the vector ALU, so say so -- otherwise every
         //  buffer load below is wrapped in a readfirstlane "waterfall" loop over its descriptor)
@@ -202,12 +216,16 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
         // (one UNSIGNED compare per pixel: with `xx >= 0 && xx < W` hipcc branches on the shared half of the two conditions
         //  and, since both arms load into the same registers, puts s_waitcnt vmcnt(0) between them -- a full memory latency
         //  in front of the MFMAs of every group.  Dead items carry a column far outside either way.)
+        if constexpr (LZ) okm[slot][p] = 0u;
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
             const int xx = ox * S + x_ix[i];
             const bool in0 = (unsigned)xx < (unsigned)a.Win, in1 = (unsigned)(xx + XSTEP) < (unsigned)a.Win;
-            xv[slot][p][i][0] = buf_load4(r_x, in0 ? xb + x_stat[i] : BUF_OOB, 0);
-            xv[slot][p][i][1] = buf_load4(r_x, in1 ? xb + x_stat[i] + XSTEP * Cs * 4 : BUF_OOB, 0);
+            const int vo0 = in0 ? xb + x_stat[i] : BUF_OOB, vo1 = in1 ? xb + x_stat[i] + XSTEP * Cs * 4 : BUF_OOB;
+            xv[slot][p][i][0] = buf_load4(r_x, vo0, 0);
+            xv[slot][p][i][1] = buf_load4(r_x, vo1, 0);
+            // (the column is inside: the offset is inside the image's bytes <=> the row is)
+            if constexpr (LZ) okm[slot][p] |= (((unsigned)vo0 < x_bytes ? 1u : 0u) | ((unsigned)vo1 < x_bytes ? 2u : 0u)) << (2 * i);
         }
 #pragma unroll
         for (int i = 0; i < NID; ++i) {
@@ -237,6 +255,20 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
 #pragma unroll
         for (int i = 0; i < NIX; ++i)
             if (NT * (i + 1) <= XP || tid + NT * i < XP) {
+                if constexpr (LZ) {
+                    if (lz) {
+                        const float cap0 = ((okm[slot][p] >> (2 * i)) & 1u) ? __builtin_inff() : 0.f;
+                        const float cap1 = ((okm[slot][p] >> (2 * i + 1)) & 1u) ? __builtin_inff() : 0.f;
+                        f32x4 t0, t1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            t0[j] = lazy_act(xv[slot][p][i][0][j], lzA[j], lzB[j], cap0);
+                            t1[j] = lazy_act(xv[slot][p][i][1][j], lzA[j], lzB[j], cap1);
+                        }
+                        put(xt + p * CB * XCH + x_dst[i], XPL, t0, t1, XCH, 1.f);
+                        continue;
+                    }
+                }
                 put(xt + p * CB * XCH + x_dst[i], XPL, xv[slot][p][i][0], xv[slot][p][i][1], XCH, x_scale);
             }
 #pragma unroll
@@ -364,11 +396,18 @@ __global__ __launch_bounds__(64 * WN * WC, S == 2 ? MC_WG16_S2_OCC : 2) void wgr
     }
 }
 
-template <int KS, int S, int WN, int WC, int SPL>
+template <int KS, int S, int WN, int WC, int SPL, bool LZ = false>
 static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
     using Cfg = WgB16Cfg<KS, S, WN, WC, SPL>;
     if (a.pb != Cfg::PB) return hipErrorInvalidValue;
-    auto kern = wgrad_bf16_kernel<KS, S, WN, WC, SPL>;
+    if constexpr (!LZ) {
+        for (int i = 0; i < a.nsrc; ++i)
+            if (a.src[i].la) {
+                if constexpr (SPL == 2) return launch_wg16<KS, S, WN, WC, SPL, true>(a, st);
+                else return hipErrorInvalidValue;
+            }
+    }
+    auto kern = wgrad_bf16_kernel<KS, S, WN, WC, SPL, LZ>;
     static bool attr_set = false;
     // experiment knob (only with -DMC_DEBUG_HOOKS): MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the
     // workgroups per CU

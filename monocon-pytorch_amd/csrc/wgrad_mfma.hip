@@ -429,7 +429,16 @@ void wgrad_plan(WgradArgs &a, int ks, int stride) {
 }
 size_t wgrad_partial_floats(const WgradArgs &a, int ks) { return (size_t)a.ksplit * ks * ks * a.Cout * a.Cin; }
 
+bool wgrad_lazy_capable(const WgradArgs &a, int ks, int stride) {
+    if (a.prec != 3) return false;
+    if (a.pipe) return a.pipe == 4;
+    if (a.small) return wgrad_thin_ok(a, ks, stride);
+    return wgrad_sources_ok(a) && wgrad_bf16_ok(a, ks, stride);
+}
+
 hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, hipStream_t st) {
+    for (int i = 0; i < a.nsrc; ++i)
+        if (a.src[i].la && !wgrad_lazy_capable(a, ks, stride)) return hipErrorInvalidValue;
     prof_last = {2, 2.0 * a.B * a.Hout * a.Wout * (double)a.Cout * a.Cin * ks * ks,
                  4.0 * ((double)a.B * a.Hin * a.Win * a.Cin + (double)a.B * a.Hout * a.Wout * a.Cout + (double)ks * ks * a.Cin * a.Cout)};
     hipError_t e = hipErrorInvalidValue;

@@ -57,7 +57,9 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float s, unsigned
 
 __device__ __forceinline__ void wp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KS, int WN, int WC, int WK>
+// LZ: some source of X is a lazy tensor (ConvSrc::la in conv_mfma.h: raw conv output + BatchNorm coefficients, its value
+// max(fma(y, la, lb), 0) formed while X is staged); its own instantiation, so that every other launch keeps its registers
+template <int KS, int WN, int WC, int WK, bool LZ = false>
 // (the 4-wave build is meant to SHARE a CU with whatever the main stream runs: at most half of a SIMD's registers)
 __global__ __launch_bounds__(64 * WN * WC * WK, WN * WC * WK == 4 ? 2 : 1) void wgrad_pipe_kernel(const WgradArgs a) {
     using Cfg = WgPipeCfg<KS, WN, WC, WK>;
@@ -129,6 +131,29 @@ __global__ __launch_bounds__(64 * WN * WC * WK, WN * WC * WK == 4 ? 2 : 1) void 
     }
 
     f32x4 xv[2][NIX][2], dv[2][NID][2];       // two register sets of raw fp32 data: groups g + 1 and g + 2 while g runs
+    // lazy X: the workgroup's c-tile lies in ONE source.  The coefficients of the tile's CB channels (operand scale folded in)
+    // wait in LDS behind the two tile buffers and are read back per staged item: kept in registers (8 of them) the kernel
+    // spilled, and a scratch reload is a vector-memory load -- it retires on the same in-order counter as the prefetched
+    // groups, i.e. it waits for them (measured, round 6: 0.24 -> 0.37 ms per launch).  okm[slot] bit 2i + k = pixel k of item
+    // i lies inside the image (padding stays 0, not relu(lb)).
+    const bool lz = LZ && a.src[si].la != nullptr;
+    [[maybe_unused]] f32x4 *lz_tab = reinterpret_cast<f32x4 *>(lds_raw + 2 * BUF);      // [2][XC4]: A, B per channel quad
+    if constexpr (LZ) {
+        if (lz && tid < XC4) {
+            f32x4 cA = {0.f, 0.f, 0.f, 0.f}, cB = cA;
+            if (cs0 + tid * 4 < Cs && c0 + tid * 4 < a.Cin) {
+                cA = *reinterpret_cast<const f32x4 *>(a.src[si].la + cs0 + tid * 4);
+                cB = *reinterpret_cast<const f32x4 *>(a.src[si].lb + cs0 + tid * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cA[j] *= x_scale; cB[j] *= x_scale; }
+            lz_tab[tid] = cA;
+            lz_tab[XC4 + tid] = cB;
+        }
+        __syncthreads();
+    }
+    [[maybe_unused]] const unsigned x_bytes = (unsigned)(a.Hin * a.Win * Cs) * 4u;
+    [[maybe_unused]] unsigned okm[2] = {0u, 0u};
     auto fetch = [&](int gi, auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
         const int img = __builtin_amdgcn_readfirstlane(gi / a.groups_per_img);
@@ -144,12 +169,16 @@ __global__ __launch_bounds__(64 * WN * WC * WK, WN * WC * WK == 4 ? 2 : 1) void 
         // (one UNSIGNED compare per pixel: with `xx >= 0 && xx < W` hipcc branches on the shared half of the two conditions
         //  and, since both arms load into the same registers, puts s_waitcnt vmcnt(0) between them -- a full memory latency
         //  in the middle of the MFMA stream, every group)
+        if constexpr (LZ) okm[slot] = 0u;
 #pragma unroll
         for (int i = 0; i < NIX; ++i) {
             const int xx = ox + x_ix[i];
             const bool in0 = (unsigned)xx < (unsigned)a.Win, in1 = (unsigned)(xx + 1) < (unsigned)a.Win;
-            xv[slot][i][0] = buf_load4(r_x, in0 ? xb + x_stat[i] : BUF_OOB, 0);
-            xv[slot][i][1] = buf_load4(r_x, in1 ? xb + x_stat[i] + Cs * 4 : BUF_OOB, 0);
+            const int vo0 = in0 ? xb + x_stat[i] : BUF_OOB, vo1 = in1 ? xb + x_stat[i] + Cs * 4 : BUF_OOB;
+            xv[slot][i][0] = buf_load4(r_x, vo0, 0);
+            xv[slot][i][1] = buf_load4(r_x, vo1, 0);
+            // (the column is inside: the offset is inside the image's bytes <=> the row is)
+            if constexpr (LZ) okm[slot] |= (((unsigned)vo0 < x_bytes ? 1u : 0u) | ((unsigned)vo1 < x_bytes ? 2u : 0u)) << (2 * i);
         }
 #pragma unroll
         for (int i = 0; i < NID; ++i) {
@@ -172,6 +201,21 @@ __global__ __launch_bounds__(64 * WN * WC * WK, WN * WC * WK == 4 ? 2 : 1) void 
     // part `part` of `parts` of the conversion of register set `slot` into tile buffer `buf`
     auto store_x = [&](unsigned char *buf, auto slot_c, int i) {
         constexpr int slot = decltype(slot_c)::value;
+        if constexpr (LZ) {
+            if (lz) {
+                const float cap0 = ((okm[slot] >> (2 * i)) & 1u) ? __builtin_inff() : 0.f;
+                const float cap1 = ((okm[slot] >> (2 * i + 1)) & 1u) ? __builtin_inff() : 0.f;
+                const f32x4 lzA = lz_tab[xc4], lzB = lz_tab[XC4 + xc4];
+                f32x4 t0, t1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t0[j] = lazy_act(xv[slot][i][0][j], lzA[j], lzB[j], cap0);
+                    t1[j] = lazy_act(xv[slot][i][1][j], lzA[j], lzB[j], cap1);
+                }
+                put(buf + x_dst[i], XPL, t0, t1, XCH, 1.f);
+                return;
+            }
+        }
         put(buf + x_dst[i], XPL, xv[slot][i][0], xv[slot][i][1], XCH, x_scale);
     };
     auto store_d = [&](unsigned char *buf, auto slot_c, int i) {
@@ -279,19 +323,27 @@ __global__ __launch_bounds__(64 * WN * WC * WK, WN * WC * WK == 4 ? 2 : 1) void 
     }
 }
 
-template <int KS, int WN, int WC, int WK>
+template <int KS, int WN, int WC, int WK, bool LZ = false>
 static hipError_t launch_wp(const WgradArgs &a, hipStream_t st) {
     using Cfg = WgPipeCfg<KS, WN, WC, WK>;
-    auto kern = wgrad_pipe_kernel<KS, WN, WC, WK>;
+    if constexpr (!LZ) {
+        for (int i = 0; i < a.nsrc; ++i)
+            if (a.src[i].la) {
+                if constexpr (WN == 2 && WC == 2 && WK == 1) return launch_wp<KS, WN, WC, WK, true>(a, st);      // (the default tile)
+                else return hipErrorInvalidValue;
+            }
+    }
+    auto kern = wgrad_pipe_kernel<KS, WN, WC, WK, LZ>;
+    constexpr size_t lds_bytes = Cfg::LDS_BYTES + (LZ ? 2 * (Cfg::CB / 4) * 16 : 0);      // (+ the lazy coefficient table)
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)Cfg::LDS_BYTES);
+                                           (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     if (a.ksplit % WK) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kern, dim3((a.ksplit / WK) * a.n_tiles * a.c_tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, dim3((a.ksplit / WK) * a.n_tiles * a.c_tiles), dim3(Cfg::NT), lds_bytes, st, a);
     return hipGetLastError();
 }
 
