@@ -760,6 +760,7 @@ inline int conv_chunks_per_image(int cfg, int Hout, int Wout) {
     return ((Wout + 7) / 8) * ((Hout + 3) / 4);           // every tiling: one partial per 4x8 patch
 }
 bool conv_small_ok(const ConvArgs &a, int ks, int stride);
+bool conv_small_lazy_ok(const ConvArgs &a, int ks, int stride);     // conv_small_kernel<2, 16, 2, LZ>: lazy source (ConvSrc::la)
 bool conv_bf16_ok(const ConvArgs &a, int ks, int stride);
 hipError_t launch_conv_bf16(const ConvArgs &a, int ks, int stride, hipStream_t st, ConvArgs *resolved);
 // nsplit: 1 = bf16, 3 = three bf16 pieces, 2 = two fp16 pieces of w * 2^e_w (amax: the weight tensor's max |w|, see ConvArgs)

@@ -104,7 +104,7 @@ int conv_pick_cfg(int Cout, int CoutP, int ks, int stride, int B, int Hout, int 
 
 bool conv_lazy_capable(const ConvArgs &a, int ks, int stride) {
     if (a.prec != 3 || a.bm_y) return false;
-    if (conv_thin_ok(a, ks, stride)) return true;
+    if (conv_thin_ok(a, ks, stride) || conv_small_lazy_ok(a, ks, stride)) return true;
     return conv_bf16_ok(a, ks, stride) && (ks == 3 || ks == 1);
 }
 
@@ -123,7 +123,7 @@ hipError_t launch_conv(const ConvArgs &a_in, int ks, int stride, hipStream_t st,
         if (sc[i] % ck) return hipErrorInvalidValue;
     if (a.cfg == CFG_SMALL) {
         if (!conv_small_ok(a, ks, stride)) return hipErrorInvalidValue;
-        if (lazy && !conv_thin_ok(a, ks, stride)) return hipErrorInvalidValue;      // (the fp32 row kernel does not form lazy sources)
+        if (lazy && !conv_thin_ok(a, ks, stride) && !conv_small_lazy_ok(a, ks, stride)) return hipErrorInvalidValue;
         a.ppr = (a.Wout + 7) / 8;
         a.ppi = a.ppr * ((a.Hout + 3) / 4);
         a.chunks = a.Hout;

@@ -27,8 +27,12 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef CS_PD
 #define CS_PD 2          // groups in flight ahead of the one being computed (A/B in one session: 1 -> 2 = -0.23 ms per step, 3 = slower)
 #endif
-template <int S, int CIN, int NTN>
+// LZ: the source is a lazy tensor (ConvSrc::la in conv_mfma.h: raw conv output + BatchNorm coefficients).  A lane always holds
+// channels 4 * kq .. + 3 of its pixels, so the coefficients stay in registers and max(fma(y, la, lb), 0) is formed in front of
+// the MFMAs (fp32 operands: no operand scale); padding stays 0 (`cap`: rows per descriptor, columns in the two edge groups).
+template <int S, int CIN, int NTN, bool LZ = false>
 __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
+    static_assert(!LZ || CIN == 16, "lazy source: the 16-channel layers");
     constexpr int KG = CIN / 16;          // 16-byte channel groups per lane and tap
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,6 +63,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     const float floor_v = a.relu ? 0.f : -__builtin_inff();
     float vmax = 0.f;                 // max |out| of this lane (ConvArgs::amax_out)
 
+    [[maybe_unused]] f32x4 lzA = {0.f, 0.f, 0.f, 0.f}, lzB = lzA;
+    if constexpr (LZ) {
+        lzA = reinterpret_cast<const f32x4 *>(a.src[0].la)[kq];
+        lzB = reinterpret_cast<const f32x4 *>(a.src[0].lb)[kq];
+    }
     const int vx = (li * S * CIN + kq * 4) * 4;                     // input lane offset inside a group
     constexpr int NR = (S == 1 && CIN == 16) ? 2 : 1;               // output rows per pass: a pair shares 2 of its 4 input rows
     constexpr int NI = (NR - 1) * S + 3;                            // input rows per pass
@@ -67,12 +76,14 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
     for (int pr = xcd_order(blockIdx.x, gridDim.x) * 4 + wave; pr < RP; pr += gridDim.x * 4) {
         const int img = pr / hp, oy = (pr - img * hp) * NR;
         __amdgpu_buffer_rsrc_t r_x[NI], r_out[NR], r_res[NR];
+        [[maybe_unused]] float rowcap[NI], ecap[3] = {0.f, 0.f, 0.f};      // LZ: 0 for padding rows / (edge groups) padding columns
 #pragma unroll
         for (int r = 0; r < NI; ++r) {
             const int iy = oy * S + r - 1;
             const bool ok = iy >= 0 && iy < a.Hin;
             r_x[r] = make_rsrc(a.src[0].p + ((size_t)img * a.Hin + (ok ? iy : 0)) * a.Win * CIN,
                                ok ? (unsigned)(a.Win * CIN) * 4u : 0u);
+            rowcap[r] = ok ? __builtin_inff() : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
@@ -101,10 +112,24 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
                             const int px = (x0 + li) * S + s - 1;
                             av[r * 3 + s][kg] = buf_load4(
                                 r_x[r], (px >= 0 && px < a.Win) ? (px * CIN + kg * 16 + kq * 4) * 4 : BUF_OOB, 0);
+                            if constexpr (LZ) ecap[s] = (px >= 0 && px < a.Win) ? __builtin_inff() : 0.f;
                         }
                     }
         };
-        auto compute = [&](int x0, const f32x4 (&av)[NI * 3][KG]) {
+        auto compute = [&](int x0, const f32x4 (&av_in)[NI * 3][KG], bool edge = false) {
+            f32x4 av[NI * 3][KG];
+#pragma unroll
+            for (int t = 0; t < NI * 3; ++t)
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) {
+                    if constexpr (LZ) {
+                        const float cap = edge ? fminf(rowcap[t / 3], ecap[t % 3]) : rowcap[t / 3];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) av[t][kg][jj] = lazy_act(av_in[t][kg][jj], lzA[jj], lzB[jj], cap);
+                    } else {
+                        av[t][kg] = av_in[t][kg];
+                    }
+                }
             f32x4v acc[NR][NTN];
 #pragma unroll
             for (int q = 0; q < NR; ++q)
@@ -161,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
         if (n >= 2 * PD) {
 #pragma unroll
             for (int d = 0; d < PD; ++d) fetch(16 + 16 * d, false, ring[d]);
-            compute(0, ev);
+            compute(0, ev, true);
             for (; g + 2 * PD <= n; g += PD) {
 #pragma unroll
                 for (int d = 0; d < PD; ++d) {
@@ -173,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
             for (int d = 0; d < PD; ++d) compute(16 + 16 * (g + d), ring[d]);
             g += PD;
         } else {
-            compute(0, ev);
+            compute(0, ev, true);
         }
         for (; g < n; ++g) {
             fetch(16 + 16 * g, false, ev);
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvArgs a) {
         }
         if (a.Wout > 16) {
             fetch(a.Wout - 16, true, ev);
-            compute(a.Wout - 16, ev);
+            compute(a.Wout - 16, ev, true);
         }
 
         if (do_stats) {
@@ -216,8 +241,19 @@ bool conv_small_ok(const ConvArgs &a, int ks, int stride) {
     return true;
 }
 
+bool conv_small_lazy_ok(const ConvArgs &a, int ks, int stride) {
+    return conv_small_ok(a, ks, stride) && stride == 2 && a.Cin == 16 && a.Cout == 32 && a.src[0].la && a.src[0].lb;
+}
+
 hipError_t launch_conv_small(const ConvArgs &a, int stride, hipStream_t st) {
     if (conv_thin_ok(a, 3, stride)) return launch_conv_thin(a, st);      // mode 3: the fp16-pipe kernel (conv_thin.hip)
+    if (a.src[0].la) {          // lazy source: the stride-2 16 -> 32 layer (DLA level1) is the one that needs it
+        if (!conv_small_lazy_ok(a, 3, stride)) return hipErrorInvalidValue;
+        int lblocks = (a.B * a.Hout + 3) / 4;
+        if (lblocks > 2048) lblocks = 2048;
+        hipLaunchKernelGGL((conv_small_kernel<2, 16, 2, true>), dim3(lblocks), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     const int nr = (stride == 1 && a.Cin == 16) ? 2 : 1;             // rows per wave pass (see the kernel)
     const int rows = a.B * ((a.Hout + nr - 1) / nr);
     int blocks = (rows + 3) / 4;

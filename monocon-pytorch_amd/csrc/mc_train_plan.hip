@@ -229,6 +229,12 @@ struct TB {   // train plan builder
     // Tree's `project` branch (BatchNorm without ReLU, consumed as the residual of the block beside it); 0: every
     // activation is stored (rounds 1-5).  Outputs of a residual add are always stored.
     int lazy_mask = [] { const char *e = std::getenv("MONOCON_HIP_LAZY_Z"); return e ? std::atoi(e) : 3; }();
+    // A lazy map costs its MFMA-kernel consumers one fma + one v_med3 per staged element (measured, B = 32: a 3x3 weight
+    // gradient +0.03 ms, a conv +0.01 ms per launch) and saves one element-wise pass over the map (2 x its bytes at ~5.3
+    // TB/s): worth it for the large maps only.  MONOCON_HIP_LAZY_MIN: elements per image from which a ReLU'd map whose
+    // consumers are convolutions is lazy; maps with element-wise consumers only (neck proj -> deconv, project -> residual)
+    // always are.
+    long long lazy_min = [] { const char *e = std::getenv("MONOCON_HIP_LAZY_MIN"); return e ? std::atoll(e) : 983040ll; }();
     int n_lazy = 0, n_materialised = 0;
     // a consumer that cannot form a lazy activation on load: store it after all (one element-wise pass appended to the
     // forward at this point of the build -- i.e. before the consumer's own launch -- and the node is an ordinary one from
@@ -297,7 +303,7 @@ struct TB {   // train plan builder
         });
     }
 
-    int conv_bn(ConvLayer &Lr, const std::vector<int> &srcs, int res, bool relu, bool dead = false) {
+    int conv_bn(ConvLayer &Lr, const std::vector<int> &srcs, int res, bool relu, bool dead = false, bool elementwise_consumers = false) {
         const Tensor s0 = ts->nodes[srcs[0]].t;   // by value: node() below may reallocate ts->nodes
         const int B = s0.B;
         const int Ho = (s0.H + 2 * (Lr.ks / 2) - Lr.ks) / Lr.stride + 1, Wo = (s0.W + 2 * (Lr.ks / 2) - Lr.ks) / Lr.stride + 1;
@@ -306,7 +312,8 @@ struct TB {   // train plan builder
         r.y.B = B; r.y.H = Ho; r.y.W = Wo; r.y.C = Lr.cout;
         r.y.p = alloc(r.y.numel());
         // lazy output: BatchNorm (+ ReLU) without residual in mode 3 (the convs of every kernel family leave max |y|)
-        const bool lazy = !dead && res < 0 && h->prec == 3 && (lazy_mask & (relu ? 1 : 2)) != 0;
+        const bool lazy = !dead && res < 0 && h->prec == 3 && (lazy_mask & (relu ? 1 : 2)) != 0 &&
+                          (!relu || elementwise_consumers || (long long)Ho * Wo * Lr.cout >= lazy_min);
         r.z = dead ? -1 : node(B, Ho, Wo, Lr.cout, true, !lazy);
         ConvArgs a{};
         a.nsrc = (int)srcs.size();
@@ -737,7 +744,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
         const int j = 4 - i - 2;
         for (int t = 1; t < 4 - j; ++t) {
             const std::string pre = "neck.ida_" + std::to_string(i) + ".", tsn = std::to_string(t);
-            const int p = b.conv_bn(b.L(pre + "proj_" + tsn + ".conv"), {layers[j + t]}, -1, true);
+            const int p = b.conv_bn(b.L(pre + "proj_" + tsn + ".conv"), {layers[j + t]}, -1, true, false, /*elementwise_consumers=*/true);
             const int u = b.deconv(h->deconvs[pre + "up_" + tsn], p);
             layers[j + t] = b.conv_bn(b.L(pre + "node_" + tsn + ".conv"), {layers[j + t - 1], u}, -1, true);
         }

@@ -237,7 +237,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef WGS_PD
 #define WGS_PD 3
 #endif
-template <int S, int NTN>
+// LZ: X is a lazy tensor (ConvSrc::la in conv_mfma.h: raw conv output + BatchNorm coefficients); a lane always holds channel
+// lane & 15, so its two coefficients stay in registers and max(fma(y, la, lb), 0) is formed in front of the MFMAs (fp32
+// operands here: no operand scale).  Padding stays 0: `cap`.
+template <int S, int NTN, bool LZ = false>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
     constexpr int CIN = 16, COUT = 16 * NTN;
     __shared__ float red[9 * NTN * 4][64];
@@ -257,17 +260,22 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
     const int va = (k * COUT + j) * 4;        // dY lane offset inside a group of 4 output pixels
     const int vx = (k * S * CIN + j) * 4;     // X lane offset relative to the input pixel of output pixel 0
     const float *xsrc = a.src[0].p;
+    [[maybe_unused]] float lzA = 0.f, lzB = 0.f;
+    if constexpr (LZ) { lzA = a.src[0].la[j]; lzB = a.src[0].lb[j]; }
 
     for (int row = r_begin + wave; row < r_end; row += 4) {
         const int img = row / a.Hout, oy = row - img * a.Hout;
         const __amdgpu_buffer_rsrc_t r_dy = make_rsrc(a.dy + (size_t)row * a.Wout * COUT, (unsigned)(a.Wout * COUT) * 4u);
         __amdgpu_buffer_rsrc_t r_x[3];
+        [[maybe_unused]] float rowcap[3];      // LZ: +inf for an input row inside the image, 0 for a padding row
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int iy = oy * S + r - 1;
             const bool ok = iy >= 0 && iy < a.Hin;
             r_x[r] = make_rsrc(xsrc + ((size_t)img * a.Hin + (ok ? iy : 0)) * a.Win * CIN, ok ? (unsigned)(a.Win * CIN) * 4u : 0u);
+            rowcap[r] = ok ? __builtin_inff() : 0.f;
         }
+        [[maybe_unused]] float ecap[3] = {0.f, 0.f, 0.f};      // LZ, edge groups: 0 where this lane's column is padding
         auto fetch = [&](int x0, bool edge, float (&v)[NTN + 9]) {
 #pragma unroll
             for (int nt = 0; nt < NTN; ++nt) v[nt] = buf_load1(r_dy, va + nt * 64, x0 * COUT * 4);
@@ -280,15 +288,22 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
                     } else {
                         const int px = (x0 + k) * S + s - 1;
                         v[NTN + r * 3 + s] = buf_load1(r_x[r], (px >= 0 && px < a.Win) ? (px * CIN + j) * 4 : BUF_OOB, 0);
+                        if constexpr (LZ) ecap[s] = (px >= 0 && px < a.Win) ? __builtin_inff() : 0.f;
                     }
                 }
         };
-        auto mma = [&](const float (&v)[NTN + 9]) {
+        auto mma = [&](const float (&v)[NTN + 9], bool edge = false) {
+            float x[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if constexpr (LZ) x[t] = lazy_act(v[NTN + t], lzA, lzB, edge ? fminf(rowcap[t / 3], ecap[t % 3]) : rowcap[t / 3]);
+                else x[t] = v[NTN + t];
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NTN; ++nt)
-                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nt], v[NTN + t], acc[t][nt], 0, 0, 0);
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nt], x[t], acc[t][nt], 0, 0, 0);
         };
         // the groups of a row run as a software pipeline PD groups deep: the 9 + NTN dword loads of group g + PD are in
         // flight while the MFMAs of group g issue (without it every group paid one full memory latency: the kernel sat at
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
         float ring[PD][NTN + 9], ev[NTN + 9];
         const int n = (a.Wout - 8) / 4;               // interior groups: output pixels 4 .. Wout - 5
         fetch(0, true, ev);
-        mma(ev);
+        mma(ev, true);
         int g = 0;
         if (n >= 2 * PD) {
             // (no conditional code between the fetches and the MFMAs of the steady state: the compiler's wait counts are
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const WgradArgs a) {
         }
         if (a.Wout > 4) {
             fetch(a.Wout - 4, true, ev);
-            mma(ev);
+            mma(ev, true);
         }
     }
 
@@ -432,7 +447,7 @@ size_t wgrad_partial_floats(const WgradArgs &a, int ks) { return (size_t)a.kspli
 bool wgrad_lazy_capable(const WgradArgs &a, int ks, int stride) {
     if (a.prec != 3) return false;
     if (a.pipe) return a.pipe == 4;
-    if (a.small) return wgrad_thin_ok(a, ks, stride);
+    if (a.small) return wgrad_thin_ok(a, ks, stride) || (ks == 3 && stride == 2 && a.Cout == 32 && a.nsrc == 1);      // (wgrad_small_kernel<2, 2, LZ>)
     return wgrad_sources_ok(a) && wgrad_bf16_ok(a, ks, stride);
 }
 
@@ -446,6 +461,10 @@ hipError_t launch_wgrad(const WgradArgs &a, int ks, int stride, float *dw_oihw, 
         e = launch_wgrad_pipe(a, ks, st);
     } else if (a.small && wgrad_thin_ok(a, ks, stride)) {
         e = launch_wgrad_thin(a, st);
+    } else if (a.small && a.src[0].la) {      // lazy X: the stride-2 16 -> 32 layer (DLA level1) is the one that needs it
+        if (stride == 2 && a.Cout == 32 && a.src[0].lb) hipLaunchKernelGGL((wgrad_small_kernel<2, 2, true>), dim3(a.ksplit), dim3(256), 0, st, a);
+        else return hipErrorInvalidValue;
+        e = hipGetLastError();
     } else if (a.small) {
         if (stride == 1 && a.Cout == 16) hipLaunchKernelGGL((wgrad_small_kernel<1, 1>), dim3(a.ksplit), dim3(256), 0, st, a);
         else if (stride == 1) hipLaunchKernelGGL((wgrad_small_kernel<1, 2>), dim3(a.ksplit), dim3(256), 0, st, a);
