@@ -76,6 +76,10 @@ def parse():
                          "torch.distributed's all_reduce (also RCCL, not overlapped) instead and SAY SO -- comm_path = 'torch "
                          "(FALLBACK: <reason>)' in the line, the reason on stderr; never silent")
     ap.add_argument("--allow-fallback", action="store_true", help="(the default since round 5; kept for old command lines)")
+    ap.add_argument("--n1-json", default=None,
+                    help="file holding the compact line of an N = 1 run of the same command: the line then carries scaling_vs_n1 = "
+                         "value / (n_gpus x that run's value) (the driver computes its own from the per-N values; this is for reading "
+                         "a run by hand)")
     ap.add_argument("--full-json", default=None,
                     help="where the verbose report (every leg with its prose notes) goes; default gpurun_out/bench_full.json when "
                          "that directory exists, else bench_full.json beside this file.  stdout carries ONE compact line")
@@ -281,6 +285,13 @@ def compact_line(out, full_path):
                      "mfma_busy": _num(r, "pmc", "mfma_busy"), "clock_ghz": _num(r, "pmc", "clock_ghz"),
                      "conv_ms": r.get("conv_ms_per_step"), "wgrad_ms": _num(r, "wgrad", "ms_per_step"), "wgrad_frac": _num(r, "wgrad", "frac", nd=4),
                      "other_ms": r.get("other_ms_per_step")}
+    # the WHOLE step against the matrix pipe: (conv + data-gradient + weight-gradient FLOPs) x MFMAs per MAC / step time / peak
+    # (`frac` above is the conv family timed alone; the buckets overlap in the step)
+    if r.get("whole_step_tflops_fp32_equivalent") and r.get("peak"):
+        c["roofline"]["whole_step_frac"] = round(r["whole_step_tflops_fp32_equivalent"] * c["roofline"]["mfma_per_mac"] / r["peak"], 4)
+    c["img_s_per_gpu"] = round(out["value"] / max(out.get("n_gpus", 1), 1), 2) if isinstance(out.get("value"), (int, float)) else None
+    if out.get("scaling_vs_n1") is not None:
+        c["scaling_vs_n1"] = out["scaling_vs_n1"]
     c["workspace_gb"] = out.get("workspace_gb")
     f = out.get("forward_only")
     if f:      # BASELINE configs[1]
@@ -306,7 +317,7 @@ def compact_line(out, full_path):
         c["kitti_eval_overlaps"] = {k: out["kitti_eval_overlaps"][k] for k in ("bev_ms", "box3d_ms")}
     if out.get("power_ceiling"):
         c["power_ceiling"] = out["power_ceiling"]
-    for k in ("comm_world", "n_collectives", "comm_path", "per_rank_ms_per_step", "per_rank_exposed_allreduce_ms"):
+    for k in ("comm_world", "n_collectives", "comm_path", "comm_fallback", "per_rank_ms_per_step", "per_rank_exposed_allreduce_ms"):
         if k in out:
             c[k] = out[k]
     cb = out.get("cpu_baseline")
@@ -687,8 +698,19 @@ def main():
                 out["comm_path"] = "torch (FALLBACK: %s)" % comm["fallback_reason"]
             else:
                 out["comm_path"] = "torch"
+            # a number measured on the fallback exchange is NOT the overlapped-RCCL result; consumers key on this flag
+            # (tests/test_abi.py refuses a committed report that carries it), --strict-comm turns it into a non-zero exit
+            out["comm_fallback"] = bool(out["comm_path"].startswith("torch (FALLBACK"))
             out["per_rank_ms_per_step"] = head.get("per_rank_ms_per_step")
             out["per_rank_exposed_allreduce_ms"] = head.get("per_rank_exposed_allreduce_ms")
+        if args.n1_json:
+            try:
+                with open(args.n1_json) as f:
+                    n1 = json.loads([ln for ln in f.read().splitlines() if ln.strip().startswith("{")][-1])
+                if n1.get("n_gpus") == 1 and n1.get("value"):
+                    out["scaling_vs_n1"] = round(out["value"] / (world * float(n1["value"])), 4)
+            except (OSError, ValueError, IndexError) as e:
+                print("[bench] --n1-json unreadable: %s" % e, file=sys.stderr)
         if dec is not None:
             out["decode_only"] = dec
             out["kitti_eval_overlaps"] = evl

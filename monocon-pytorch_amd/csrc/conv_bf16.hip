@@ -526,13 +526,11 @@ static hipError_t launch_b16_one(ConvArgs a, hipStream_t st, ConvArgs *resolved)
     a.chunks = (a.ppi + Cfg::PB - 1) / Cfg::PB;
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
-    static bool attr_set = false;
+    static DynLdsOnce attr_set;
     auto kern = conv_bf16_kernel<KS, S, WM, WN, WTM, WTN, SPL, BM, LZ>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    {
+        const hipError_t e = attr_set.ensure(reinterpret_cast<const void *>(kern), (int)(Cfg::LDS_BYTES));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int ntiles = a.CoutP / Cfg::BNT;
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * a.chunks * ntiles)), dim3(Cfg::NT), Cfg::LDS_BYTES, st, a);

@@ -32,12 +32,28 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <type_traits>
 
 namespace mc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (function, DEVICE): a process-wide "already set" flag would
+// launch a second handle's kernels on another GPU without it.  One bit per device in a per-instantiation mask;
+// racing threads at worst set the attribute twice.
+struct DynLdsOnce {
+    std::atomic<unsigned long long> done{0};
+    hipError_t ensure(const void *fn, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) done.fetch_or(1ull << dev, std::memory_order_release);
+        return e;
+    }
+};
 
 struct ConvSrc {
     const float *p;

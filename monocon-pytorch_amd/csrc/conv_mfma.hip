@@ -30,13 +30,11 @@ static hipError_t launch_one(ConvArgs a, hipStream_t st, ConvArgs *resolved) {
     a.chunks = (a.ppi + Cfg::PB - 1) / Cfg::PB;
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
-    static bool attr_set = false;
+    static DynLdsOnce attr_set;
     auto kern = conv_mfma_kernel<KS, S, CK, WM, WN, WTM, WTN, BM>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    {
+        const hipError_t e = attr_set.ensure(reinterpret_cast<const void *>(kern), (int)(Cfg::LDS_BYTES));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int ntiles = a.CoutP / Cfg::BNT;
     dim3 grid((unsigned)(a.B * a.chunks * ntiles));
@@ -53,13 +51,11 @@ static hipError_t launch_one_ws(ConvArgs a, hipStream_t st, ConvArgs *resolved) 
     a.chunks = (a.ppi + Cfg::PB - 1) / Cfg::PB;
     if (a.CoutP % Cfg::BNT) return hipErrorInvalidValue;
     if (resolved) *resolved = a;
-    static bool attr_set = false;
+    static DynLdsOnce attr_set;
     auto kern = conv_mfma_ws_kernel<KS, S, CK, WM, WN, WTM, WTN>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    {
+        const hipError_t e = attr_set.ensure(reinterpret_cast<const void *>(kern), (int)(Cfg::LDS_BYTES));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int ntiles = a.CoutP / Cfg::BNT;
     dim3 grid((unsigned)(a.B * a.chunks * ntiles));

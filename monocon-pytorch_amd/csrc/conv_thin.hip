@@ -659,11 +659,10 @@ bool wgrad_thin_ok(const WgradArgs &a, int ks, int stride) {
 
 hipError_t launch_wgrad_thin(const WgradArgs &a, hipStream_t st) {
     const size_t lds = 2 * WT_PLANE + 9 * 4 * 64 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_thin16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static DynLdsOnce attr_set;
+    {
+        const hipError_t e = attr_set.ensure(reinterpret_cast<const void *>(wgrad_thin16_kernel), (int)(lds));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(wgrad_thin16_kernel, dim3(a.ksplit), dim3(256), lds, st, a);
     return hipGetLastError();

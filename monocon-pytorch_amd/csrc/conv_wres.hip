@@ -444,12 +444,10 @@ bool conv_wres_ok(const ConvArgs &a, int ks, int stride) {
 template <bool BM, bool RES, bool STATS, bool ZMASK, int EXP = 0, bool LZ = false>
 static hipError_t launch_wres_one(const ConvArgs &a, int tpr, int tpi, int total, int per_wg, int ngroups, int nwg, hipStream_t st) {
     auto kern = conv_wres_kernel<BM, RES, STATS, ZMASK, EXP, LZ>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)WresCfg::LDS_BYTES);
+    static DynLdsOnce attr_set;
+    {
+        const hipError_t e = attr_set.ensure(reinterpret_cast<const void *>(kern), (int)(WresCfg::LDS_BYTES));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(nwg * ngroups)), dim3(256), WresCfg::LDS_BYTES, st, a, tpr, tpi, total, per_wg, ngroups);
     return hipGetLastError();
@@ -464,11 +462,17 @@ hipError_t launch_conv_wres(const ConvArgs &a_in, int ks, int stride, hipStream_
     if (resolved) *resolved = a;
     const int tpr = a.Wout / 16, tpi = tpr * (a.Hout / 4), total = a.B * tpi, ngroups = a.CoutP / 64;
     // one workgroup per CU and column group where the work allows (>= 8 tiles each: the weight prologue is ~2 tiles of time)
-    static const int ncu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    // (the CU count of the CURRENT device, remembered per device: handles on different GPUs share this process -- ADVICE r5)
+    static std::atomic<int> ncu_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int ncu = ncu_of[dev].load(std::memory_order_relaxed);
+    if (ncu <= 0) {
+        int n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        ncu = n > 0 ? n : 256;
+        ncu_of[dev].store(ncu, std::memory_order_relaxed);
+    }
     int nwg = ncu;
     if (total < nwg * 8) nwg = (total + 7) / 8;
     if (nwg < 1) nwg = 1;

@@ -544,8 +544,16 @@ __global__ __launch_bounds__(192) void head_apply_kernel(const HeadApplyArgs a) 
             *reinterpret_cast<f32x4 *>(a.z_out + ((size_t)b * a.HW + hw0 + px) * (NUM_HEADS * HEAD_CH) + h * HEAD_CH + c4 * 4) = v[it];
     }
     // channel half `half` of the normalised tile -> LDS: the lanes holding it are c4 in [8 * half, 8 * half + 8)
+    // hl = hlds[wave] is PRIVATE to the wave, and `stage` runs inside the per-head switch below: a workgroup barrier there
+    // would be a barrier in wave-divergent control flow.  A wave's own LDS accesses execute in order; what is
+    // needed is that the compiler keeps them in order: a wavefront-scope fence pair around a wave barrier.
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto stage = [&](int half) {
-        if (half) __syncthreads();             // the first half is no longer read
+        if (half) wave_sync();                 // the first half is no longer read
         if ((c4 >> 3) == half) {
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(192) void head_apply_kernel(const HeadApplyArgs a) 
                 for (int j = 0; j < 4; ++j) hl[px * 33 + (c4 & 7) * 4 + j] = v[it][j];
             }
         }
-        __syncthreads();
+        wave_sync();
     };
     const int hw = hw0 + lane;
     const bool ok = hw < a.HW;

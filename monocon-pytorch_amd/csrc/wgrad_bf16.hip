@@ -408,7 +408,7 @@ static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
             }
     }
     auto kern = wgrad_bf16_kernel<KS, S, WN, WC, SPL, LZ>;
-    static bool attr_set = false;
+    static DynLdsOnce attr_set;
     // experiment knob (only with -DMC_DEBUG_HOOKS): MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the
     // workgroups per CU
     static const size_t lds_req = [] {
@@ -420,11 +420,9 @@ static hipError_t launch_wg16(const WgradArgs &a, hipStream_t st) {
         return (size_t)Cfg::LDS_BYTES;
 #endif
     }();
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_req);
+    {
+        const hipError_t e = attr_set.ensure(reinterpret_cast<const void *>(kern), (int)(lds_req));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.ksplit * a.n_tiles * a.c_tiles), dim3(Cfg::NT), lds_req, st, a);
     return hipGetLastError();

@@ -374,7 +374,7 @@ template <int KS, int S, int WN, int WC>
 static hipError_t launch_wg(WgradArgs a, hipStream_t st) {
     using Cfg = WgCfg<KS, S, WN, WC>;
     auto kern = wgrad_mfma_kernel<KS, S, WN, WC>;
-    static bool attr_set = false;
+    static DynLdsOnce attr_set;
     // experiment knob (only with -DMC_DEBUG_HOOKS): MONOCON_HIP_WGRAD_LDS_KB pads the dynamic LDS request, i.e. caps the
     // workgroups per CU
     static const size_t lds_req = [] {
@@ -386,11 +386,9 @@ static hipError_t launch_wg(WgradArgs a, hipStream_t st) {
         return (size_t)Cfg::LDS_BYTES;
 #endif
     }();
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_req);
+    {
+        const hipError_t e = attr_set.ensure(reinterpret_cast<const void *>(kern), (int)(lds_req));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.ksplit * a.n_tiles * a.c_tiles), dim3(Cfg::NT), lds_req, st, a);
     return hipGetLastError();

@@ -335,12 +335,10 @@ static hipError_t launch_wp(const WgradArgs &a, hipStream_t st) {
     }
     auto kern = wgrad_pipe_kernel<KS, WN, WC, WK, LZ>;
     constexpr size_t lds_bytes = Cfg::LDS_BYTES + (LZ ? 2 * (Cfg::CB / 4) * 16 : 0);      // (+ the lazy coefficient table)
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
+    static DynLdsOnce attr_set;
+    {
+        const hipError_t e = attr_set.ensure(reinterpret_cast<const void *>(kern), (int)(lds_bytes));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     if (a.ksplit % WK) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kern, dim3((a.ksplit / WK) * a.n_tiles * a.c_tiles), dim3(Cfg::NT), lds_bytes, st, a);

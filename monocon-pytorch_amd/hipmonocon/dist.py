@@ -84,27 +84,72 @@ def state_checksum(module):
     return tot
 
 
-_HOST_GROUP = None
+_HOST_GROUP = None          # (default process group it belongs to, gloo group or False)
+_HOST_GROUP_WARNED = False
+
+
+def _default_group_token():
+    """identity of the CURRENT default process group: a cached subgroup of a destroyed / re-created default group is stale"""
+    import torch.distributed as dist
+    try:
+        return dist.distributed_c10d._get_default_group()
+    except Exception:           # noqa: BLE001
+        return None
 
 
 def host_group():
     """Process group for the small host-side votes of the step path.  On the 'nccl' backend a collective on a device tensor
     is ordered behind everything already queued on the stream, and reading its result is a host sync that stops the host
     from running ahead of the GPU; a gloo group carries the same few bytes between the hosts in ~0.1 ms without touching
-    the device.  Created once, COLLECTIVELY (dist.new_group): call it first from a point every rank reaches (the engine's
-    distributed set-up at its first step).  None = use the default group (gloo runs, or gloo unavailable)."""
+    the device.  Created once per default process group, COLLECTIVELY (dist.new_group): call it first from a point every
+    rank reaches (the engine's distributed set-up at its first step).  Whether the group is used is itself AGREED on by all
+    ranks (a rank whose new_group failed alone would have voted on the nccl group while the others voted on
+    gloo -- mismatched collectives, a hang): one MIN all-reduce of "my creation succeeded" over the default group, and a
+    rank that succeeded where another failed destroys its group again.  The cache is tied to the default group's identity:
+    after destroy_process_group() + init_process_group() in the same process a new group is made.
+    None = use the default group (gloo runs, or gloo unavailable on some rank)."""
     global _HOST_GROUP
     if not is_distributed():
         return None
     import torch.distributed as dist
-    if _HOST_GROUP is None:
-        _HOST_GROUP = False
+    token = _default_group_token()
+    if _HOST_GROUP is None or _HOST_GROUP[0] is not token:
+        grp = False
         if dist.get_backend() == "nccl":
             try:
-                _HOST_GROUP = dist.new_group(backend="gloo")
+                grp = dist.new_group(backend="gloo")
             except Exception:           # noqa: BLE001  (no gloo in this build: the votes fall back to device tensors)
-                _HOST_GROUP = False
-    return _HOST_GROUP or None
+                grp = False
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+            t = torch.tensor([1 if grp is not False else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)          # (once, at set-up: the one device-side vote)
+            if not bool(t.item()):
+                if grp is not False:
+                    try:
+                        dist.destroy_process_group(grp)
+                    except Exception:   # noqa: BLE001
+                        pass
+                grp = False
+        _HOST_GROUP = (token, grp)
+    return _HOST_GROUP[1] or None
+
+
+def host_votes_are_cheap():
+    """False when the per-step votes would have to run on device tensors of the nccl backend (no host-side group): each one
+    is then a stream sync in front of the overlapped gradient exchange -- the callers fall back to their cached verdicts
+    (train._require_objects) and this warns once."""
+    global _HOST_GROUP_WARNED
+    if not is_distributed():
+        return True
+    import torch.distributed as dist
+    if dist.get_backend() != "nccl" or host_group() is not None:
+        return True
+    if not _HOST_GROUP_WARNED:
+        _HOST_GROUP_WARNED = True
+        import warnings
+        warnings.warn("hipmonocon: no gloo group beside the nccl backend -- the per-step label vote is skipped for label tensors "
+                      "that were already validated on this rank (ranks must then re-use / refresh their label tensors in step)")
+    return False
 
 
 def all_ranks_ok(ok, device=None):

@@ -159,11 +159,14 @@ def _require_objects(detector, label, pad_hw, num_classes=3):
     # no stream sync: the host keeps running ahead of the GPU; ADVICE r3 was about a vote that synchronised the stream) --
     # and only when somebody's is not do all ranks enter the verdict's collective, the validated ones with (True, True).
     dp = _dist.is_distributed()
-    if dp:
+    if dp and _dist.host_votes_are_cheap():
         all_cached, = _dist.all_ranks_ok_many((cached,), mask.device, host=True)
         if all_cached:
             return
     elif cached:
+        # single process -- or data parallel WITHOUT a host-side group (gloo unavailable beside nccl): a vote on
+        # device tensors would synchronise the stream in front of the overlapped gradient exchange on every step, so the
+        # round-3 contract applies instead: a label set validated on this rank is not voted on again (warned once)
         return
     H, W = pad_hw
     fh, fw = H // 4, W // 4

@@ -395,6 +395,31 @@ def dp_shards(sd_stats):
     save("dp_shards.npz", **out)
 
 
+def dp_shards8(sd_stats):
+    """(8b, round 6) the same contract for EIGHT ranks: a global batch of 16 at 64x64 in 8 shards of 2 (a rank's batch must hold
+    two images: AttnBN normalises its attention vector over the batch).  Own file, so that dp_shards.npz keeps its bytes."""
+    sd = synth.make_conditioned_state_dict(SEED, bn_stats={k: v.numpy() for k, v in sd_stats.items()})
+    gb = synth.make_conditioned_batch(SEED + 61, 16, 64, 64)
+    world, per = 8, 2
+    out = {"seed": SEED + 61, "shape": np.array([16, 64, 64])}
+    mean64, mean32 = None, None
+    for r in range(world):
+        sl = slice(r * per, (r + 1) * per)
+        b = {"img": gb["img"][sl].clone(), "label": {k: v[sl].clone() for k, v in gb["label"].items()},
+             "img_metas": {k: v[sl] for k, v in gb["img_metas"].items()}, "calib": gb["calib"][sl]}
+        g64, l64, _, _ = _grads(sd, b, True)
+        g32, l32, _, _ = _grads(sd, b, False)
+        for k in l64:
+            out["w%d.r%d.f64.%s" % (world, r, k)] = l64[k]
+        mean64 = g64 if mean64 is None else {n: mean64[n] + g64[n] for n in g64}
+        mean32 = g32 if mean32 is None else {n: mean32[n] + g32[n] for n in g32}
+    for n in mean64:
+        out["w%d.gnorm64.%s" % (world, n)] = (mean64[n] / world).norm()
+        out["w%d.g64.%s" % (world, n)] = gsample(mean64[n] / world)
+        out["w%d.gerr32.%s" % (world, n)] = _tensor_errs({n: mean32[n]}, {n: mean64[n]})[n]
+    save("dp_shards8.npz", **out)
+
+
 def init_pins():
     """(9) initialisers: the reference detector built under torch.manual_seed(5) --
     mean / std / min / max and a CRC-32 of the raw bytes of all 449 state_dict entries.  The product's
@@ -585,6 +610,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "ref_checkpoint":
         _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
         ref_checkpoint(sd_stats=_stats)
+    elif len(sys.argv) > 1 and sys.argv[1] == "dp_shards8":
+        _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
+        dp_shards8(sd_stats=_stats)
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         _stats = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(HERE, "bn_calib_seed%d.npz" % SEED)).items()}
         cond_train(sd_stats=_stats)

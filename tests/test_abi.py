@@ -103,3 +103,6 @@ def test_committed_bench_reports_are_headline_runs():
         assert "roofline" in d and d["roofline"].get("frac"), f
         assert "cpu_baseline" in d and d["cpu_baseline"].get("value"), f
         assert d["steps"] >= 5 and 300 < d["value"] < 2000, f
+        # a report measured on the fallback exchange (torch.distributed's all_reduce instead of the handle's
+        # overlapped RCCL buckets) is not evidence of the data-parallel path
+        assert not d.get("comm_fallback") and not str(d.get("comm_path", "")).startswith("torch (FALLBACK"), f

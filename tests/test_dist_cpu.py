@@ -325,3 +325,30 @@ def test_collectives_of_the_dp_start_up_and_label_vote_do_not_depend_on_rank_loc
         assert o["import"].startswith("tune table of rank 0 could not be imported"), o["import"]
         assert o["setup"] == ([(32, 384, 1280)] if r == 0 else [], world, True), o["setup"]
         assert o["labels"] == "IndexError"
+
+
+def _host_group_worker(rank, world, port, out):
+    """the host-side vote group is cached per DEFAULT process group; after destroy + re-init the cache entry of the
+    old group must not be served, and every rank must take the same decision about using it.  (On gloo there is no second
+    group to make -- the decision is "none" -- but the cache bookkeeping and the agreement are the same code.)"""
+    from hipmonocon import dist as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    res = []
+    for k in range(2):
+        os.environ["MASTER_PORT"] = str(port + k)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        g = D.host_group()
+        tok = D._HOST_GROUP[0]
+        res.append((g is None, tok is D._default_group_token(), D.host_votes_are_cheap(),
+                    D.all_ranks_ok_many((True, rank != 1), host=True)))
+        dist.destroy_process_group()
+    assert D._HOST_GROUP[0] is not None
+    out[rank] = res
+
+
+def test_host_group_cache_follows_the_default_process_group():
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_host_group_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r] == [(True, True, True, [True, False])] * 2, out[r]

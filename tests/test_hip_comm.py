@@ -137,7 +137,7 @@ from model import MonoConDetector
 from solver import AdamW
 hdist.init_from_env("nccl")                           # one process per GPU: device = LOCAL_RANK, torch.distributed on RCCL
 assert torch.cuda.current_device() == local and hdist.dp_backend() == "rccl"
-g = load_golden("dp_shards.npz")
+g = load_golden("dp_shards8.npz" if world == 8 else "dp_shards.npz")     # global batch 16 in 8 shards / 8 in 2 or 4
 stats = load_golden("bn_calib_seed7.npz")
 sd = synth.make_conditioned_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
 B, H, W = (int(x) for x in g["shape"])
@@ -166,7 +166,7 @@ for n, p in m.named_parameters():
         assert p.grad is None
         continue
     e = grad_rel_l2(p.grad, g["w%%d.g64.%%s" %% (world, n)], g["w%%d.gnorm64.%%s" %% (world, n)], p.numel())
-    bound = 4.0 * float(g["w%%d.gerr32.%%s" %% (world, n)]) + (2e-2 if world == 2 else 6e-2)
+    bound = 4.0 * float(g["w%%d.gerr32.%%s" %% (world, n)]) + (2e-2 if world == 2 else 6e-2)      # (the bounds of the gloo tests)
     assert e <= bound, (rank, n, e, bound)
     worst = max(worst, e)
 opt.step()
@@ -174,16 +174,21 @@ flat = torch.cat([p.detach().flatten() for p in m.parameters()])
 lst = [torch.zeros_like(flat) for _ in range(world)]
 dist.all_gather(lst, flat)
 assert all(torch.equal(x, lst[0]) for x in lst), "parameters differ across ranks after the optimizer step"
-print("RCCL_OK rank %%d world %%d exposed %%.3f ms worst grad err %%.2e" %% (rank, world, eng.comm_exposed_ms(), worst), flush=True)
+exposed = eng.comm_exposed_ms()
+# 78 MB of gradients in four buckets, three of them launched while the backbone's backward still runs: at these tiny shapes
+# the whole backward is a few ms, so the bound is loose -- what it catches is an exchange that serialises (>> 1 ms per bucket)
+assert exposed < 1.5 * 4, (rank, exposed)
+print("RCCL_OK rank %%d world %%d exposed %%.3f ms worst grad err %%.2e" %% (rank, world, exposed, worst), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the first multi-GPU box runs this by itself")
+@pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("mode", ["f16x2", "fp32"])
-def test_two_ranks_on_two_devices_exchange_gradients_over_rccl(tmp_path, mode):
-    """SURVEY 8e on hardware (VERDICT r4 item 8; nothing upstream: the reference is single-GPU, README.MD:11,15): two
+def test_ranks_on_their_own_devices_exchange_gradients_over_rccl(tmp_path, mode, world):
+    """SURVEY 8e on hardware (VERDICT r4 item 8, widened in round 6 to 2 / 4 / 8 ranks -- whatever the box holds; nothing
+    upstream: the reference is single-GPU, README.MD:11,15): `world`
     processes, one GPU each, torch.distributed on 'nccl' (= RCCL); the handle builds its OWN communicator
     (mc_comm_init world 2, id broadcast by rank 0), mc_backward launches the four gradient buckets on it while the
     backbone's backward still runs, and every rank ends with the mean of the reference's per-shard fp64 gradients
@@ -192,7 +197,8 @@ def test_two_ranks_on_two_devices_exchange_gradients_over_rccl(tmp_path, mode):
     import socket
     import subprocess
     import sys
-    world = 2
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs: the first box that has them runs this by itself" % world)
     script = os.path.join(tmp_path, "rccl_worker.py")
     open(script, "w").write(_RCCL_WORKER % {"repo": REPO, "tmp": str(tmp_path), "mode": mode})
     with socket.socket() as s:
