@@ -1023,8 +1023,16 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
                 HIPCHK(hh, launch_stem_wgrad(ts->img, dyp, B, H, W, part, dw, st, imax, imax ? dymax : nullptr, yfp, cfp, yfmax));
                 return 0;
             });
-            ts->bwd_side.resize(ts->bwd.size(), 1);
-            b.g_release(r.z, b.last_side_closure());
+            // MONOCON_HIP_STEM_WGRAD_MAIN=1 (measured, round 6; default off): the stem's weight gradient on the caller's stream.
+            // When it can start (after level0's data gradient and the BatchNorm-backward coefficients) the caller's stream has
+            // nothing left to do while the weight-gradient stream is busy with level0's weight gradient for another 0.8 ms
+            // (rocprofv3: main idle from 46.27 ms of the step, side busy until 47.87) -- yet run side by side the two
+            // front-end weight gradients finish no earlier: 48.77 / 48.82 ms per step (three runs each, one session).  Also
+            // measured neutral in the same round: the data-gradient panels packed on the weight-gradient stream at the head of
+            // the backward instead of on the caller's stream in front of the forward (49.64 / 49.69 ms).
+            static const bool stem_main = [] { const char *e = std::getenv("MONOCON_HIP_STEM_WGRAD_MAIN"); return e && std::atoi(e) != 0; }();
+            ts->bwd_side.resize(ts->bwd.size(), stem_main ? 0 : 1);
+            b.g_release(r.z, stem_main ? -1 : b.last_side_closure());
         }
     }
     if (head_only) {
