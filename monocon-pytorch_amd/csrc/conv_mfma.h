@@ -104,6 +104,11 @@ struct ConvArgs {
     // the separate three-tensor reduction pass over the activation disappears
     const float *bm_y;       // pre-BN conv output y of the forward, or null (mode off)
     const float *bm_z;       // post-BN map z (mask z > 0), bm_relu == 1
+    // round 6: the same mask BIT-PACKED, [pixel][Cout / 32] words (bit c % 32 of word c / 32 = z[pixel][c] > 0), written by the
+    // forward's affine_act pass of a residual layer (the only layers whose mask cannot be recomputed from y alone): the
+    // epilogue then reads one broadcast word per row instead of one float per lane -- 1/32 of the bytes (252 MB -> 8 MB for a
+    // 64-channel 96x320 map at B = 32).  Optional; with it bm_z is not read.  Cout % 32 == 0.
+    const unsigned *bm_zbits;
     const float *bm_a, *bm_b;// forward BN coefficients (mask fma(y, a, b) > 0, bit-identical to z > 0), bm_relu == 2
     int bm_relu;             // 0: no ReLU (no mask), 1, 2
     // prec 3 (conv_bf16.hip, fp32 emulated by a 2-way fp16 split): both operands are scaled by a power of two derived
@@ -277,8 +282,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
     const __amdgpu_buffer_rsrc_t r_res =
         make_rsrc(has_res ? a.res + (size_t)img * a.r_img : a.out, has_res ? (unsigned)a.r_img * 4u : 0u);
     const __amdgpu_buffer_rsrc_t r_y = make_rsrc(bm ? a.bm_y + (size_t)img * a.o_img : a.out, bm ? (unsigned)a.o_img * 4u : 0u);
+    // the stored mask: floats (dense layout of the output) or, when bm_zbits is given, one word per pixel and 32 channels
+    const bool zbits = bm && bm_relu == 1 && a.bm_zbits != nullptr;
+    const int zwords = a.Cout >> 5;                                     // words per pixel of the bit-packed mask
+    const unsigned zimg = zbits ? (unsigned)(a.Hout * a.Wout * zwords) * 4u : (unsigned)a.o_img * 4u;      // bytes per image
     const __amdgpu_buffer_rsrc_t r_z =
-        make_rsrc(bm && bm_relu == 1 ? a.bm_z + (size_t)img * a.o_img : a.out, bm && bm_relu == 1 ? (unsigned)a.o_img * 4u : 0u);
+        make_rsrc(bm && bm_relu == 1 ? (zbits ? reinterpret_cast<const float *>(a.bm_zbits) + (size_t)img * a.Hout * a.Wout * zwords
+                                              : a.bm_z + (size_t)img * a.o_img)
+                                     : a.out,
+                  bm && bm_relu == 1 ? zimg : 0u);
     // statistics partials are per 4x8 PATCH and channel: stats[b][patch][CoutP][2].  A patch's 32 values are
     // summed in an order fixed by the MFMA layout, so the partials -- and with them train-mode BN -- do not depend
     // on the workgroup shape the autotuner picked.
@@ -290,6 +302,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
         const int v_out = nok ? (4 * g * a.o_px + a.out_coff + n) * 4 : BUF_OOB;
         const int v_res = nok ? (4 * g * a.r_px + n) * 4 : BUF_OOB;
         const int v_bm = nok ? (4 * g * a.o_px + n) * 4 : BUF_OOB;      // y / z share the dense layout of the output
+        const int v_zb = nok ? (4 * g * zwords + (n >> 5)) * 4 : BUF_OOB;   // bit-packed mask: word n / 32 of pixel (ox0 + 4g + ..)
 #pragma unroll
         for (int tm = 0; tm < WTM; ++tm) {
             const int p = wm * WTM + tm;
@@ -319,9 +332,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         for (int r = 0; r < 16; ++r)
                             yv[r] = buf_load1(r_y, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
                         if constexpr (ZMASK) {
+                            if (zbits) {       // (wave-uniform) one word per row, the same for the 32 lanes of a half wave
+                                const int s_zb = (oy0 * a.Wout + ox0) * zwords * 4;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                zv[r] = buf_load1(r_z, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+                                for (int r = 0; r < 16; ++r) {
+                                    const unsigned w = __builtin_bit_cast(unsigned, buf_load1(r_z, v_zb, s_zb + ((r >> 2) * a.Wout + (r & 3)) * zwords * 4));
+                                    zv[r] = ((w >> (n & 31)) & 1u) ? 1.f : 0.f;
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    zv[r] = buf_load1(r_z, v_bm, s_out + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+                            }
                         }
                     }
 #pragma unroll
@@ -358,7 +380,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, f32x16 (&acc)[W
                         if (bm) {
                             const float yy = buf_load1(r_y, (y * a.o_row + x * a.o_px + n) * 4, 0);
                             bool on = true;
-                            if (bm_relu == 1) on = buf_load1(r_z, (y * a.o_row + x * a.o_px + n) * 4, 0) > 0.f;
+                            if (bm_relu == 1)
+                                on = zbits ? ((__builtin_bit_cast(unsigned, buf_load1(r_z, ((y * a.Wout + x) * zwords + (n >> 5)) * 4, 0)) >> (n & 31)) & 1u) != 0u
+                                           : buf_load1(r_z, (y * a.o_row + x * a.o_px + n) * 4, 0) > 0.f;
                             else if (bm_relu == 2) on = fmaf(yy, ma, mb) > 0.f;
                             v = on ? v : 0.f;
                             ssum += v;

@@ -10,7 +10,7 @@ static ProfLast conv_cost(const ConvArgs &a, int ks) {
     const double taps = win_h(ks) * win_w(ks);
     // algorithmic bytes: the input, the output (+ the residual / the gradient accumulated into), the weights, and for a
     // backward-statistics launch the forward's y (and z where the ReLU mask is the stored activation's)
-    const int extra = (a.res ? 1 : 0) + (a.bm_y ? 1 : 0) + ((a.bm_y && a.bm_relu == 1) ? 1 : 0);
+    const int extra = (a.res ? 1 : 0) + (a.bm_y ? 1 : 0) + ((a.bm_y && a.bm_relu == 1 && !a.bm_zbits) ? 1 : 0);      // (a bit-packed mask is 1/32 of a map: not counted)
     return {1, 2.0 * px_out * a.Cout * a.Cin * taps,
             4.0 * (px_in * a.Cin + px_out * a.Cout * (1 + extra) + taps * a.Cin * a.Cout)};
 }

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     //      (oy0 + (r >> 2), ox0 + (r & 3) + 4 g)) per call, operations and their order as in conv_epilogue
     float Y[16];
     __amdgpu_buffer_rsrc_t e_out = make_rsrc(a.out, 0u), e_res = e_out, e_y = e_out, e_z = e_out;
-    int e_sout = 0, e_sres = 0, e_patch = 0, e_img = 0;
+    int e_sout = 0, e_sres = 0, e_patch = 0, e_img = 0, e_szb = 0;
+    const int v_zb = nok ? (4 * g * (a.Cout >> 5) + (ncol >> 5)) * 4 : BUF_OOB;     // bit-packed mask: this lane's word of pixel 4g
     float ssum = 0.f, ssq = 0.f;
     // operands of the rows in flight: requested LEAD K-steps before their row is finished.  Three steps (~400 cycles) cover an
     // L2 hit; the residual of the eval forward's two BasicBlock launches comes from HBM (1-2 us under load): with a lead of
@@ -268,7 +269,13 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         e_out = make_rsrc(a.out + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
         if constexpr (RES) e_res = make_rsrc(a.res + (size_t)c.img * a.r_img, (unsigned)a.r_img * 4u);
         if constexpr (BM) e_y = make_rsrc(a.bm_y + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
-        if constexpr (BM && ZMASK) e_z = make_rsrc(a.bm_z + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
+        if constexpr (BM && ZMASK) {
+            if (a.bm_zbits)      // bit-packed mask (ConvArgs::bm_zbits): [pixel][Cout / 32] words
+                e_z = make_rsrc(a.bm_zbits + (size_t)c.img * a.Hout * a.Wout * (a.Cout >> 5), (unsigned)(a.Hout * a.Wout * (a.Cout >> 5)) * 4u);
+            else
+                e_z = make_rsrc(a.bm_z + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
+            e_szb = ((oy0 * a.Wout + ox0) * (a.Cout >> 5)) * 4;
+        }
         e_sout = (oy0 * a.o_row + ox0 * a.o_px) * 4;
         e_sres = (oy0 * a.r_row + ox0 * a.r_px) * 4;
         ssum = 0.f; ssq = 0.f;
@@ -276,7 +283,14 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     auto epi_load = [&](int r) {
         if constexpr (RES) rvr[r % RING] = buf_load1(e_res, v_res, e_sres + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
         if constexpr (BM) yvr[r % RING] = buf_load1(e_y, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
-        if constexpr (BM && ZMASK) zvr[r % RING] = buf_load1(e_z, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+        if constexpr (BM && ZMASK) {
+            if (a.bm_zbits) {
+                const unsigned w = __builtin_bit_cast(unsigned, buf_load1(e_z, v_zb, e_szb + ((r >> 2) * a.Wout + (r & 3)) * (a.Cout >> 5) * 4));
+                zvr[r % RING] = ((w >> (ncol & 31)) & 1u) ? 1.f : 0.f;
+            } else {
+                zvr[r % RING] = buf_load1(e_z, v_bm, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4);
+            }
+        }
     };
     // a row in three parts, one per MFMA gap of its K-step: (1) value + mask, (2) statistics, ReLU, max |v|, (3) the store
     float e_v = 0.f;

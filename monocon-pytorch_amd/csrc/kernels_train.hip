@@ -282,7 +282,10 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
                                                          int C4, int RG, int rows_per_img, int blocks_per_img,
                                                          int rows_per_block, int per_sample, int relu,
                                                          f32x4 *__restrict__ z, unsigned *__restrict__ amax,
-                                                         const float *__restrict__ ra, const float *__restrict__ rbc, int rrelu) {
+                                                         const float *__restrict__ ra, const float *__restrict__ rbc, int rrelu,
+                                                         unsigned *__restrict__ zbits) {
+    // zbits: also leave the ReLU mask bit-packed, [row][C / 32] words (ConvArgs::bm_zbits; C % 32 == 0: the eight threads
+    // of a word are eight neighbouring lanes of one wave)
     // ra / rb: the residual is a LAZY tensor (ConvSrc::la): res holds its producer's raw conv output, its value is
     // act(ra * res + rb), formed here (a Tree's `project` branch, BatchNorm without ReLU: model/backbone/dla.py:181-185,198)
     const int c4 = threadIdx.x % C4, rg = threadIdx.x / C4;
@@ -304,6 +307,14 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
     };
     const unsigned base = ((unsigned)b * rows_per_img) * C4 + c4;
     const unsigned step = (unsigned)RG * C4;
+    auto put_bits = [&](const f32x4 zv, int row) {      // the word of channels 32 (c4 / 8) .. + 31 of this row
+        unsigned m = (zv[0] > 0.f ? 1u : 0u) | (zv[1] > 0.f ? 2u : 0u) | (zv[2] > 0.f ? 4u : 0u) | (zv[3] > 0.f ? 8u : 0u);
+        m <<= 4 * (c4 & 7);
+        m |= (unsigned)__shfl_xor((int)m, 1);
+        m |= (unsigned)__shfl_xor((int)m, 2);
+        m |= (unsigned)__shfl_xor((int)m, 4);
+        if ((c4 & 7) == 0) zbits[((size_t)b * rows_per_img + row) * (C4 >> 3) + (c4 >> 3)] = m;
+    };
     int r = r0 + rg;
     for (; r + 3 * RG < r1; r += 4 * RG) {
         const unsigned e = base + (unsigned)r * C4;
@@ -324,6 +335,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
                 vmax = fmaxf(vmax, fabsf(v[u][j]));
             }
             z[e + u * step] = v[u];
+            if (zbits) put_bits(v[u], r + u * RG);
         }
     }
     for (; r < r1; r += RG) {
@@ -339,20 +351,22 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const f32x4 *__restrict
             vmax = fmaxf(vmax, fabsf(v[j]));
         }
         z[e] = v;
+        if (zbits) put_bits(v, r);
     }
     if (amax) amax_update_block(amax, vmax);
 }
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *z, hipStream_t st, unsigned *amax, const float *res_a,
-                             const float *res_b, int res_relu) {
+                             const float *res_b, int res_relu, unsigned *zbits) {
     if (C % 4 || C / 4 > 256 || (size_t)B * rows_per_img * (C / 4) >= (1ull << 32)) return hipErrorInvalidValue;
+    if (zbits && (C % 32 || !relu)) return hipErrorInvalidValue;
     if ((res_a != nullptr) != (res_b != nullptr) || (res_a && !res)) return hipErrorInvalidValue;
     if (dbg_skip("aact")) return hipSuccess;
     const RowSplit rs = row_split(B, rows_per_img, C / 4);
     hipLaunchKernelGGL(affine_act_kernel, dim3(B * rs.blocks_per_img), dim3(rs.threads), 0, st,
                        reinterpret_cast<const f32x4 *>(y), a, b, reinterpret_cast<const f32x4 *>(res), C / 4, rs.rg,
                        (int)rows_per_img, rs.blocks_per_img, rs.rows_per_block, per_sample, relu, reinterpret_cast<f32x4 *>(z), amax,
-                       res_a, res_b, res_relu);
+                       res_a, res_b, res_relu, zbits);
     return hipGetLastError();
 }
 

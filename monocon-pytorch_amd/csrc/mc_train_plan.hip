@@ -54,6 +54,7 @@ struct Rec {
     Tensor y;
     float *mean = nullptr, *rstd = nullptr;
     float *ca = nullptr, *cb = nullptr;   // forward BN coefficients z = act(ca*y + cb (+ res))
+    unsigned *zbits = nullptr;            // residual layers: the ReLU mask of z, bit-packed by the forward (ConvArgs::bm_zbits)
     std::string bn;
 };
 
@@ -365,8 +366,14 @@ struct TB {   // train plan builder
             unsigned *zmax = ts->nodes[r.z].t.amax;
             const size_t rows = (size_t)Ho * Wo;
             const int C = Lr.cout, rl = relu;
+            // a residual layer's ReLU mask cannot be recomputed from y alone: the forward leaves it bit-packed for the
+            // backward-statistics epilogue of the data gradient that completes this map's gradient (1/32 of the bytes of z;
+            // MONOCON_HIP_ZBITS=0: that epilogue reads z as in rounds 1-5)
+            static const bool zbits_on = [] { const char *e = std::getenv("MONOCON_HIP_ZBITS"); return !e || std::atoi(e) != 0; }();
+            unsigned *zb = (zbits_on && res >= 0 && relu && C % 32 == 0) ? reinterpret_cast<unsigned *>(alloc((size_t)B * rows * (C / 32))) : nullptr;
+            r.zbits = zb;
             ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_affine_act(yp, ca, cb, rp, B, rows, C, 0, rl, zp, st, zmax, ra, rb, rrelu));
+                HIPCHK(hh, launch_affine_act(yp, ca, cb, rp, B, rows, C, 0, rl, zp, st, zmax, ra, rb, rrelu, zb));
                 return 0;
             });
         }
@@ -614,6 +621,7 @@ struct TB {   // train plan builder
             float *partial = alloc((size_t)nbp * cstride * 2);
             lc->stats = partial;
             lc->bm_y = yp; lc->bm_z = zp; lc->bm_a = fa; lc->bm_b = fb; lc->bm_relu = relu;
+            lc->bm_zbits = relu == 1 ? r.zbits : nullptr;
             if (wres_bwd >= 1 && !(lc->cfg & (CFG_SMALL | CFG_WS)) && conv_wres_ok(*lc, 3, 1)) lc->cfg |= CFG_WRES;      // (see emit_dgrad)
             if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
                 fprintf(stderr, "[plan]   twin of %-36s cfg %3d  K %4d  Cout %3d  %dx%d  res %d  nsrc %d srcC %d wres %d\n", bn.c_str(), lc->cfg,

@@ -116,7 +116,8 @@ hipError_t launch_bn_finalize(const float *partial, int nb, int Cstride, double 
 size_t partial_fold_doubles(int nb, int C);   // scratch for `fold` (0: the partial list is short, no pre-pass)
 hipError_t launch_affine_act(const float *y, const float *a, const float *b, const float *res, int B, size_t rows_per_img,
                              int C, int per_sample, int relu, float *z, hipStream_t st, unsigned *amax = nullptr,
-                             const float *res_a = nullptr, const float *res_b = nullptr, int res_relu = 0);   // lazy residual
+                             const float *res_a = nullptr, const float *res_b = nullptr, int res_relu = 0,    // lazy residual
+                             unsigned *zbits = nullptr);      // also the ReLU mask bit-packed, [row][C / 32] words (ConvArgs::bm_zbits)
 hipError_t launch_bn_bwd_finalize(const float *partial, int nb, int Cstride, double n, int C, const float *gamma,
                                   const float *mean, const float *rstd, float *dgamma, float *dbeta, float *coef,
                                   hipStream_t st, double *fold = nullptr);
