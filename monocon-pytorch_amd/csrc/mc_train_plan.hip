@@ -369,7 +369,7 @@ struct TB {   // train plan builder
             // a residual layer's ReLU mask cannot be recomputed from y alone: the forward leaves it bit-packed for the
             // backward-statistics epilogue of the data gradient that completes this map's gradient (1/32 of the bytes of z;
             // MONOCON_HIP_ZBITS=0: that epilogue reads z as in rounds 1-5)
-            static const bool zbits_on = [] { const char *e = std::getenv("MONOCON_HIP_ZBITS"); return !e || std::atoi(e) != 0; }();
+            const bool zbits_on = [] { const char *e = std::getenv("MONOCON_HIP_ZBITS"); return !e || std::atoi(e) != 0; }();      // (per plan build)
             unsigned *zb = (zbits_on && res >= 0 && relu && C % 32 == 0) ? reinterpret_cast<unsigned *>(alloc((size_t)B * rows * (C / 32))) : nullptr;
             r.zbits = zb;
             ts->fwd.push_back([=](mc_handle *hh, hipStream_t st) {

@@ -280,6 +280,51 @@ def test_train_step_is_independent_of_the_conv_tiling(golden_sd):
 
 
 
+def test_lazy_activations_track_the_stored_ones(golden_sd, monkeypatch):
+    """Round 6: in mode f16x2 the post-BatchNorm activations without residual are never stored -- every consumer
+    (conv / weight-gradient staging, pools, deconvs, the residual input of the next block) forms max(a * y + b, 0) on load
+    (model/backbone/dla.py:34-51, dla_neck.py:30-38 under train-mode BatchNorm).  With the same operand scale the staged
+    fp16 pieces are bit-identical to those of a stored map; the scale itself comes from a bound of max |z| instead of its
+    exact value, so the step agrees to round-off of the 22-bit operand split, not bit for bit.  MONOCON_HIP_LAZY_MIN=0 makes
+    every eligible map lazy at this small size.  The bit-packed ReLU mask of the residual layers (MONOCON_HIP_ZBITS) is the
+    same mask: bit-identical."""
+    from model import MonoConDetector
+    batch = to_cuda(synth.make_batch(GOLDEN_SEED + 12, 3, 128, 224))
+    res = {}
+    for tag, env in (("stored", {"MONOCON_HIP_LAZY_Z": "0"}),
+                     ("lazy", {"MONOCON_HIP_LAZY_Z": "3", "MONOCON_HIP_LAZY_MIN": "0"}),
+                     ("lazy_nobits", {"MONOCON_HIP_LAZY_Z": "3", "MONOCON_HIP_LAZY_MIN": "0", "MONOCON_HIP_ZBITS": "0"}),
+                     ("relu_only", {"MONOCON_HIP_LAZY_Z": "1", "MONOCON_HIP_LAZY_MIN": "0"})):
+        for k in ("MONOCON_HIP_LAZY_Z", "MONOCON_HIP_LAZY_MIN", "MONOCON_HIP_ZBITS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)              # read when the train plan is built
+        m = MonoConDetector(34, pretrained_backbone=False)
+        m.load_state_dict(golden_sd, strict=True)
+        m = m.cuda().train().set_precision("f16x2")
+        _, loss = m(batch)
+        sum(loss.values()).backward()
+        torch.cuda.synchronize()
+        res[tag] = ({k: float(v.detach()) for k, v in loss.items()},
+                    {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
+                    {n: b.detach().clone().double() for n, b in m.named_buffers()}, m._engine().workspace_bytes())
+    for k in res["lazy"][1]:                                   # the same ReLU masks, read from bits or from z
+        assert torch.equal(res["lazy"][1][k], res["lazy_nobits"][1][k]), k
+    assert res["lazy"][0] == res["lazy_nobits"][0]
+    assert res["lazy"][3] < res["relu_only"][3] < res["stored"][3]      # maps that are never allocated (at B = 32, 384x1280: 30.3 -> 24.4 GB)
+    for tag in ("lazy", "relu_only"):
+        for k, v in res["stored"][0].items():
+            assert abs(res[tag][0][k] - v) <= 2e-5 * abs(v) + 1e-7, (tag, k, res[tag][0][k], v)
+        worst = 0.0
+        for n, g in res["stored"][1].items():
+            a, b = res[tag][1][n].double(), g.double()
+            e = float((a - b).norm() / b.norm().clamp_min(1e-3 * (b.numel() ** 0.5) * float(b.abs().max().clamp_min(1e-30))))
+            worst = max(worst, e)
+            assert e <= 2e-3, (tag, n, e)
+        for n, b in res["stored"][2].items():
+            assert float((res[tag][2][n] - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7, (tag, n)
+
+
 @pytest.mark.parametrize("precision", ("fp32", "f16x2"))
 def test_head_backward_without_the_stored_gradient_is_bit_identical(golden_sd, precision, monkeypatch):
     """the AttnBN backward of the heads forms the ReLU-masked gradient of the nine 1x1 convs again from the raw prediction
