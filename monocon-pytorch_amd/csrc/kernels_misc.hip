@@ -225,38 +225,67 @@ __global__ __launch_bounds__(256) void deconv4_kernel(const f32x4 *__restrict__ 
                                                       const f32x4 *__restrict__ wpk, f32x4 *__restrict__ out,
                                                       unsigned *__restrict__ amax, const f32x4 *__restrict__ la,
                                                       const f32x4 *__restrict__ lb) {
+    // Round 6: the four output rows of a block share four input rows (h - 1 .. h + 2, h = oy0 / 2) and two input columns:
+    // all 8 inputs and 8 filter taps of the thread are requested up front (one output at a time, behind `continue`
+    // branches, the kernel had 16 dependent-ish loads per thread: 118 us for 315 MB at B = 32), then the four outputs are
+    // formed in the ORIGINAL order of their <= 4 terms (dy = 0: dx = 0, 1; dy = 1: dx = 0, 1) -- an absent input is a zero
+    // term, which leaves the sum's bits unchanged.
     const int Wo = 2 * W;
     float vmax = 0.f;          // max |out| of this thread (amax != null, see ConvArgs::amax_in)
     const unsigned ex = blockIdx.x * 256u + threadIdx.x;
     const int b = blockIdx.z;
+    const bool live = ex < (unsigned)(Wo * C4);
     const int c = (int)(ex % (unsigned)C4), ox = (int)(ex / (unsigned)C4);
-    f32x4 lav = {1.f, 1.f, 1.f, 1.f}, lbv = {0.f, 0.f, 0.f, 0.f};       // lazy input (ConvSrc::la in conv_mfma.h)
-    if (la && ex < (unsigned)(Wo * C4)) { lav = la[c]; lbv = lb[c]; }
-    for (int oy = blockIdx.y * 4; oy < min(2 * H, (int)blockIdx.y * 4 + 4) && ex < (unsigned)(Wo * C4); ++oy) {      // four output rows per block
-        const int iy1 = (oy + 1) >> 1, ky1 = oy + 1 - 2 * iy1;   // ky1 in {0,1}
+    if (live) {
+        const int oy0 = blockIdx.y * 4, h = oy0 >> 1;
         const int ix1 = (ox + 1) >> 1, kx1 = ox + 1 - 2 * ix1;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 v[4][2], w[4][2];
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            const int iy = iy1 - dy, ky = ky1 + 2 * dy;
-            if (iy < 0 || iy >= H) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int iy = h - 1 + r;
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                const int ix = ix1 - dx, kx = kx1 + 2 * dx;
-                if (ix < 0 || ix >= W) continue;
-                f32x4 v = in[(((size_t)b * H + iy) * W + ix) * C4 + c];
-                if (la) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], lav[j], lbv[j]), 0.f);
-                }
-                const f32x4 w = wpk[(ky * 4 + kx) * C4 + c];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[j], w[j], acc[j]);
+                const int ix = ix1 - dx;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                v[r][dx] = ok ? in[(((size_t)b * H + iy) * W + ix) * C4 + c] : zero;
+                w[r][dx] = wpk[(r * 4 + kx1 + 2 * dx) * C4 + c];          // filter row ky = r (used below by its own ky), column kx1 + 2 dx
             }
         }
-        out[(((size_t)b * (2 * H) + oy) * Wo) * C4 + ex] = acc;
+        if (la) {               // lazy input (ConvSrc::la in conv_mfma.h): formed on load; positions outside stay 0
+            const f32x4 lav = la[c], lbv = lb[c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(acc[j]));
+            for (int r = 0; r < 4; ++r) {
+                const int iy = h - 1 + r;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int ix = ix1 - dx;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[r][dx][j] = fmaxf(fmaf(v[r][dx][j], lav[j], lbv[j]), 0.f);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = oy0 + q;
+            if (oy >= 2 * H) break;
+            // oy = 2h + q: input row iy1 = h + (q + 1) / 2, filter row ky1 = 1 - q % 2 (compile-time: v / w stay registers)
+            f32x4 acc = zero;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int r = ((q + 1) >> 1) - dy + 1, ky = (1 - (q & 1)) + 2 * dy;      // row of v (input row h - 1 + r), filter row
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(v[r][dx][j], w[ky][dx][j], acc[j]);
+                }
+            }
+            out[(((size_t)b * (2 * H) + oy) * Wo) * C4 + ex] = acc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(acc[j]));
+        }
     }
     if (amax) amax_update_block(amax, vmax);
 }

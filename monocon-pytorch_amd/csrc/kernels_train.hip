@@ -650,9 +650,14 @@ hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C
 
 // ... and wrt the (C,1,4,4) weights: dw[c,ky,kx] = sum_{b,iy,ix} in[b,iy,ix,c] * dout[b,2iy-1+ky,2ix-1+kx,c].
 // One workgroup per (image row-block); partial [blocks][16][C] then reduced by colsum-like pass.
+// FUSED (round 6): with din / wpk given the same pass also forms the gradient wrt the input -- the two kernels read the same
+// 4x4 windows of dout (measured at B = 32: 502 + 556 MB for the 64-channel layers where 315 MB are algorithmic); the terms of
+// din are added in deconv4_bwd_data_kernel's order (ky outer, kx inner), so its bits do not change.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restrict__ in, const float *__restrict__ dout,
                                                             int B, int H, int W, int C, float *__restrict__ partial,
-                                                            const float *__restrict__ la, const float *__restrict__ lb) {
+                                                            const float *__restrict__ la, const float *__restrict__ lb,
+                                                            const f32x4 *__restrict__ wpk, f32x4 *__restrict__ din) {
     // one workgroup per (b, iy) input row; a thread owns 4 channels and every XG-th column, 16-byte
     // loads; the column groups are summed by wave shuffles + one LDS image (fixed order)
     __shared__ float red[16][256];
@@ -665,8 +670,14 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
     for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 lav = {1.f, 1.f, 1.f, 1.f}, lbv = {0.f, 0.f, 0.f, 0.f};       // lazy input (ConvSrc::la)
     if (la) { lav = reinterpret_cast<const f32x4 *>(la)[c4]; lbv = reinterpret_cast<const f32x4 *>(lb)[c4]; }
+    f32x4 wk[FUSED ? 16 : 1];
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wk[k] = wpk[k * C4 + c4];
+    }
     for (int ix = xg; ix < W; ix += XG) {
         f32x4 v = in4[(((size_t)b * H + iy) * W + ix) * C4 + c4];
+        [[maybe_unused]] f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
         if (la) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], lav[j], lbv[j]), 0.f);
@@ -682,8 +693,13 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
                 const f32x4 d = do4[(((size_t)b * 2 * H + oy) * 2 * W + ox) * C4 + c4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[ky * 4 + kx][j] = fmaf(v[j], d[j], acc[ky * 4 + kx][j]);
+                if constexpr (FUSED) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gacc[j] = fmaf(d[j], wk[ky * 4 + kx][j], gacc[j]);
+                }
             }
         }
+        if constexpr (FUSED) din[(((size_t)b * H + iy) * W + ix) * C4 + c4] = gacc;
     }
     // lanes c4 + C4*j of a wave hold the same channels
     for (int o = C4; o < 64; o <<= 1)
@@ -720,9 +736,13 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_reduce_kernel(const float *
 }
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C) { return (size_t)B * H * 16 * C; }
 hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
-                                hipStream_t st, const float *la, const float *lb) {
-    if (C % 4 || C > 256 || 256 % (C / 4)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(deconv4_bwd_w_kernel, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb);
+                                hipStream_t st, const float *la, const float *lb, const float *wpk, float *din) {
+    if (C % 4 || C > 256 || 256 % (C / 4) || (wpk != nullptr) != (din != nullptr)) return hipErrorInvalidValue;
+    if (din)
+        hipLaunchKernelGGL(deconv4_bwd_w_kernel<true>, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb,
+                           reinterpret_cast<const f32x4 *>(wpk), reinterpret_cast<f32x4 *>(din));
+    else
+        hipLaunchKernelGGL(deconv4_bwd_w_kernel<false>, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb, nullptr, nullptr);
     hipLaunchKernelGGL(deconv4_bwd_w_reduce_kernel, dim3(C * 16), dim3(256), 0, st, partial, B * H, C, dw);
     return hipGetLastError();
 }

@@ -992,9 +992,15 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             float *gi = b.g_acquire(r.in), *dw = b.G(r.D->name + ".weight");
             const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C;
             float *part = b.alloc(deconv4_bwd_w_partial_floats(Bq, Hq, Cq));
+            // MONOCON_HIP_DECONV_FUSE=0: the data gradient and the weight gradient of the depthwise deconv as two passes (rounds 1-5)
+            const bool dc_fuse = [] { const char *e = std::getenv("MONOCON_HIP_DECONV_FUSE"); return !e || std::atoi(e) != 0; }();
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_deconv4_bwd_data(go, Bq, Hq, Wq, Cq, wp, gi, st));
-                HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st, xla, xlb));
+                if (dc_fuse) {
+                    HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st, xla, xlb, wp, gi));
+                } else {
+                    HIPCHK(hh, launch_deconv4_bwd_data(go, Bq, Hq, Wq, Cq, wp, gi, st));
+                    HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st, xla, xlb));
+                }
                 return 0;
             });
             in.ginit = true;
