@@ -563,12 +563,20 @@ hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *part
 }
 
 // 2x2/2 max-pool backward: gradient goes to the first maximum in window scan order (torch)
-__global__ void maxpool2_bwd_kernel(const f32x4 *__restrict__ x, const f32x4 *__restrict__ dout, int B, int H, int W,
+// la / lb: x is a lazy tensor (ConvSrc::la) -- the window is compared on max(fma(y, la, lb), 0), the values the forward pooled.
+// STATS (round 6; lazy x, accumulate): this launch COMPLETES the gradient of x, a BatchNorm + ReLU output, so it also does what
+// the BatchNorm backward's reduction pass would: it applies the ReLU mask (the formed value > 0) to the total gradient it
+// writes and leaves the (sum d, sum d * y) partials per workgroup and channel in `partial` [gridDim.x][C][2] -- the
+// three-tensor chan_reduce pass over the map disappears, and the element-wise pass behind it needs no mask.  A thread keeps
+// ONE channel quad (the stride of the grid-stride loop is a multiple of C4); a workgroup's threads of a quad are folded in
+// thread order.
+template <bool STATS>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const f32x4 *__restrict__ x, const f32x4 *__restrict__ dout, int B, int H, int W,
                                     int C4, f32x4 *__restrict__ dx, int accumulate, const f32x4 *__restrict__ la,
-                                    const f32x4 *__restrict__ lb) {
-    // la / lb: x is a lazy tensor (ConvSrc::la) -- the window is compared on max(fma(y, la, lb), 0), the values the forward pooled
+                                    const f32x4 *__restrict__ lb, float *__restrict__ partial) {
     const int Ho = H / 2, Wo = W / 2;
     const size_t total = (size_t)B * Ho * Wo * C4;
+    [[maybe_unused]] f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int c = e % C4;
         const size_t p = e / C4;
@@ -577,6 +585,7 @@ __global__ void maxpool2_bwd_kernel(const f32x4 *__restrict__ x, const f32x4 *__
         const size_t i00 = ((b * H + 2 * oy) * W + 2 * ox) * C4 + c, i01 = i00 + C4, i10 = i00 + (size_t)W * C4, i11 = i10 + C4;
         f32x4 v00 = x[i00], v01 = x[i01], v10 = x[i10], v11 = x[i11];
         const f32x4 g = dout[e];
+        [[maybe_unused]] const f32x4 y00 = v00, y01 = v01, y10 = v10, y11 = v11;      // (STATS: the raw conv outputs)
         if (la) {
             const f32x4 av = la[c], bv = lb[c];
 #pragma unroll
@@ -595,21 +604,56 @@ __global__ void maxpool2_bwd_kernel(const f32x4 *__restrict__ x, const f32x4 *__
         }
         if (accumulate) {
             f32x4 t;
-            t = dx[i00]; for (int j = 0; j < 4; ++j) t[j] += g00[j]; dx[i00] = t;
-            t = dx[i01]; for (int j = 0; j < 4; ++j) t[j] += g01[j]; dx[i01] = t;
-            t = dx[i10]; for (int j = 0; j < 4; ++j) t[j] += g10[j]; dx[i10] = t;
-            t = dx[i11]; for (int j = 0; j < 4; ++j) t[j] += g11[j]; dx[i11] = t;
-        } else {
-            dx[i00] = g00; dx[i01] = g01; dx[i10] = g10; dx[i11] = g11;
+            t = dx[i00]; for (int j = 0; j < 4; ++j) g00[j] += t[j];
+            t = dx[i01]; for (int j = 0; j < 4; ++j) g01[j] += t[j];
+            t = dx[i10]; for (int j = 0; j < 4; ++j) g10[j] += t[j];
+            t = dx[i11]; for (int j = 0; j < 4; ++j) g11[j] += t[j];
+        }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g00[j] = v00[j] > 0.f ? g00[j] : 0.f; g01[j] = v01[j] > 0.f ? g01[j] : 0.f;
+                g10[j] = v10[j] > 0.f ? g10[j] : 0.f; g11[j] = v11[j] > 0.f ? g11[j] : 0.f;
+                s1[j] += g00[j]; s2[j] += g00[j] * y00[j];
+                s1[j] += g01[j]; s2[j] += g01[j] * y01[j];
+                s1[j] += g10[j]; s2[j] += g10[j] * y10[j];
+                s1[j] += g11[j]; s2[j] += g11[j] * y11[j];
+            }
+        }
+        dx[i00] = g00; dx[i01] = g01; dx[i10] = g10; dx[i11] = g11;
+    }
+    if constexpr (STATS) {
+        __shared__ float red[256 * 8];
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s1[j]; red[tid * 8 + 4 + j] = s2[j]; }
+        __syncthreads();
+        if (tid < C4) {          // (thread t holds quad t % C4: the loop's stride is a multiple of C4)
+            float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+            for (int t = tid; t < 256; t += C4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a1[j] += red[t * 8 + j]; a2[j] += red[t * 8 + 4 + j]; }
+            float *dst = partial + ((size_t)blockIdx.x * (4 * C4) + tid * 4) * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[j * 2] = a1[j]; dst[j * 2 + 1] = a2[j]; }
         }
     }
 }
+int maxpool2_bwd_blocks(int B, int H, int W, int C) { return grid_for((size_t)B * (H / 2) * (W / 2) * (C / 4), 256); }
 hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
-                               hipStream_t st, const float *la, const float *lb) {
+                               hipStream_t st, const float *la, const float *lb, float *stats_partial) {
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(x),
+    const int blocks = grid_for(total, 256);
+    if (stats_partial) {       // the fused BatchNorm-backward statistics: lazy x, a gradient to complete, a fixed quad per thread
+        if (!la || !lb || !accumulate || C % 4 || 256 % (C / 4)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(x),
+                           reinterpret_cast<const f32x4 *>(dout), B, H, W, C / 4, reinterpret_cast<f32x4 *>(dx), accumulate,
+                           reinterpret_cast<const f32x4 *>(la), reinterpret_cast<const f32x4 *>(lb), stats_partial);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(x),
                        reinterpret_cast<const f32x4 *>(dout), B, H, W, C / 4, reinterpret_cast<f32x4 *>(dx), accumulate,
-                       reinterpret_cast<const f32x4 *>(la), reinterpret_cast<const f32x4 *>(lb));
+                       reinterpret_cast<const f32x4 *>(la), reinterpret_cast<const f32x4 *>(lb), nullptr);
     return hipGetLastError();
 }
 

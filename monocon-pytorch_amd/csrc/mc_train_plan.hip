@@ -26,12 +26,21 @@ struct TNode {
     // the launch that wrote g last, when that is a generic stride-1 data-gradient conv (else null): its epilogue
     // sees the COMPLETE gradient of this map and can take over the reductions of the BatchNorm backward
     ConvArgs *last_conv = nullptr;
+    // ... or, when it was a max-pool backward that accumulated into g (round 6): that launch can mask the total and leave the
+    // BatchNorm-backward partials (launch_maxpool2_bwd's stats_partial)
+    struct PoolBwdArgs *last_pool = nullptr;
     // LAZY activation (round 6, precision mode 3): the post-BatchNorm map z = act(la[c] * y + lb[c]) is never written --
     // t.p is the producing layer's raw conv output y, and every consumer forms z while it loads its operand (ConvSrc::la
     // in conv_mfma.h; act = ReLU when lrelu).  null: t.p holds the values.  TB::materialise() turns a lazy node into a
     // stored one (an affine_act pass appended to the forward) for a consumer that cannot form it.
     const float *la = nullptr, *lb = nullptr;
     bool lrelu = true;
+};
+
+struct PoolBwdArgs {       // a max-pool backward launch (stable address: bn_backward may still attach `stats`)
+    const float *x, *dout, *la, *lb;
+    float *dx, *stats;
+    int B, H, W, C, acc;
 };
 
 struct PackJob {           // dgrad panel refreshed from the master weights before every forward
@@ -69,6 +78,7 @@ struct TrainState {
     std::vector<Rec> recs;
     std::vector<Fn> fwd, bwd;
     std::deque<ConvArgs> dgrads;     // data-gradient launches (stable addresses: bn_backward may still patch them)
+    std::deque<PoolBwdArgs> pool_bwds;
     // backward closures that only produce weight gradients (nothing downstream in the step reads them) run
     // on a second stream: MFMA-bound wgrad overlaps the HBM-bound BN passes and the tails of the dgrad chain
     std::vector<char> bwd_side;
@@ -487,7 +497,7 @@ struct TB {   // train plan builder
                     return 0;
                 });
                 sn.ginit = true;
-                sn.last_conv = nullptr;
+                sn.last_conv = nullptr; sn.last_pool = nullptr;
                 return;
             }
             for (int cls = 0; cls < 4; ++cls) {
@@ -512,7 +522,7 @@ struct TB {   // train plan builder
                 ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) { HIPCHK(hh, launch_conv(d, kk, 1, st)); return 0; });
             }
             sn.ginit = true;
-            sn.last_conv = nullptr;
+            sn.last_conv = nullptr; sn.last_pool = nullptr;
             return;
         }
         float *panel;
@@ -546,6 +556,7 @@ struct TB {   // train plan builder
         sn.ginit = true;
         // (the fp32 row kernel has no backward-statistics epilogue; its fp16-pipe replacement for 16 -> 16 layers has)
         sn.last_conv = (d.cfg == CFG_SMALL && !conv_thin_ok(d, ks, 1)) ? nullptr : dp;
+        sn.last_pool = nullptr;
     }
 
     void emit_wgrad(const std::vector<int> &srcs, const Tensor &dy, int dy_ld, int Cout, int ks, int stride, float *dw) {
@@ -601,7 +612,7 @@ struct TB {   // train plan builder
             gres = g_acquire(r.res);
             gmode = ts->nodes[r.res].ginit ? 2 : 1;
             ts->nodes[r.res].ginit = true;
-            ts->nodes[r.res].last_conv = nullptr;
+            ts->nodes[r.res].last_conv = nullptr; ts->nodes[r.res].last_pool = nullptr;
         }
         const double n = (double)B * rows;
         ConvArgs *lc = zn.last_conv;
@@ -645,6 +656,28 @@ struct TB {   // train plan builder
                 return 0;
             });
             return dy;
+        }
+        // the gradient of this map was completed by a max-pool backward over a LAZY map (it holds y, forms z for its window
+        // comparison anyway): that launch masks the total and leaves the partials -- no reduction pass (MONOCON_HIP_POOL_STATS=0: off)
+        {
+            const bool pool_stats = [] { const char *e = std::getenv("MONOCON_HIP_POOL_STATS"); return !e || std::atoi(e) != 0; }();
+            PoolBwdArgs *pl = zn.last_pool;
+            if (pool_stats && pl && relu == 2 && pl->la == fa && pl->lb == fb && pl->x == yp && pl->acc && pl->dx == zn.g && pl->C == C &&
+                pl->H * pl->W == rows && !pl->stats && !want_skip_affine && C % 4 == 0 && 256 % (C / 4) == 0) {
+                const int nbp = maxpool2_bwd_blocks(B, pl->H, pl->W, C);
+                float *partial = alloc((size_t)nbp * C * 2);
+                pl->stats = partial;
+                double *fold = fold_scratch(nbp, C);
+                if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
+                    fprintf(stderr, "[plan]   statistics of %-36s left by the max-pool backward (%d partial rows)\n", bn.c_str(), nbp);
+                ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
+                    HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, C, n, C, gamma, mean, rstd, dg, db, coef, st, fold));
+                    HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, 0, dyp, gres, gmode, st, nullptr, nullptr, nullptr,
+                                                 nullptr, dymax));
+                    return 0;
+                });
+                return dy;
+            }
         }
         const int nb = chan_reduce_blocks(B, rows);
         float *partial = alloc((size_t)nb * C * 2);
@@ -973,13 +1006,15 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             TNode &in = ts->nodes[r.in];
             const TNode &o = ts->nodes[r.z];
             if (!o.ginit || !in.needs_grad) continue;
-            const float *xp = in.t.p, *go = o.g, *xla = in.la, *xlb = in.lb;      // (lazy x: its ReLU'd values are compared)
             float *gi = b.g_acquire(r.in);
-            const int Bq = in.t.B, Hq = in.t.H, Wq = in.t.W, Cq = in.t.C, acc = in.ginit;
+            PoolBwdArgs pa{in.t.p, o.g, in.la, in.lb, gi, nullptr, in.t.B, in.t.H, in.t.W, in.t.C, in.ginit ? 1 : 0};     // (lazy x: its ReLU'd values are compared)
+            ts->pool_bwds.push_back(pa);
+            PoolBwdArgs *pp = &ts->pool_bwds.back();
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
-                HIPCHK(hh, launch_maxpool2_bwd(xp, go, Bq, Hq, Wq, Cq, gi, acc, st, xla, xlb));
+                HIPCHK(hh, launch_maxpool2_bwd(pp->x, pp->dout, pp->B, pp->H, pp->W, pp->C, pp->dx, pp->acc, st, pp->la, pp->lb, pp->stats));
                 return 0;
             });
+            in.last_pool = pp;
             in.ginit = true;
             in.last_conv = nullptr;
             b.g_release(r.z, -1);
@@ -1004,7 +1039,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
                 return 0;
             });
             in.ginit = true;
-            in.last_conv = nullptr;
+            in.last_conv = nullptr; in.last_pool = nullptr;
             b.g_release(r.z, -1);
         } else if (r.kind == REC_CONV) {
             if (r.dead || !ts->nodes[r.z].ginit) continue;

@@ -132,7 +132,9 @@ size_t colsum_partial_floats(size_t rows, int ld);
 hipError_t launch_colsum(const float *x, size_t rows, int C, int ld, float *partial, float *out, hipStream_t st);
 hipError_t launch_colsum_final(const float *partial, int nb, int C, float *out, hipStream_t st);   // partial [nb][C][2] -> out[C]
 hipError_t launch_maxpool2_bwd(const float *x, const float *dout, int B, int H, int W, int C, float *dx, int accumulate,
-                               hipStream_t st, const float *la = nullptr, const float *lb = nullptr);   // la / lb: lazy x (ConvSrc::la)
+                               hipStream_t st, const float *la = nullptr, const float *lb = nullptr,    // la / lb: lazy x (ConvSrc::la)
+                               float *stats_partial = nullptr);   // [maxpool2_bwd_blocks()][C][2]: also mask + BatchNorm-backward partials
+int maxpool2_bwd_blocks(int B, int H, int W, int C);
 hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C, const float *wpk, float *din,
                                    hipStream_t st);
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C);

@@ -373,15 +373,17 @@ def test_fused_stride2_thin_data_gradient_matches_the_four_class_launches(golden
         torch.cuda.synchronize()
         res.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     four, one = res
-    below = 0
+    below = differing = 0
     for n in four:
         if n.startswith("backbone.base_layer") or n.startswith("backbone.level0"):
             below += 1
-            assert not torch.equal(four[n], one[n]) or n.endswith(".bias")      # (it IS the other kernel)
+            differing += int(not torch.equal(four[n], one[n]))
             assert rel_err(one[n].cpu(), four[n].cpu()) < 1e-6, n
         else:
             assert torch.equal(four[n], one[n]), n
-    assert below == 6
+    # (it IS the other kernel: the six tensors below level1 differ at rounding level -- a 16-element BatchNorm gradient can
+    #  round to the same floats by chance, the 3x3 / 7x7 weight gradients cannot all do so)
+    assert below == 6 and differing >= 2
 
 
 def test_full_size_train_step_is_deterministic(golden_sd):
