@@ -697,21 +697,27 @@ hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C
 // FUSED (round 6): with din / wpk given the same pass also forms the gradient wrt the input -- the two kernels read the same
 // 4x4 windows of dout (measured at B = 32: 502 + 556 MB for the 64-channel layers where 315 MB are algorithmic); the terms of
 // din are added in deconv4_bwd_data_kernel's order (ky outer, kx inner), so its bits do not change.
-template <bool FUSED>
+// STATS (FUSED, lazy input): `in` is a BatchNorm + ReLU output with this deconv as its only consumer, so din IS its complete
+// gradient: it is masked here (formed value > 0) and the BatchNorm-backward partials (sum d, sum d * y) per workgroup and
+// channel go to `stats` [gridDim.x][C][2], summed like two more filter taps -- no reduction pass over the map.
+template <bool FUSED, bool STATS = false>
 __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restrict__ in, const float *__restrict__ dout,
                                                             int B, int H, int W, int C, float *__restrict__ partial,
                                                             const float *__restrict__ la, const float *__restrict__ lb,
-                                                            const f32x4 *__restrict__ wpk, f32x4 *__restrict__ din) {
+                                                            const f32x4 *__restrict__ wpk, f32x4 *__restrict__ din,
+                                                            float *__restrict__ stats) {
+    static_assert(!STATS || FUSED, "statistics of the gradient this pass forms");
     // one workgroup per (b, iy) input row; a thread owns 4 channels and every XG-th column, 16-byte
     // loads; the column groups are summed by wave shuffles + one LDS image (fixed order)
-    __shared__ float red[16][256];
+    constexpr int NA = STATS ? 18 : 16;          // accumulators: the 16 taps (+ the two statistics sums)
+    __shared__ float red[NA][256];
     const int C4 = C >> 2, XG = 256 / C4;
     const int tid = threadIdx.x, c4 = tid % C4, xg = tid / C4;
     const int b = blockIdx.x / H, iy = blockIdx.x % H;
     const f32x4 *in4 = reinterpret_cast<const f32x4 *>(in), *do4 = reinterpret_cast<const f32x4 *>(dout);
-    f32x4 acc[16];
+    f32x4 acc[NA];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NA; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 lav = {1.f, 1.f, 1.f, 1.f}, lbv = {0.f, 0.f, 0.f, 0.f};       // lazy input (ConvSrc::la)
     if (la) { lav = reinterpret_cast<const f32x4 *>(la)[c4]; lbv = reinterpret_cast<const f32x4 *>(lb)[c4]; }
     f32x4 wk[FUSED ? 16 : 1];
@@ -722,6 +728,7 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
     for (int ix = xg; ix < W; ix += XG) {
         f32x4 v = in4[(((size_t)b * H + iy) * W + ix) * C4 + c4];
         [[maybe_unused]] f32x4 gacc = {0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] const f32x4 yraw = v;
         if (la) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], lav[j], lbv[j]), 0.f);
@@ -743,12 +750,20 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
                 }
             }
         }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gacc[j] = v[j] > 0.f ? gacc[j] : 0.f;
+                acc[16][j] += gacc[j];
+                acc[17][j] = fmaf(gacc[j], yraw[j], acc[17][j]);
+            }
+        }
         if constexpr (FUSED) din[(((size_t)b * H + iy) * W + ix) * C4 + c4] = gacc;
     }
     // lanes c4 + C4*j of a wave hold the same channels
     for (int o = C4; o < 64; o <<= 1)
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < NA; ++k)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[k][j] += __shfl_xor(acc[k][j], o);
     const int wave = tid >> 6, lane = tid & 63;
@@ -756,7 +771,7 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
         if (wave == w && lane < C4 && lane < 64) {
             // with C4 = 64 a wave covers all channel groups once; otherwise lanes < C4 hold the wave's sum
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
+            for (int k = 0; k < NA; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float *dst = &red[k][(tid % C4) * 4 + j];
@@ -766,6 +781,9 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
         __syncthreads();
     }
     for (int e = tid; e < 16 * C; e += 256) partial[(size_t)blockIdx.x * 16 * C + e] = red[e / C][e % C];
+    if constexpr (STATS) {
+        for (int e = tid; e < 2 * C; e += 256) stats[((size_t)blockIdx.x * C + e % C) * 2 + e / C] = red[16 + e / C][e % C];
+    }
 }
 __global__ __launch_bounds__(256) void deconv4_bwd_w_reduce_kernel(const float *__restrict__ partial, int nblocks, int C,
                                                                    float *__restrict__ dw /*(C,1,4,4)*/) {
@@ -780,13 +798,18 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_reduce_kernel(const float *
 }
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C) { return (size_t)B * H * 16 * C; }
 hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
-                                hipStream_t st, const float *la, const float *lb, const float *wpk, float *din) {
+                                hipStream_t st, const float *la, const float *lb, const float *wpk, float *din, float *stats) {
     if (C % 4 || C > 256 || 256 % (C / 4) || (wpk != nullptr) != (din != nullptr)) return hipErrorInvalidValue;
-    if (din)
-        hipLaunchKernelGGL(deconv4_bwd_w_kernel<true>, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb,
-                           reinterpret_cast<const f32x4 *>(wpk), reinterpret_cast<f32x4 *>(din));
+    if (stats && (!din || !la || !lb)) return hipErrorInvalidValue;
+    if (stats)
+        hipLaunchKernelGGL((deconv4_bwd_w_kernel<true, true>), dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb,
+                           reinterpret_cast<const f32x4 *>(wpk), reinterpret_cast<f32x4 *>(din), stats);
+    else if (din)
+        hipLaunchKernelGGL((deconv4_bwd_w_kernel<true, false>), dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb,
+                           reinterpret_cast<const f32x4 *>(wpk), reinterpret_cast<f32x4 *>(din), nullptr);
     else
-        hipLaunchKernelGGL(deconv4_bwd_w_kernel<false>, dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb, nullptr, nullptr);
+        hipLaunchKernelGGL((deconv4_bwd_w_kernel<false, false>), dim3(B * H), dim3(256), 0, st, in, dout, B, H, W, C, partial, la, lb, nullptr, nullptr,
+                           nullptr);
     hipLaunchKernelGGL(deconv4_bwd_w_reduce_kernel, dim3(C * 16), dim3(256), 0, st, partial, B * H, C, dw);
     return hipGetLastError();
 }

@@ -29,6 +29,7 @@ struct TNode {
     // ... or, when it was a max-pool backward that accumulated into g (round 6): that launch can mask the total and leave the
     // BatchNorm-backward partials (launch_maxpool2_bwd's stats_partial)
     struct PoolBwdArgs *last_pool = nullptr;
+    float **last_deconv_stats = nullptr;      // ... or the fused depthwise-deconv backward (this map's only consumer): where to attach `stats`
     // LAZY activation (round 6, precision mode 3): the post-BatchNorm map z = act(la[c] * y + lb[c]) is never written --
     // t.p is the producing layer's raw conv output y, and every consumer forms z while it loads its operand (ConvSrc::la
     // in conv_mfma.h; act = ReLU when lrelu).  null: t.p holds the values.  TB::materialise() turns a lazy node into a
@@ -79,6 +80,7 @@ struct TrainState {
     std::vector<Fn> fwd, bwd;
     std::deque<ConvArgs> dgrads;     // data-gradient launches (stable addresses: bn_backward may still patch them)
     std::deque<PoolBwdArgs> pool_bwds;
+    std::deque<float *> deconv_stats;      // per fused deconv backward: its statistics buffer (null until bn_backward attaches one)
     // backward closures that only produce weight gradients (nothing downstream in the step reads them) run
     // on a second stream: MFMA-bound wgrad overlaps the HBM-bound BN passes and the tails of the dgrad chain
     std::vector<char> bwd_side;
@@ -679,6 +681,25 @@ struct TB {   // train plan builder
                 return dy;
             }
         }
+        // ... or by the fused backward of the depthwise deconv that is its only consumer (neck proj -> up): same contract
+        if (float **ds = zn.last_deconv_stats) {
+            const bool dc_stats = [] { const char *e = std::getenv("MONOCON_HIP_DECONV_STATS"); return !e || std::atoi(e) != 0; }();
+            if (dc_stats && relu == 2 && zn.la == fa && zn.lb == fb && !*ds && !want_skip_affine && !gres) {
+                const int nbp = B * r.y.H;            // one workgroup per (image, row) of the deconv's input
+                float *partial = alloc((size_t)nbp * C * 2);
+                *ds = partial;
+                double *fold = fold_scratch(nbp, C);
+                if (std::getenv("MONOCON_HIP_PLAN_DEBUG"))
+                    fprintf(stderr, "[plan]   statistics of %-36s left by the deconv backward (%d partial rows)\n", bn.c_str(), nbp);
+                ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
+                    HIPCHK(hh, launch_bn_bwd_finalize(partial, nbp, C, n, C, gamma, mean, rstd, dg, db, coef, st, fold));
+                    HIPCHK(hh, launch_affine_bwd(gz, zp, yp, coef, B, (size_t)rows, C, 0, 0, dyp, nullptr, 0, st, nullptr, nullptr, nullptr,
+                                                 nullptr, dymax));
+                    return 0;
+                });
+                return dy;
+            }
+        }
         const int nb = chan_reduce_blocks(B, rows);
         float *partial = alloc((size_t)nb * C * 2);
         double *fold2 = fold_scratch(nb, C);      // (61 440 partial rows at full resolution: 16 workgroups walking them took 87 us)
@@ -1029,9 +1050,11 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             float *part = b.alloc(deconv4_bwd_w_partial_floats(Bq, Hq, Cq));
             // MONOCON_HIP_DECONV_FUSE=0: the data gradient and the weight gradient of the depthwise deconv as two passes (rounds 1-5)
             const bool dc_fuse = [] { const char *e = std::getenv("MONOCON_HIP_DECONV_FUSE"); return !e || std::atoi(e) != 0; }();
+            ts->deconv_stats.push_back(nullptr);
+            float **dstats = &ts->deconv_stats.back();
             ts->bwd.push_back([=](mc_handle *hh, hipStream_t st) {
                 if (dc_fuse) {
-                    HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st, xla, xlb, wp, gi));
+                    HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st, xla, xlb, wp, gi, *dstats));
                 } else {
                     HIPCHK(hh, launch_deconv4_bwd_data(go, Bq, Hq, Wq, Cq, wp, gi, st));
                     HIPCHK(hh, launch_deconv4_bwd_w(xp, go, Bq, Hq, Wq, Cq, part, dw, st, xla, xlb));
@@ -1040,6 +1063,7 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             });
             in.ginit = true;
             in.last_conv = nullptr; in.last_pool = nullptr;
+            in.last_deconv_stats = (dc_fuse && xla && xlb) ? dstats : nullptr;
             b.g_release(r.z, -1);
         } else if (r.kind == REC_CONV) {
             if (r.dead || !ts->nodes[r.z].ginit) continue;

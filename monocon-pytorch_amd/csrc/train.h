@@ -140,7 +140,8 @@ hipError_t launch_deconv4_bwd_data(const float *dout, int B, int H, int W, int C
 size_t deconv4_bwd_w_partial_floats(int B, int H, int C);
 hipError_t launch_deconv4_bwd_w(const float *in, const float *dout, int B, int H, int W, int C, float *partial, float *dw,
                                 hipStream_t st, const float *la = nullptr, const float *lb = nullptr,    // la / lb: lazy in
-                                const float *wpk = nullptr, float *din = nullptr);   // both given: the same pass also writes din (= launch_deconv4_bwd_data)
+                                const float *wpk = nullptr, float *din = nullptr,   // both given: the same pass also writes din (= launch_deconv4_bwd_data)
+                                float *stats = nullptr);   // [B * H][C][2] (lazy `in` only): din masked by its ReLU + its BatchNorm-backward partials
 
 // ---- head / stem train kernels (kernels_head_train.hip)
 hipError_t launch_pack_conv_w_dgrad(const float *w, int Cout, int CinTotal, int k, int c_off, int Cs, int CsP, int CoutPad,
