@@ -733,22 +733,34 @@ __global__ __launch_bounds__(256) void deconv4_bwd_w_kernel(const float *__restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], lav[j], lbv[j]), 0.f);
         }
+        // the 16 dout values of the window in two batches of eight, requested before any is used (behind `continue` branches the
+        // loads were issued and waited for one at a time); a tap outside the map contributes an exact zero term
 #pragma unroll
-        for (int ky = 0; ky < 4; ++ky) {
-            const int oy = 2 * iy - 1 + ky;
-            if (oy < 0 || oy >= 2 * H) continue;
+        for (int kh = 0; kh < 2; ++kh) {
+            f32x4 dv[2][4];
 #pragma unroll
-            for (int kx = 0; kx < 4; ++kx) {
-                const int ox = 2 * ix - 1 + kx;
-                if (ox < 0 || ox >= 2 * W) continue;
-                const f32x4 d = do4[(((size_t)b * 2 * H + oy) * 2 * W + ox) * C4 + c4];
+            for (int q = 0; q < 2; ++q) {
+                const int oy = 2 * iy - 1 + 2 * kh + q;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[ky * 4 + kx][j] = fmaf(v[j], d[j], acc[ky * 4 + kx][j]);
-                if constexpr (FUSED) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) gacc[j] = fmaf(d[j], wk[ky * 4 + kx][j], gacc[j]);
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int ox = 2 * ix - 1 + kx;
+                    const bool ok = oy >= 0 && oy < 2 * H && ox >= 0 && ox < 2 * W;
+                    dv[q][kx] = ok ? do4[(((size_t)b * 2 * H + oy) * 2 * W + ox) * C4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx) {
+                    const int k = (2 * kh + q) * 4 + kx;
+                    const f32x4 d = dv[q][kx];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(v[j], d[j], acc[k][j]);
+                    if constexpr (FUSED) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gacc[j] = fmaf(d[j], wk[k][j], gacc[j]);
+                    }
+                }
         }
         if constexpr (STATS) {
 #pragma unroll
