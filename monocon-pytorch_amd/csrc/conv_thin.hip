@@ -559,10 +559,23 @@ __global__ __launch_bounds__(256) void wgrad_thin16_kernel(const WgradArgs a) {
             if (lazy) okm |= (((unsigned)vo0 < x_bytes ? 1u : 0u) | ((unsigned)vo1 < x_bytes ? 2u : 0u)) << (2 * i);
         }
     };
-    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    // dY of a tile (the wave's row: 4 groups of 32 pixels x 8 dword loads) is requested ONE TILE AHEAD, together with the next
+    // X window: loaded where it is converted, every tile paid a full memory latency with one other wave per SIMD to cover it
+    // (round 6; the kernel reached 3.3 TB/s alone).  Past the last tile the same tile is requested again and never used: the
+    // loads stay unconditional (hipcc's wait counts are path-insensitive).
+    float araw[WT_XT / 32][8];
+    auto fetch_dy = [&](int tl, float (&dst)[WT_XT / 32][8]) {
         const int b = tl / (tiles_y * tiles_x), rem = tl - b * tiles_y * tiles_x;
-        const int y0 = (rem / tiles_x) * 4, x0 = (rem % tiles_x) * WT_XT;
+        const int y = (rem / tiles_x) * 4 + wave, x0 = (rem % tiles_x) * WT_XT;
+        const __amdgpu_buffer_rsrc_t r_dy =
+            make_rsrc(a.dy + ((size_t)b * H + (y < H ? y : 0)) * W * a.dy_ld, y < H ? (unsigned)(W * a.dy_ld) * 4u : 0u);
+#pragma unroll
+        for (int G = 0; G < WT_XT / 32; ++G)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) dst[G][t] = buf_load1(r_dy, va + t * 64, (x0 + G * 32) * 64);      // beyond the row: zero
+    };
+    if ((int)blockIdx.x < ntiles) { fetch(blockIdx.x); fetch_dy(blockIdx.x, araw); }
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         __syncthreads();                         // the previous tile's reads are done
 #pragma unroll
         for (int i = 0; i < NIW; ++i) {
@@ -580,15 +593,10 @@ __global__ __launch_bounds__(256) void wgrad_thin16_kernel(const WgradArgs a) {
             }
         }
         __syncthreads();
-        if (tl + (int)gridDim.x < ntiles) fetch(tl + gridDim.x);
-        const int y = y0 + wave;
-        const __amdgpu_buffer_rsrc_t r_dy =
-            make_rsrc(a.dy + ((size_t)b * H + (y < H ? y : 0)) * W * a.dy_ld, y < H ? (unsigned)(W * a.dy_ld) * 4u : 0u);
-        float araw[WT_XT / 32][8];
-#pragma unroll
-        for (int G = 0; G < WT_XT / 32; ++G)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) araw[G][t] = buf_load1(r_dy, va + t * 64, (x0 + G * 32) * 64);      // beyond the row: zero
+        const int tnext = tl + (int)gridDim.x < ntiles ? tl + (int)gridDim.x : tl;
+        if (tl + (int)gridDim.x < ntiles) fetch(tnext);
+        float anext[WT_XT / 32][8];
+        fetch_dy(tnext, anext);
 #pragma unroll
         for (int G = 0; G < WT_XT / 32; ++G) {
             f16x8 ah, al;
@@ -625,6 +633,10 @@ __global__ __launch_bounds__(256) void wgrad_thin16_kernel(const WgradArgs a) {
                 }
             }
         }
+#pragma unroll
+        for (int G = 0; G < WT_XT / 32; ++G)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) araw[G][t] = anext[G][t];
     }
     // workgroup reduction, wave after wave (fixed order).  D: row (n) = 4 * (lane >> 4) + q, column (c) = lane & 15
     __syncthreads();
