@@ -316,7 +316,8 @@ struct TB {   // train plan builder
         });
     }
 
-    int conv_bn(ConvLayer &Lr, const std::vector<int> &srcs, int res, bool relu, bool dead = false, bool elementwise_consumers = false) {
+    int conv_bn(ConvLayer &Lr, const std::vector<int> &srcs, int res, bool relu, bool dead = false, bool elementwise_consumers = false,
+                bool never_lazy = false) {
         const Tensor s0 = ts->nodes[srcs[0]].t;   // by value: node() below may reallocate ts->nodes
         const int B = s0.B;
         const int Ho = (s0.H + 2 * (Lr.ks / 2) - Lr.ks) / Lr.stride + 1, Wo = (s0.W + 2 * (Lr.ks / 2) - Lr.ks) / Lr.stride + 1;
@@ -325,7 +326,7 @@ struct TB {   // train plan builder
         r.y.B = B; r.y.H = Ho; r.y.W = Wo; r.y.C = Lr.cout;
         r.y.p = alloc(r.y.numel());
         // lazy output: BatchNorm (+ ReLU) without residual in mode 3 (the convs of every kernel family leave max |y|)
-        const bool lazy = !dead && res < 0 && h->prec == 3 && (lazy_mask & (relu ? 1 : 2)) != 0 &&
+        const bool lazy = !dead && !never_lazy && res < 0 && h->prec == 3 && (lazy_mask & (relu ? 1 : 2)) != 0 &&
                           (!relu || elementwise_consumers || (long long)Ho * Wo * Lr.cout >= lazy_min);
         r.z = dead ? -1 : node(B, Ho, Wo, Lr.cout, true, !lazy);
         ConvArgs a{};
@@ -808,7 +809,12 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             const std::string pre = "neck.ida_" + std::to_string(i) + ".", tsn = std::to_string(t);
             const int p = b.conv_bn(b.L(pre + "proj_" + tsn + ".conv"), {layers[j + t]}, -1, true, false, /*elementwise_consumers=*/true);
             const int u = b.deconv(h->deconvs[pre + "up_" + tsn], p);
-            layers[j + t] = b.conv_bn(b.L(pre + "node_" + tsn + ".conv"), {layers[j + t - 1], u}, -1, true);
+            // the neck's LAST node is `feat`: its consumers are the fused 64 -> 576 head conv and that conv's weight gradient, the
+            // two longest launches of the step -- formed on load it cost them 0.15 + 0.22 ms (alone) to save a 0.095 ms pass:
+            // stored (MONOCON_HIP_LAZY_FEAT=1: lazy like the other nodes)
+            static const bool lazy_feat = [] { const char *e = std::getenv("MONOCON_HIP_LAZY_FEAT"); return e && std::atoi(e) != 0; }();
+            const bool is_feat = i == 2 && t == 3;
+            layers[j + t] = b.conv_bn(b.L(pre + "node_" + tsn + ".conv"), {layers[j + t - 1], u}, -1, true, false, false, is_feat && !lazy_feat);
         }
     }
     feat = layers[3];
