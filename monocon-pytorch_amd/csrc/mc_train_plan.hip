@@ -812,7 +812,8 @@ static TrainState *build_train(mc_handle *h, int B, int H, int W, bool head_only
             // the neck's LAST node is `feat`: its consumers are the fused 64 -> 576 head conv and that conv's weight gradient, the
             // two longest launches of the step -- formed on load it cost them 0.15 + 0.22 ms (alone) to save a 0.095 ms pass:
             // stored (MONOCON_HIP_LAZY_FEAT=1: lazy like the other nodes)
-            static const bool lazy_feat = [] { const char *e = std::getenv("MONOCON_HIP_LAZY_FEAT"); return e && std::atoi(e) != 0; }();
+            const char *lf_env = std::getenv("MONOCON_HIP_LAZY_FEAT");                  // read per plan build
+            const bool lazy_feat = lf_env && std::atoi(lf_env) != 0;
             const bool is_feat = i == 2 && t == 3;
             layers[j + t] = b.conv_bn(b.L(pre + "node_" + tsn + ".conv"), {layers[j + t - 1], u}, -1, true, false, false, is_feat && !lazy_feat);
         }

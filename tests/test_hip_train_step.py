@@ -287,15 +287,17 @@ def test_lazy_activations_track_the_stored_ones(golden_sd, monkeypatch):
     fp16 pieces are bit-identical to those of a stored map; the scale itself comes from a bound of max |z| instead of its
     exact value, so the step agrees to round-off of the 22-bit operand split, not bit for bit.  MONOCON_HIP_LAZY_MIN=0 makes
     every eligible map lazy at this small size.  The bit-packed ReLU mask of the residual layers (MONOCON_HIP_ZBITS) is the
-    same mask: bit-identical."""
+    same mask: bit-identical.  `feat`, the input of the heads, is stored by default (its consumers are the two longest launches of
+    the step); MONOCON_HIP_LAZY_FEAT=1 makes it lazy like the other nodes."""
     from model import MonoConDetector
     batch = to_cuda(synth.make_batch(GOLDEN_SEED + 12, 3, 128, 224))
     res = {}
     for tag, env in (("stored", {"MONOCON_HIP_LAZY_Z": "0"}),
                      ("lazy", {"MONOCON_HIP_LAZY_Z": "3", "MONOCON_HIP_LAZY_MIN": "0"}),
                      ("lazy_nobits", {"MONOCON_HIP_LAZY_Z": "3", "MONOCON_HIP_LAZY_MIN": "0", "MONOCON_HIP_ZBITS": "0"}),
+                     ("lazy_feat", {"MONOCON_HIP_LAZY_Z": "3", "MONOCON_HIP_LAZY_MIN": "0", "MONOCON_HIP_LAZY_FEAT": "1"}),
                      ("relu_only", {"MONOCON_HIP_LAZY_Z": "1", "MONOCON_HIP_LAZY_MIN": "0"})):
-        for k in ("MONOCON_HIP_LAZY_Z", "MONOCON_HIP_LAZY_MIN", "MONOCON_HIP_ZBITS"):
+        for k in ("MONOCON_HIP_LAZY_Z", "MONOCON_HIP_LAZY_MIN", "MONOCON_HIP_ZBITS", "MONOCON_HIP_LAZY_FEAT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)              # read when the train plan is built
@@ -311,8 +313,8 @@ def test_lazy_activations_track_the_stored_ones(golden_sd, monkeypatch):
     for k in res["lazy"][1]:                                   # the same ReLU masks, read from bits or from z
         assert torch.equal(res["lazy"][1][k], res["lazy_nobits"][1][k]), k
     assert res["lazy"][0] == res["lazy_nobits"][0]
-    assert res["lazy"][3] < res["relu_only"][3] < res["stored"][3]      # maps that are never allocated (at B = 32, 384x1280: 30.3 -> 24.4 GB)
-    for tag in ("lazy", "relu_only"):
+    assert res["lazy_feat"][3] < res["lazy"][3] < res["relu_only"][3] < res["stored"][3]      # maps that are never allocated (at B = 32, 384x1280: 30.3 -> 24.4 GB)
+    for tag in ("lazy", "lazy_feat", "relu_only"):
         for k, v in res["stored"][0].items():
             assert abs(res[tag][0][k] - v) <= 2e-5 * abs(v) + 1e-7, (tag, k, res[tag][0][k], v)
         worst = 0.0
