@@ -47,6 +47,8 @@ for p in (os.path.join(REPO, "monocon-pytorch_amd"), REPO):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL's peer mappings (read at runtime init)
+
 import numpy as np
 import torch
 
