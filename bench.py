@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--precision", default=os.environ.get("MONOCON_BENCH_PRECISION", "f16x2"), choices=("f16x2", "bf16x3", "fp32"),
                     help="precision mode of the headline value: all three keep fp32 values and meet the fp32 parity tolerances")
+    ap.add_argument("--feed-steps", type=int, default=32,
+                    help="steps per epoch of the engine_feed leg (N=1 only: RingLoader workers -> pinned ring -> copy stream -> "
+                         "step, the engine's own loop); 0 = skip")
+    ap.add_argument("--feed-workers", type=int, default=8)
     ap.add_argument("--realistic-steps", type=int, default=6,
                     help="steps of the realistic_loop leg (fresh labels + H2D of uint8 frames + loss.item() per step); 0 = skip")
     ap.add_argument("--strict-comm", action="store_true",
@@ -311,6 +315,9 @@ def compact_line(out, full_path):
         c["modes"] = modes
     if out.get("realistic_loop"):
         c["realistic_loop"] = {"img_s": out["realistic_loop"]["images_per_sec"], "ms": out["realistic_loop"]["ms_per_step"]}
+    if out.get("engine_feed") and "ms_per_step" in out["engine_feed"]:
+        c["engine_feed"] = {"img_s": out["engine_feed"]["images_per_sec"], "ms": out["engine_feed"]["ms_per_step"],
+                            "workers": out["engine_feed"]["workers"]}
     if out.get("input_feed"):
         c["input_feed"] = {k: v for k, v in out["input_feed"].items() if k != "note"}
     if out.get("decode_only"):     # BASELINE configs[4]
@@ -499,6 +506,54 @@ def main():
                             "host sync), uint8 HWC frames host -> device (pinned, second stream, %.0f MB/step) + mc_preprocess, "
                             "total_loss.item() every step" % (B * H * W * 3 / 1e6)}
 
+    def engine_feed_leg(mode, steps, workers):
+        """The headline step fed the way MonoconEngine.train_one_epoch feeds it (engine/monocon_engine.py, hipmonocon/feed.py):
+        worker processes write float32 CHW frames (the reference's collate contract, monocon_dataset.py:173-200) into the
+        shared page-locked ring, the batch is uploaded one step ahead on a copy stream, the labels are checked on the host,
+        the loss of each step is read back one step late.  One epoch to start the workers, one timed (its first batch waits for a worker to fill a
+        slot: ~0.1 s once per epoch, in the number)."""
+        from dataset.synthetic_dataset import PooledSyntheticDataset
+        from hipmonocon.feed import DeferredScalars, DevicePrefetcher, RingLoader
+        m.train().set_precision(mode)
+        ds = PooledSyntheticDataset(B * steps, H, W, pool=8, seed=900)
+        ring = RingLoader(ds, B, workers, shuffle=True, collate_fn=ds.collate_fn)
+        try:
+            def epoch():
+                losses, got, t_wait = DeferredScalars(), [], 0.0
+                it = iter(DevicePrefetcher(ring, torch.device("cuda", torch.cuda.current_device()), m))
+                while True:
+                    ta = time.perf_counter()
+                    batch = next(it, None)
+                    t_wait += time.perf_counter() - ta
+                    if batch is None:
+                        break
+                    opt.zero_grad()
+                    _, loss = m(batch)
+                    total = sum(v for v in loss.values())
+                    total.backward()
+                    losses.push(total)
+                    opt.step()
+                    sch.step()
+                    got += losses.ready(1)
+                return got + losses.ready(0), t_wait
+            epoch()
+            sync_all()
+            t0 = time.perf_counter()
+            got, t_wait = epoch()
+            sync_all()
+            dt = time.perf_counter() - t0
+            pinned = bool(ring.pinned)
+        finally:
+            ring.close()
+        assert len(got) == steps and all(np.isfinite(v) for v in got)
+        return {"ms_per_step": round(dt / steps * 1e3, 3), "images_per_sec": round(B * steps / dt, 2), "steps": steps,
+                "workers": workers, "host_ms_per_step_waiting_for_the_batch": round(t_wait / steps * 1e3, 3),
+                "ring_gb": round(ring.ring.numel() * 4 / 1e9, 2), "pinned": pinned,
+                "workload": "headline train step fed by the engine's loop: %d fork-server workers write float32 CHW frames "
+                            "(%.0f MB per batch, pre-drawn samples) into a shared page-locked ring of %d batch slots, upload "
+                            "one step ahead on a copy stream, labels checked on the host, loss read back one step late"
+                            % (workers, B * 3 * H * W * 4 / 1e6, ring.nslots)}
+
     def forward_leg(mode, steps):
         m.eval().set_precision(mode)
         eng = m._engine()           # re-binds the (updated) parameters for the eval plan
@@ -594,6 +649,13 @@ def main():
     if args.realistic_steps > 0:
         _phase("realistic loop (fresh labels, H2D of uint8 frames on a second stream, loss.item() per step)")
         real = realistic_leg(headline_mode, args.realistic_steps)
+    feed = None
+    if args.feed_steps > 0 and world == 1:
+        _phase("engine feed (RingLoader workers -> pinned ring -> copy stream -> step)")
+        try:
+            feed = engine_feed_leg(headline_mode, args.feed_steps, args.feed_workers)
+        except Exception as e:      # noqa: BLE001  (a host without /dev/shm room, ...: reported, the bench line stands)
+            feed = {"error": "%s: %s" % (type(e).__name__, e)}
     m.set_precision(headline_mode)
     eng = m.eval()._engine()
 
@@ -689,6 +751,8 @@ def main():
                 out["fp32_emulated_f16x2"] = blk
         if real is not None:
             out["realistic_loop"] = real
+        if feed is not None:
+            out["engine_feed"] = feed
         if dist_on:
             out["multi_gpu"] = {k: head[k] for k in ("per_rank_ms_per_step", "per_rank_exposed_allreduce_ms", "comm") if k in head}
             comm = head.get("comm") or {}

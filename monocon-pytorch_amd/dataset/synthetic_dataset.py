@@ -35,3 +35,22 @@ class SyntheticMonoConDataset(Dataset):
         """no KITTI ground truth to score against: report detection counts only."""
         n3d = sum(len(r['boxes_3d']) if isinstance(r, dict) and 'boxes_3d' in r else 0 for r in results.get('img_bbox', []))
         return {'num_results': float(len(results.get('img_bbox', []))), 'num_boxes_3d': float(n3d)}
+
+
+class PooledSyntheticDataset(Dataset):
+    """``length`` samples handed out as copies of ``pool`` pre-drawn ones (drawing a 384x1280 sample costs ~0.4 s: too slow to
+    time a feed with).  Same sample dicts and collate as SyntheticMonoConDataset."""
+
+    def __init__(self, length: int, height: int = 384, width: int = 1280, pool: int = 8, seed: int = 0):
+        base = SyntheticMonoConDataset(length=pool, height=height, width=width, seed=seed)
+        self.length, self.pool = length, [base[i] for i in range(pool)]
+
+    collate_fn = staticmethod(SyntheticMonoConDataset.collate_fn)
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx: int) -> Dict[str, Any]:
+        d = self.pool[idx % len(self.pool)]
+        return {'img': d['img'].clone(), 'label': {k: v.clone() for k, v in d['label'].items()}, 'calib': d['calib'],
+                'img_metas': dict(d['img_metas'], sample_idx=idx)}

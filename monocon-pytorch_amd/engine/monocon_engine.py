@@ -21,7 +21,21 @@ from engine.base_engine import BaseEngine
 from model import MonoConDetector
 from solver import AdamW, CyclicScheduler
 from utils.decorators import decorator_timer
+from hipmonocon.feed import WORKER_CONTEXT, DeferredScalars, DevicePrefetcher, RingLoader
 from utils.engine_utils import move_data_device, progress_to_string_bar, reduce_loss_dict, tprint
+
+
+class _SeedWorker:
+    """worker_init_fn (module level: the workers of a fork server get it pickled).  torch seeds numpy per WORKER from a base seed
+    that is the same on every rank (replicas start from rank 0's seed): offset it per rank, or all ranks would draw the same
+    augmentation decisions for their shards"""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def __call__(self, worker_id):
+        import numpy as np
+        np.random.seed((torch.initial_seed() + 1000003 * (self.rank + 1)) % (2 ** 32))
 
 
 class MonoconEngine(BaseEngine):
@@ -66,19 +80,30 @@ class MonoconEngine(BaseEngine):
         sampler = None
         if self.world > 1 and is_train:
             sampler = DistributedSampler(dataset, num_replicas=self.world, rank=self.rank, shuffle=True, drop_last=True)
-        rank = self.rank
-
-        def seed_worker(worker_id):
-            # torch seeds numpy per WORKER from a base seed that is the same on every rank (replicas start from rank 0's
-            # seed): offset it per rank, or all ranks would draw the same augmentation decisions for their shards
-            import numpy as np
-            np.random.seed((torch.initial_seed() + 1000003 * (rank + 1)) % (2 ** 32))
+        seed_worker = _SeedWorker(self.rank)
         if is_train and self.cfg.DATA.NUM_WORKERS == 0 and self.world > 1:
             seed_worker(0)
-        loader = DataLoader(dataset, batch_size=self.cfg.DATA.BATCH_SIZE, num_workers=self.cfg.DATA.NUM_WORKERS,
-                            shuffle=(is_train and sampler is None), sampler=sampler, collate_fn=dataset.collate_fn,
-                            drop_last=(self.world > 1 and is_train),
-                            worker_init_fn=seed_worker if (is_train and self.cfg.DATA.NUM_WORKERS > 0) else None)
+        shuffle, drop_last = (is_train and sampler is None), (self.world > 1 and is_train)
+        init_fn = seed_worker if (is_train and self.cfg.DATA.NUM_WORKERS > 0) else None
+        loader = None
+        if self.cfg.DATA.NUM_WORKERS > 0 and torch.cuda.is_available() and bool(self.cfg.DATA.get('RING_LOADER', True)):
+            # worker processes + a HIP device: the frames go through a shared, page-locked ring of batch slots instead of the
+            # workers' queues (hipmonocon/feed.py: a DataLoader delivers a 32-frame float32 batch every 75-105 ms, the ring
+            # every ~10).  Same batches in the same order; DATA.RING_LOADER: False is the reference's DataLoader.
+            try:
+                loader = RingLoader(dataset, self.cfg.DATA.BATCH_SIZE, self.cfg.DATA.NUM_WORKERS, shuffle=shuffle, sampler=sampler,
+                                    drop_last=drop_last, collate_fn=dataset.collate_fn, worker_init_fn=init_fn)
+            except (RuntimeError, OSError) as e:        # e.g. /dev/shm too small for the ring
+                self._say("RingLoader unavailable (%s): using torch's DataLoader." % (e,))
+        if loader is None:
+            # pin_memory: a loader thread page-locks every batch, so that DevicePrefetcher's uploads are asynchronous -- and
+            # beside page-locked memory the workers must not be forks of this process (hipmonocon/feed.py, RingLoader)
+            beside_device = torch.cuda.is_available() and self.cfg.DATA.NUM_WORKERS > 0
+            loader = DataLoader(dataset, batch_size=self.cfg.DATA.BATCH_SIZE, num_workers=self.cfg.DATA.NUM_WORKERS,
+                                shuffle=shuffle, sampler=sampler, collate_fn=dataset.collate_fn, drop_last=drop_last,
+                                pin_memory=torch.cuda.is_available(), worker_init_fn=init_fn,
+                                multiprocessing_context=WORKER_CONTEXT if beside_device else None,
+                                persistent_workers=beside_device)
         return dataset, loader
 
     @decorator_timer
@@ -86,24 +111,37 @@ class MonoconEngine(BaseEngine):
         epoch_losses = []
         if isinstance(getattr(self.train_loader, 'sampler', None), DistributedSampler):
             self.train_loader.sampler.set_epoch(self.epochs)
-        for batch_idx, data_dict in enumerate(self.train_loader):
+        # the batches arrive on the device one step ahead (copy stream, labels checked on the host) and the loss of a step is
+        # read back while the NEXT one runs: nothing between two log lines drains the stream (hipmonocon/feed.py)
+        losses = DeferredScalars()
+
+        def collect(keep):
+            got = losses.ready(keep)
+            epoch_losses.extend(got)
+            self.entire_losses.extend(got)
+
+        # MONOCON_HIP_SYNC_LOOP=1: the reference's loop as written (upload on the compute stream, loss read inside the step)
+        sync_loop = os.environ.get("MONOCON_HIP_SYNC_LOOP", "0") == "1"
+        feed = self.train_loader if sync_loop else DevicePrefetcher(self.train_loader, self.current_device, self.model)
+        for batch_idx, data_dict in enumerate(feed):
             self.optimizer.zero_grad()
-            data_dict = move_data_device(data_dict, self.current_device)
+            data_dict = move_data_device(data_dict, self.current_device)      # (a no-op for what the prefetcher uploaded)
             _, loss_dict = self.model(data_dict)
             total_loss = reduce_loss_dict(loss_dict)
             total_loss.backward()                       # HIP backward + (N > 1) gradient all-reduce
-            step_loss = total_loss.detach().item()
-            epoch_losses.append(step_loss)
-            self.entire_losses.append(step_loss)
+            losses.push(total_loss)
             self.optimizer.step()                       # fused clip (SOLVER.CLIP_GRAD) + AdamW
             if self.scheduler is not None:
                 self.scheduler.step()
-            if self.global_iters % self.log_period == 0 and self.is_main:
+            logging = self.global_iters % self.log_period == 0 and self.is_main
+            collect(0 if (logging or sync_loop) else 1)
+            if logging:
                 bar = progress_to_string_bar(batch_idx + 1, len(self.train_loader), bins=20)
                 recent = sum(self.entire_losses[-100:]) / len(self.entire_losses[-100:])
-                print("| Progress %s | LR %.6f | Loss %8.4f (%8.4f) |" % (bar, self.current_lr, step_loss, recent))
+                print("| Progress %s | LR %.6f | Loss %8.4f (%8.4f) |" % (bar, self.current_lr, self.entire_losses[-1], recent))
                 self._update_dict_to_writer(loss_dict, tag='loss')
             self._iter_update()
+        collect(0)
         self._epoch_update()
         return sum(epoch_losses) / max(len(epoch_losses), 1)
 
@@ -115,7 +153,7 @@ class MonoconEngine(BaseEngine):
             self._say("Model is converted to eval mode.")
         container = {'img_bbox': [], 'img_bbox2d': []}
         synthetic = str(self.cfg.DATA.ROOT).startswith('synthetic')
-        for test_data in self.test_loader:
+        for test_data in DevicePrefetcher(self.test_loader, self.current_device):
             test_data = move_data_device(test_data, self.current_device)
             if synthetic:            # KITTI text export needs dataset metadata the synthetic set does not have
                 res = self.model.batch_eval(test_data, get_vis_format=True)

@@ -192,6 +192,31 @@ def _require_objects(detector, label, pad_hw, num_classes=3):
     object.__setattr__(detector, "_mask_validated", (weakref.ref(mask), mask._version))
 
 
+def labels_ok_on_host(label, pad_hw, num_classes=3):
+    """_require_objects' test on label tensors that are still in HOST memory (a DataLoader batch before its upload): the same
+    fp32 arithmetic, no device work and no read-back.  True only for a batch the device-side test would pass; for anything
+    else (labels already on a device, no valid object, an object outside the map or the classes) False -- the caller then
+    leaves the batch to _require_objects, which raises as the reference does, on every rank together."""
+    mask = label["mask"]
+    if mask.is_cuda or label["gt_bboxes"].is_cuda or label["gt_labels"].is_cuda:
+        return False
+    H, W = pad_hw
+    fh, fw = H // 4, W // 4
+    bb, cls = label["gt_bboxes"].float(), label["gt_labels"]
+    wr, hr = torch.tensor(fw / W, dtype=torch.float32), torch.tensor(fh / H, dtype=torch.float32)
+    xi = ((bb[..., 0] + bb[..., 2]) * wr / 2.0).trunc()
+    yi = ((bb[..., 1] + bb[..., 3]) * hr / 2.0).trunc()
+    bad = ((xi < 0) | (xi >= fw) | (yi < 0) | (yi >= fh) | (cls < 0) | (cls >= num_classes)) & (mask != 0)
+    return bool(mask.sum() != 0) and not bool(bad.any())
+
+
+def note_labels_validated(detector, label):
+    """the device copy ``label`` of a batch that labels_ok_on_host passed: _require_objects will not read a verdict back for
+    it (under data parallelism the ranks still vote, over the host-side group, on whether all of them are in that state)"""
+    mask = label["mask"]
+    object.__setattr__(detector, "_mask_validated", (weakref.ref(mask), mask._version))
+
+
 def forward_train(detector, data_dict):
     img = data_dict["img"]
     if not img.is_cuda:

@@ -16,6 +16,8 @@ GOLDEN_SEED = 7
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch 2.10's own DataLoader pin thread passes the deprecated argument, once per tensor of every batch
+    config.addinivalue_line("filterwarnings", r"ignore:The argument 'device' of Tensor\.(pin_memory|is_pinned)\(\) is deprecated:DeprecationWarning")
 
 
 def load_golden(name):

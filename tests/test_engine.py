@@ -87,6 +87,48 @@ def test_engine_trains_checkpoints_and_resumes(tmp_path):
     assert ev['num_results'] == 2.0
 
 
+@pytest.mark.gpu
+def test_engine_loop_reports_the_losses_of_the_reference_loop(tmp_path, monkeypatch):
+    """the default loop uploads a batch ahead on a copy stream, checks the labels on the host and reads each step's loss one
+    step late (hipmonocon/feed.py); MONOCON_HIP_SYNC_LOOP=1 is the reference's loop as written (monocon_engine.py:84-102:
+    move_data_device + total_loss.item() inside the step).  Same shuffled batches, same steps: the same loss per step, in the
+    same order, and the same weights at the end.  LOG_PERIOD=3 leaves steps whose loss is only read afterwards."""
+    from engine.monocon_engine import MonoconEngine
+    from utils.engine_utils import set_random_seed
+    res = []
+    for tag, sync in (("a", "0"), ("b", "1")):
+        monkeypatch.setenv("MONOCON_HIP_SYNC_LOOP", sync)
+        set_random_seed(3)                  # as train.py does before it builds the engine: same weights, same shuffles
+        cfg = small_cfg(os.path.join(tmp_path, tag))
+        cfg.PERIOD.LOG_PERIOD = 3
+        os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
+        eng = MonoconEngine(cfg)
+        eng.train()
+        res.append((list(eng.entire_losses), {k: v.detach().cpu().clone() for k, v in eng.model.state_dict().items()}))
+    assert len(res[0][0]) == 4 and res[0][0] == res[1][0]
+    assert all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
+
+
+@pytest.mark.gpu
+def test_train_script_with_worker_processes(tmp_path):
+    """`python train.py ... DATA.NUM_WORKERS 2` (reference train.py:19-45): with workers and a device the engine feeds itself
+    through hipmonocon.feed.RingLoader -- fork-server workers (the script is imported again by each of them: its body sits
+    behind the __main__ guard), frames through the page-locked ring, two epochs over the same persistent workers"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "monocon-pytorch_amd", "train.py"),
+           "OUTPUT_DIR", str(tmp_path), "SEED", "5", "DATA.ROOT", "synthetic", "DATA.SYNTHETIC_LENGTH", "8",
+           "DATA.SYNTHETIC_HW", "[96, 224]", "DATA.BATCH_SIZE", "2", "DATA.NUM_WORKERS", "2",
+           "MODEL.BACKBONE.IMAGENET_PRETRAINED", "False", "SOLVER.OPTIM.NUM_EPOCHS", "2", "PERIOD.EVAL_PERIOD", "1",
+           "PERIOD.LOG_PERIOD", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("- Average Loss:") == 2 and "Using Random Seed 5" in r.stdout
+    assert "RingLoader unavailable" not in r.stdout
+    assert os.path.isfile(os.path.join(tmp_path, "checkpoints", "epoch_002_final.pth"))
+
+
 def test_kitti_conversion_matches_reference_golden():
     """utils/kitti_convert_utils.py (host-side) against the reference's annos for the same decode."""
     import numpy as np

@@ -184,3 +184,165 @@ def test_detector_trains_and_evaluates_on_the_file_dataset(golden_sd, tmp_path):
     assert json.load(open(out_json)) == ap
     ds.write_kitti_results(res, str(tmp_path))
     assert os.path.isfile(os.path.join(str(tmp_path), "img_bbox", "000007.txt"))
+
+
+def test_host_side_label_check_agrees_with_the_device_rule():
+    """hipmonocon.train.labels_ok_on_host: the test _require_objects runs on the device (utils/target_generator.py:70-75,
+    losses/l1_loss.py:15 in the reference: an index error / an assertion), on tensors that have not left the host"""
+    from hipmonocon.train import labels_ok_on_host
+    H, W = 128, 224
+    lab = synth.make_batch(5, 3, H, W)["label"]
+    assert labels_ok_on_host(lab, (H, W))
+    empty = {k: v.clone() for k, v in lab.items()}
+    empty["mask"].zero_()
+    assert not labels_ok_on_host(empty, (H, W))                         # no valid object in the batch
+    b, o = [int(i[0]) for i in torch.nonzero(lab["mask"], as_tuple=True)]
+    outside = {k: v.clone() for k, v in lab.items()}
+    outside["gt_bboxes"][b, o] = torch.tensor([W + 8.0, 10.0, W + 40.0, 40.0])     # centre right of the map
+    assert not labels_ok_on_host(outside, (H, W))
+    edge = {k: v.clone() for k, v in lab.items()}
+    edge["gt_bboxes"][b, o] = torch.tensor([W - 8.0, H - 8.0, W - 0.5, H - 0.5])   # centre in the last cell: inside
+    assert labels_ok_on_host(edge, (H, W))
+    cls = {k: v.clone() for k, v in lab.items()}
+    cls["gt_labels"][b, o] = 3
+    assert not labels_ok_on_host(cls, (H, W))
+    cls["gt_labels"][b, o] = -1
+    assert not labels_ok_on_host(cls, (H, W))
+    ignored = {k: v.clone() for k, v in lab.items()}
+    slot = [int(i[0]) for i in torch.nonzero(lab["mask"] == 0, as_tuple=True)]
+    ignored["gt_labels"][slot[0], slot[1]] = 7                          # an unused slot may hold anything
+    assert labels_ok_on_host(ignored, (H, W))
+
+
+def test_feed_helpers_without_a_device():
+    """DevicePrefetcher passes batches through when there is no HIP device; DeferredScalars keeps order and `keep`"""
+    from hipmonocon.feed import DeferredScalars, DevicePrefetcher
+    batches = [{"img": torch.full((1, 3, 32, 32), float(i)), "label": {"mask": torch.ones(1, 2)}, "img_metas": {"idx": [i]}}
+               for i in range(4)]
+    got = list(DevicePrefetcher(batches, "cpu"))
+    assert [int(b["img"][0, 0, 0, 0]) for b in got] == [0, 1, 2, 3] and all(a is b for a, b in zip(got, batches))
+    assert len(DevicePrefetcher(batches, None)) == 4
+    d = DeferredScalars()
+    out = []
+    for i in range(5):
+        d.push(torch.tensor(float(i)))
+        out += d.ready(keep=1)
+        assert out == [float(j) for j in range(i)]
+    assert d.ready(0) == [4.0] and d.ready(0) == []
+
+
+@pytest.mark.gpu
+def test_prefetcher_hands_over_the_loader_batches_validated():
+    """the batches of a pinned DataLoader arrive on the device in order and equal to the host copies; a batch that passes the
+    host-side label check is marked on the detector (its forward reads no verdict back), one that fails is not -- and the
+    forward then raises as the reference does (target_generator.py:70-75)"""
+    from torch.utils.data import DataLoader
+    from dataset.synthetic_dataset import SyntheticMonoConDataset
+    from hipmonocon.feed import DeferredScalars, DevicePrefetcher
+    from model import MonoConDetector
+    ds = SyntheticMonoConDataset(length=6, height=96, width=224, seed=3)
+    host = list(DataLoader(ds, batch_size=2, collate_fn=ds.collate_fn))
+    m = MonoConDetector(34, pretrained_backbone=False).cuda().train()
+    loader = DataLoader(ds, batch_size=2, collate_fn=ds.collate_fn, pin_memory=True)
+    n = 0
+    for dev, ref in zip(DevicePrefetcher(loader, "cuda:0", m), host):
+        assert dev["img"].is_cuda and torch.equal(dev["img"].cpu(), ref["img"])
+        for k, v in ref["label"].items():
+            assert dev["label"][k].is_cuda and torch.equal(dev["label"][k].cpu(), v), k
+        seen = m._mask_validated
+        assert seen[0]() is dev["label"]["mask"]
+        _, loss = m(dev)
+        assert all(torch.isfinite(v) for v in loss.values())
+        n += 1
+    assert n == 3
+
+    class Bad(torch.utils.data.Dataset):
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            d = ds[i]
+            d["label"]["gt_labels"] = torch.full_like(d["label"]["gt_labels"], 5.0)
+            return d
+    object.__setattr__(m, "_mask_validated", None)
+    it = iter(DevicePrefetcher(DataLoader(Bad(), batch_size=2, collate_fn=ds.collate_fn), "cuda:0", m))
+    dev = next(it)
+    assert m._mask_validated is None
+    with pytest.raises(IndexError):
+        m(dev)
+    d = DeferredScalars()
+    vals = [torch.tensor(float(i), device="cuda") * 2 for i in range(4)]
+    got = []
+    for v in vals:
+        d.push(v)
+        got += d.ready(1)
+    assert got + d.ready(0) == [0.0, 2.0, 4.0, 6.0]
+
+
+def _same_batch(a, b):
+    assert torch.equal(a["img"], b["img"])
+    assert a["label"].keys() == b["label"].keys() and all(torch.equal(a["label"][k], b["label"][k]) for k in a["label"])
+    assert a["img_metas"] == b["img_metas"]
+
+
+def test_ring_loader_yields_the_batches_of_a_dataloader():
+    """hipmonocon.feed.RingLoader: the workers write the frames into a shared ring of batch slots, only the labels travel
+    through their queues -- same batches, same order, same collated dict as the DataLoader the reference builds
+    (engine/monocon_engine.py:60-72), over two epochs, a ragged last batch and several trips around the ring"""
+    from torch.utils.data import DataLoader
+    from dataset.synthetic_dataset import SyntheticMonoConDataset
+    from hipmonocon.feed import RingLoader
+    ds = SyntheticMonoConDataset(length=23, height=32, width=64, seed=4)
+    ref = list(DataLoader(ds, batch_size=3, collate_fn=ds.collate_fn))
+    rl = RingLoader(ds, batch_size=3, num_workers=2, prefetch_factor=1, pin=False)
+    assert rl.nslots == 5 and len(rl) == len(ref) == 8 and not rl.pinned
+    for epoch in range(2):
+        got = list(rl)
+        assert len(got) == 8 and tuple(got[-1]["img"].shape) == (2, 3, 32, 64)
+        for a, b in zip(got, ref):
+            _same_batch(a, b)
+    g = torch.Generator().manual_seed(11)
+    order = [b["img_metas"]["sample_idx"] for b in RingLoader(ds, 4, 2, shuffle=True, drop_last=True, pin=False, generator=g)]
+    assert len(order) == 5 and sorted(i for b in order for i in b) != [i for b in order for i in b]
+    assert len({i for b in order for i in b}) == 20
+    # a consumer that uploads out of the ring itself sees views of the slots, and reports its uploads
+    class Ev:
+        def __init__(self, log, k):
+            self.log, self.k = log, k
+
+        def synchronize(self):
+            self.log.append(self.k)
+    log = []
+    for k, (a, b) in enumerate(zip(rl.host_batches(), ref)):
+        assert a["img"].untyped_storage().data_ptr() == rl.ring.untyped_storage().data_ptr()
+        _same_batch(a, b)
+        rl.note_upload(Ev(log, k))
+    assert log == [0, 1, 2, 3, 4, 5]       # batch k (and the end of the epoch, k = 8) is asked for only after the upload of batch k - 3 has completed
+    with pytest.raises(ValueError):
+        RingLoader(ds, 3, 0)
+    # frames of a shape the ring was not built for travel with their samples, as under a DataLoader
+    small = RingLoader(ds, batch_size=3, num_workers=1, pin=False, image_shape=(3, 16, 16))
+    for a, b in zip(small, ref[:2]):
+        _same_batch(a, b)
+
+
+@pytest.mark.gpu
+def test_ring_loader_uploads_out_of_its_pinned_ring():
+    """under a DevicePrefetcher the frames go from the page-locked ring to the device in one asynchronous copy; the batches
+    are those of the DataLoader, over more batches than the ring has slots"""
+    from torch.utils.data import DataLoader
+    from dataset.synthetic_dataset import SyntheticMonoConDataset
+    from hipmonocon.feed import DevicePrefetcher, RingLoader
+    ds = SyntheticMonoConDataset(length=30, height=64, width=96, seed=9)
+    ref = list(DataLoader(ds, batch_size=2, collate_fn=ds.collate_fn))
+    rl = RingLoader(ds, batch_size=2, num_workers=2, prefetch_factor=1)
+    assert rl.pinned and rl.ring.is_pinned() and rl.nslots == 5
+    for epoch in range(2):
+        n = 0
+        for dev, host in zip(DevicePrefetcher(rl, "cuda:0"), ref):
+            assert dev["img"].is_cuda and torch.equal(dev["img"].cpu(), host["img"])
+            assert all(torch.equal(dev["label"][k].cpu(), host["label"][k]) for k in host["label"])
+            n += 1
+        assert n == 15
+    rl.close()
+    assert not rl.pinned
