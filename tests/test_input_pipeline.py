@@ -346,3 +346,24 @@ def test_ring_loader_uploads_out_of_its_pinned_ring():
         assert n == 15
     rl.close()
     assert not rl.pinned
+
+
+def test_ring_loader_over_the_file_dataset():
+    """the KITTI file dataset through RingLoader's fork-server workers (the dataset, its transforms and its collate are
+    pickled for them): the batch of the DataLoader the reference builds (monocon_engine.py:60-72), and the 'train' split's
+    augmented frames keep the padded shape the ring is built for (transforms/augmentations.py: crops are pasted back)"""
+    from torch.utils.data import DataLoader
+    from dataset.monocon_dataset import MonoConDataset
+    from hipmonocon.feed import RingLoader
+    ds = MonoConDataset(MINI, "val")
+    ref = list(DataLoader(ds, batch_size=2, collate_fn=ds.collate_fn))
+    rl = RingLoader(ds, batch_size=2, num_workers=1, pin=False)
+    assert tuple(rl.ring.shape) == (5, 2, 3, 384, 1248)
+    got = list(rl)
+    assert len(got) == len(ref) == 1
+    _same_batch(got[0], ref[0])
+    assert [c.P2.tolist() for c in got[0]["calib"]] == [c.P2.tolist() for c in ref[0]["calib"]]
+    tr = MonoConDataset(MINI, "train")
+    for b in RingLoader(tr, batch_size=2, num_workers=1, pin=False):
+        assert tuple(b["img"].shape) == (2, 3, 384, 1248) and torch.isfinite(b["img"]).all()
+        assert b["label"]["mask"].shape == (2, 30)
