@@ -510,8 +510,8 @@ def main():
         """The headline step fed the way MonoconEngine.train_one_epoch feeds it (engine/monocon_engine.py, hipmonocon/feed.py):
         worker processes write float32 CHW frames (the reference's collate contract, monocon_dataset.py:173-200) into the
         shared page-locked ring, the batch is uploaded one step ahead on a copy stream, the labels are checked on the host,
-        the loss of each step is read back one step late.  One epoch to start the workers, one timed (its first batch waits for a worker to fill a
-        slot: ~0.1 s once per epoch, in the number)."""
+        the loss of each step is read back one step late.  One epoch to start the workers, one timed (the loader serves all epochs from one
+        iterator: the first batches of an epoch are in the ring before the previous one ends)."""
         from dataset.synthetic_dataset import PooledSyntheticDataset
         from hipmonocon.feed import DeferredScalars, DevicePrefetcher, RingLoader
         m.train().set_precision(mode)

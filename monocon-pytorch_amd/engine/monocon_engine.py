@@ -21,7 +21,7 @@ from engine.base_engine import BaseEngine
 from model import MonoConDetector
 from solver import AdamW, CyclicScheduler
 from utils.decorators import decorator_timer
-from hipmonocon.feed import WORKER_CONTEXT, DeferredScalars, DevicePrefetcher, RingLoader
+from hipmonocon.feed import WORKER_CONTEXT, DeferredScalars, DevicePrefetcher, RingLoader, prepare_worker_context
 from utils.engine_utils import move_data_device, progress_to_string_bar, reduce_loss_dict, tprint
 
 
@@ -99,6 +99,8 @@ class MonoconEngine(BaseEngine):
             # pin_memory: a loader thread page-locks every batch, so that DevicePrefetcher's uploads are asynchronous -- and
             # beside page-locked memory the workers must not be forks of this process (hipmonocon/feed.py, RingLoader)
             beside_device = torch.cuda.is_available() and self.cfg.DATA.NUM_WORKERS > 0
+            if beside_device:
+                prepare_worker_context()
             loader = DataLoader(dataset, batch_size=self.cfg.DATA.BATCH_SIZE, num_workers=self.cfg.DATA.NUM_WORKERS,
                                 shuffle=shuffle, sampler=sampler, collate_fn=dataset.collate_fn, drop_last=drop_last,
                                 pin_memory=torch.cuda.is_available(), worker_init_fn=init_fn,
@@ -109,7 +111,7 @@ class MonoconEngine(BaseEngine):
     @decorator_timer
     def train_one_epoch(self) -> float:
         epoch_losses = []
-        if isinstance(getattr(self.train_loader, 'sampler', None), DistributedSampler):
+        if hasattr(getattr(self.train_loader, 'sampler', None), 'set_epoch'):      # DistributedSampler (RingLoader shows it guarded)
             self.train_loader.sampler.set_epoch(self.epochs)
         # the batches arrive on the device one step ahead (copy stream, labels checked on the host) and the loss of a step is
         # read back while the NEXT one runs: nothing between two log lines drains the stream (hipmonocon/feed.py)

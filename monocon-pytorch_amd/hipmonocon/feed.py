@@ -29,6 +29,15 @@ from . import train as _train
 WORKER_CONTEXT = "forkserver"      # how loaders beside a HIP device start their workers (see RingLoader)
 
 
+def prepare_worker_context():
+    """the fork server imports torch ONCE and the workers are forked from it with the modules in place (otherwise every worker of
+    every loader imports torch by itself: seconds each, much longer on a box whose image is not in the page cache yet).  Has to
+    run before the first worker of the process is started; a no-op afterwards."""
+    if WORKER_CONTEXT == "forkserver":
+        import multiprocessing
+        multiprocessing.set_forkserver_preload(["torch", "numpy", "torch.utils.data", __name__])
+
+
 def _upload(obj, device):
     if isinstance(obj, torch.Tensor):
         return obj.to(device, non_blocking=True)
@@ -129,19 +138,54 @@ class DeferredScalars:
 
 class _RingBatchSampler(torch.utils.data.Sampler):
     """the batches of ``base`` (lists of sample indices) with the ring slot of the batch and the sample's place in it attached
-    to every index: the DATASET (in a worker) writes the frame there"""
+    to every index: the DATASET (in a worker) writes the frame there.  ENDLESS: one pass over ``base`` after the other, so that
+    the workers fill slots for the next epoch while the tail of this one (and whatever the loop does between two epochs) is
+    still being consumed; a sampler with ``set_epoch`` (DistributedSampler) is moved on by one per pass, which is what the
+    engine does at the start of every epoch (RingLoader's _EpochGuard notices a caller that does otherwise)."""
 
-    def __init__(self, base, nslots):
-        self.base, self.nslots, self.count = base, nslots, 0
+    def __init__(self, base, nslots, sampler):
+        self.base, self.nslots, self.count, self.sampler = base, nslots, 0, sampler
+        self.epoch_of_next_pass = None
 
     def __len__(self):
         return len(self.base)
 
     def __iter__(self):
-        for idxs in self.base:
-            slot = self.count % self.nslots
-            self.count += 1                 # runs on over epochs: slots are reused in dispatch order
-            yield [(int(i), slot, pos) for pos, i in enumerate(idxs)]
+        paced = hasattr(self.sampler, "set_epoch") and hasattr(self.sampler, "epoch")
+        self.epoch_of_next_pass = self.sampler.epoch if paced else None
+        while True:
+            if paced:
+                self.sampler.set_epoch(self.epoch_of_next_pass)
+                self.epoch_of_next_pass += 1
+            for idxs in self.base:
+                slot = self.count % self.nslots
+                self.count += 1                 # runs on over passes: slots are reused in dispatch order
+                yield [(int(i), slot, pos) for pos, i in enumerate(idxs)]
+
+
+class _EpochGuard:
+    """what RingLoader shows as its ``sampler``: the caller's sampler, with ``set_epoch`` watched -- the passes the workers
+    are already filling slots for assumed epoch, epoch + 1, ...; a caller that sets anything else (a resume, a replay) makes
+    the loader start over from that epoch instead of handing out batches of the wrong permutation"""
+
+    def __init__(self, loader, sampler):
+        object.__setattr__(self, "_loader", loader)
+        object.__setattr__(self, "_sampler", sampler)
+
+    def __getattr__(self, name):
+        return getattr(self._sampler, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._sampler, name, value)
+
+    def __iter__(self):
+        return iter(self._sampler)
+
+    def __len__(self):
+        return len(self._sampler)
+
+    def set_epoch(self, epoch):
+        self._loader._epoch_wanted(epoch)
 
 
 class _RingDataset(torch.utils.data.Dataset):
@@ -190,7 +234,11 @@ class RingLoader:
     Iterating it yields host batches (``img`` a COPY of the slot); under a DevicePrefetcher the frames are uploaded straight out
     of the ring and a slot is refilled only after its upload has completed: a batch is dispatched to a worker when the consumer
     takes one, at most ``prefetch_factor * num_workers`` are in flight, and the ring has three slots more than that -- the loader
-    waits for the upload of the batch handed out three batches ago before it asks for the next one."""
+    waits for the upload of the batch handed out three batches ago before it asks for the next one.
+
+    One iterator of the underlying DataLoader serves all epochs (the batch sampler is endless, an epoch is ``len(self)`` batches
+    of it): the first batch of an epoch is already in the ring when the previous epoch ends -- filling it takes a worker
+    32 decodes, as long as dozens of steps."""
 
     EXTRA_SLOTS = 3
 
@@ -204,7 +252,8 @@ class RingLoader:
         self.collate_fn = collate_fn if collate_fn is not None else dataset.collate_fn
         if sampler is None:
             sampler = RandomSampler(dataset, generator=generator) if shuffle else SequentialSampler(dataset)
-        self.sampler = sampler
+        self._sampler = sampler
+        self.sampler = _EpochGuard(self, sampler) if hasattr(sampler, "set_epoch") else sampler
         if image_shape is None:
             image_shape = tuple(dataset[0]["img"].shape)
         self.nslots = prefetch_factor * self.num_workers + self.EXTRA_SLOTS
@@ -224,12 +273,15 @@ class RingLoader:
                 warnings.warn("RingLoader: hipHostRegister of the %.1f GB ring failed (%s): uploads will be staged copies"
                               % (self.ring.numel() * self.ring.element_size() / 1e9, rc))
         self._uploads = collections.deque()
-        self._bs = _RingBatchSampler(BatchSampler(sampler, self.batch_size, drop_last), self.nslots)
+        self._bs = _RingBatchSampler(BatchSampler(sampler, self.batch_size, drop_last), self.nslots, sampler)
+        self._it, self._midway, self._epochs_out, self._epoch0 = None, False, 0, None
         # The workers live as long as the loader and come from a FORK SERVER, not from a fork of this process: children forked
         # from a process that holds page-locked memory (the ring, torch's pinned blocks) slow every launch of the parent's
         # GPU work down for as long as they live -- measured on this platform: 45 -> 600 ms per train step (COW
         # write-protection of the parent's pages against the driver's MMU notifiers on its pinned ranges).  Dataset, collate
         # and worker_init_fn therefore have to be picklable.
+        if (mp_context or WORKER_CONTEXT) == "forkserver":
+            prepare_worker_context()
         self._dl = DataLoader(_RingDataset(dataset, self.ring), batch_sampler=self._bs, num_workers=self.num_workers,
                               collate_fn=_RingCollate(self.collate_fn, self.ring), worker_init_fn=worker_init_fn,
                               prefetch_factor=prefetch_factor, multiprocessing_context=mp_context or WORKER_CONTEXT,
@@ -238,24 +290,35 @@ class RingLoader:
     def __len__(self):
         return len(self._bs)
 
+    def _epoch_wanted(self, epoch):
+        """set_epoch of the caller, before an epoch: fine when it is the epoch that pass was (or will be) sampled for"""
+        running = self._it is not None and not self._midway
+        if running and self._epoch0 is not None and epoch == self._epoch0 + self._epochs_out:
+            return
+        self._sampler.set_epoch(epoch)
+        self._it = None                         # (re)start from that epoch: what the workers have queued belongs to others
+
     def _batches(self, copies):
-        # nothing of an earlier epoch may still be on its way out of the ring when the new iterator dispatches its first
-        # prefetch_factor * num_workers batches
-        while self._uploads:
-            self._uploads.popleft().synchronize()
-        it = iter(self._dl)
-        while True:
+        if self._it is None or self._midway:
+            # (re)start: nothing may still be on its way out of the ring when the new iterator dispatches its first
+            # prefetch_factor * num_workers batches
+            while self._uploads:
+                self._uploads.popleft().synchronize()
+            self._epoch0 = getattr(self._sampler, "epoch", None) if hasattr(self._sampler, "set_epoch") else None
+            self._it = iter(self._dl)           # persistent workers: resets them, stale batches are dropped
+            self._epochs_out = 0
+        self._midway = True                     # an epoch abandoned half-way is not continued by the next one
+        for _ in range(len(self._bs)):
             while len(self._uploads) > self.EXTRA_SLOTS - 1:
                 self._uploads.popleft().synchronize()
-            try:
-                batch = next(it)                    # (hands one more batch, i.e. one more slot, to a worker)
-            except StopIteration:
-                return
+            batch = next(self._it)              # (hands one more batch, i.e. one more slot, to a worker)
             tag = batch.get("img")
             if isinstance(tag, tuple) and tag and tag[0] == "ring":
                 view = self.ring[tag[1], :tag[2]]
                 batch["img"] = view.clone() if copies else view
             yield batch
+        self._midway = False
+        self._epochs_out += 1
 
     def host_batches(self):
         """the batches with ``img`` a VIEW of the ring slot: the consumer must report the event of each upload (note_upload)

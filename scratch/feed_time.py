@@ -28,6 +28,7 @@ def main():
     def loop(feed, tag):
         losses = DeferredScalars()
         t_wait = t_enq = 0.0
+        evs = []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         it = iter(feed)
@@ -39,12 +40,16 @@ def main():
             except StopIteration:
                 break
             tb = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             opt.zero_grad()
             _, loss = m(batch)
             total = sum(loss.values())
             total.backward()
             losses.push(total)
             opt.step()
+            e1.record()
+            evs.append((e0, e1))
             losses.ready(1)
             tc = time.perf_counter()
             t_wait += tb - ta
@@ -52,8 +57,10 @@ def main():
             n += 1
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print("%-34s %7.2f ms/step (%6.1f img/s): waiting for the batch %6.2f, enqueueing the step %6.2f ms"
-              % (tag, dt / n * 1e3, B * n / dt, t_wait / n * 1e3, t_enq / n * 1e3), flush=True)
+        busy = sum(a.elapsed_time(b) for a, b in evs[2:]) / max(len(evs) - 2, 1)
+        gap = sum(evs[i][1].elapsed_time(evs[i + 1][0]) for i in range(2, len(evs) - 1)) / max(len(evs) - 3, 1)
+        print("%-34s %7.2f ms/step (%6.1f img/s): waiting for the batch %6.2f, enqueueing the step %6.2f ms; on the device: step %6.2f ms, gap to the next %5.2f ms"
+              % (tag, dt / n * 1e3, B * n / dt, t_wait / n * 1e3, t_enq / n * 1e3, busy, gap), flush=True)
 
     resident = ds.collate_fn([ds[i] for i in range(B)])
     resident = {"img": resident["img"].cuda(), "label": {k: v.cuda() for k, v in resident["label"].items()},
@@ -65,16 +72,11 @@ def main():
               for _ in range(3)]
     loop(DevicePrefetcher([pinned[i % 3] for i in range(steps)], "cuda:0", m), "pinned host batches + prefetcher (no workers)")
     loop(DevicePrefetcher([pinned[i % 3] for i in range(steps)], "cuda:0", m), "pinned host batches + prefetcher (no workers)")
-    for w in sorted({4, 8, workers}):
-        ring = RingLoader(ds, B, w, shuffle=True, collate_fn=ds.collate_fn)
-        for rep in range(3):
-            loop(DevicePrefetcher(ring, "cuda:0", m), "RingLoader + prefetcher (%d w), epoch %d" % (w, rep))
-        ring.close()
-        del ring
-    dl = DataLoader(ds, batch_size=B, num_workers=workers, shuffle=True, collate_fn=ds.collate_fn, pin_memory=True,
-                    multiprocessing_context="forkserver", persistent_workers=True)
+    ring = RingLoader(ds, B, workers, shuffle=True, collate_fn=ds.collate_fn)
     for rep in range(3):
-        loop(DevicePrefetcher(dl, "cuda:0", m), "DataLoader(pin, forkserver) + prefetcher (%d w), epoch %d" % (workers, rep))
+        loop(DevicePrefetcher(ring, "cuda:0", m), "RingLoader + prefetcher (%d w), epoch %d" % (workers, rep))
+    ring.close()
+    del ring
 
 
 if __name__ == "__main__":

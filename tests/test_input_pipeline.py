@@ -317,7 +317,7 @@ def test_ring_loader_yields_the_batches_of_a_dataloader():
         assert a["img"].untyped_storage().data_ptr() == rl.ring.untyped_storage().data_ptr()
         _same_batch(a, b)
         rl.note_upload(Ev(log, k))
-    assert log == [0, 1, 2, 3, 4, 5]       # batch k (and the end of the epoch, k = 8) is asked for only after the upload of batch k - 3 has completed
+    assert log == [0, 1, 2, 3, 4]          # batch k is asked for only after the upload of batch k - 3 has completed
     with pytest.raises(ValueError):
         RingLoader(ds, 3, 0)
     # frames of a shape the ring was not built for travel with their samples, as under a DataLoader
@@ -408,3 +408,36 @@ def test_ring_slots_are_not_refilled_before_their_upload():
         seen += len(want)
     assert seen == 4800 and int(bad) == 0          # (scratch/ring_stress_broken.py: with the events ignored this loop does see bad frames)
     rl.close()
+
+
+def test_ring_loader_epochs_follow_the_distributed_sampler():
+    """one iterator serves all epochs (the workers fill slots for epoch e + 1 while e is consumed), so RingLoader moves a
+    sampler with set_epoch on by itself: the batches of epoch e are those of DataLoader + DistributedSampler.set_epoch(e), the
+    engine's call at the start of each epoch (monocon_engine.py, train_one_epoch) is a no-op, a different epoch (a resume, a
+    replay) or an epoch abandoned half-way starts the loader over"""
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from dataset.synthetic_dataset import SyntheticMonoConDataset
+    from hipmonocon.feed import RingLoader
+    ds = SyntheticMonoConDataset(length=13, height=32, width=64, seed=6)
+
+    def reference(epoch):
+        sp = DistributedSampler(ds, num_replicas=2, rank=1, shuffle=True, drop_last=True, seed=3)
+        sp.set_epoch(epoch)
+        return [b["img_metas"]["sample_idx"] for b in DataLoader(ds, batch_size=2, sampler=sp, collate_fn=ds.collate_fn)]
+
+    sp = DistributedSampler(ds, num_replicas=2, rank=1, shuffle=True, drop_last=True, seed=3)
+    rl = RingLoader(ds, batch_size=2, num_workers=2, sampler=sp, pin=False)
+    ids = lambda: [b["img_metas"]["sample_idx"] for b in rl]
+    for epoch in (4, 5, 6):                      # the engine's sequence
+        rl.sampler.set_epoch(epoch)
+        assert ids() == reference(epoch) and len(reference(epoch)) == 3
+    assert ids() == reference(7)                 # ... and without the call
+    rl.sampler.set_epoch(2)                      # a replay
+    assert ids() == reference(2)
+    it = iter(rl)
+    next(it)                                     # an epoch left after one batch
+    del it
+    rl.sampler.set_epoch(3)
+    assert ids() == reference(3)
+    assert reference(4) != reference(5)
