@@ -280,6 +280,20 @@ int mc_op_nhwc_to_nchw(mc_handle *h, const float *in, int B, int C, int H, int W
 int mc_preprocess(mc_handle *h, const void *img_hwc, int dtype, int H, int W, const double mean[3],
                   const double std[3], int pad_h, int pad_w, float *out_chw, void *stream);
 
+/* The IMAGE work of the reference's random train augmentations -- PhotometricDistortion, RandomShift, RandomHorizontalFlip,
+ * RandomCrop3D (transforms/default_transforms.py:27-372; dataset/monocon_dataset.py:39-46 lists them for the 'train' split) --
+ * followed by Normalize + Pad + ToTensor, for B raw frames in one launch.  The host side (the loader's workers) still draws
+ * the random numbers and moves labels and calibration; it ships each decoded uint8 frame, zero-padded to (src_h, src_w, 3),
+ * with 24 float32 parameters: 0 H, 1 W (the frame's own size), 2 flags, 3 brightness delta, 4 contrast before the HSV stage,
+ * 5 saturation, 6 hue delta, 7 contrast after it, 8-10 channel permutation (on BGR), 11 shift x, 12 shift y, 13-16 crop window
+ * x0 y0 x1 y1.  flags: 1 colour stage present (it is a float32 BGR -> HSV -> BGR round trip even when nothing is drawn),
+ * 2 brightness, 4 contrast before, 8 saturation, 16 hue, 32 contrast after, 64 permutation, 128 shift, 256 flip, 512 window.
+ * frames_hwc: (B, src_h, src_w, 3) uint8; params: (B, 24) float32; out_bchw: (B, 3, pad_h, pad_w) float32, all on the device.
+ * Every value is bit-identical to the host pipeline's (float32 operation by operation, then the float64 normalisation of
+ * mc_preprocess); with flags 0 it is mc_preprocess of a uint8 frame. */
+int mc_preprocess_augmented(mc_handle *h, const unsigned char *frames_hwc, const float *params, int B, int src_h, int src_w,
+                            const double mean[3], const double std[3], int pad_h, int pad_w, float *out_bchw, void *stream);
+
 /* ---- KITTI AP evaluation (last row) -------------------------------------------------------------
  * Device part: pairwise overlaps of rotated boxes.  All pointers are device pointers; results are row-major (N, K).
  *

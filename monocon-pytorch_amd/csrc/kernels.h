@@ -123,5 +123,7 @@ int decode_chunks(int n_per_image);    // candidate-list chunks per image (sizes
 
 hipError_t launch_preprocess(const void *img_hwc, int is_u8, int H, int W, const double mean[3], const double std[3], int Hp,
                              int Wp, float *out_chw, hipStream_t st);
+hipError_t launch_preprocess_aug(const unsigned char *frames, const float *prm, int B, int Hs, int Ws, const double mean[3],
+                                 const double std[3], int Hp, int Wp, float *out, hipStream_t st);
 
 }  // namespace mc

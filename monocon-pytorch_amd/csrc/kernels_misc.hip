@@ -638,6 +638,113 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const T *__restrict__ i
     out[plane + o] = v1;
     out[2 * plane + o] = v2;
 }
+// The random train augmentations' IMAGE work (transforms/augmentations.py of this package = the reference's
+// transforms/default_transforms.py:27-372 PhotometricDistortion, RandomShift, RandomHorizontalFlip, RandomCrop3D without cv2)
+// + Normalize + Pad + ToTensor, for a whole batch of raw uint8 frames in one launch.  The loader's workers draw the random
+// numbers, move the labels and the calibration, and ship the decoded frame with 24 numbers; what costs them ~80 ms per frame
+// (the float32 HSV round trip over 1.4 M values) is 12 bytes in / 12 bytes out per pixel here.
+//   * geometry is an index map: out(y, x) = inside the crop window ? in(y - sy, (flipped ? W - 1 - x : x) - sx) : 0, and 0
+//     wherever the source falls outside the frame (the shifted canvas is zero-filled BEFORE Normalize: those pixels come out as
+//     -mean / std, the Pad region as 0);
+//   * the colour chain is the numpy one, float32 operation by operation (every product and sum rounded on its own: no fma
+//     contraction), so the frame is bit-identical to the host pipeline's (tests/test_augment_device.py).
+// prm (24 floats per image; integers are exact in float32): 0 H, 1 W, 2 flags, 3 brightness delta, 4 contrast before the HSV
+// stage, 5 saturation, 6 hue delta, 7 contrast after it, 8-10 channel permutation (on BGR), 11 sx, 12 sy, 13-16 window
+// x0 y0 x1 y1.  flags: 1 colour stage present, 2 brightness, 4 contrast before, 8 saturation, 16 hue, 32 contrast after,
+// 64 permutation, 128 shift, 256 flip, 512 window.
+namespace {
+// float32 division through float64: the float64 quotient of two floats rounds to what a correctly rounded float32 division
+// gives (53 >= 2 * 24 + 2 bits) -- independent of how the compiler is told to divide floats.
+__device__ __forceinline__ float div_rn(float a, float b) { return (float)((double)a / (double)b); }
+__device__ __forceinline__ void aug_colour(float &c0, float &c1, float &c2, const float *__restrict__ prm, int flags) {
+// numpy rounds every product and every sum: no a * b + c may become an fma here.  (HIP's __fmul_rn / __fadd_rn are plain
+// operators and do not stop the contraction -- a first version built on them was 5 ulp off in 2 % of the pixels.)
+#pragma clang fp contract(off)
+    float b = c2, g = c1, r = c0;                                   // RGB -> BGR
+    if (flags & 2) { const float d = prm[3]; b = b + d; g = g + d; r = r + d; }
+    if (flags & 4) { const float a = prm[4]; b = b * a; g = g * a; r = r * a; }
+    const float eps = 1.1920928955078125e-07f;
+    float v = fmaxf(fmaxf(b, g), r);
+    const float diff = v - fminf(fminf(b, g), r);
+    float s = div_rn(diff, fabsf(v) + eps);
+    const float k = div_rn(60.0f, diff + eps);
+    float h;
+    if (v == r) { h = (g - b) * k; }
+    else if (v == g) { const float t0 = (b - r) * k; h = t0 + 120.0f; }
+    else { const float t0 = (r - g) * k; h = t0 + 240.0f; }
+    if (h < 0.f) h = h + 360.0f;
+    if (flags & 8) s = s * prm[5];
+    if (flags & 16) {
+        float hue = h + prm[6];
+        if (hue > 360.f) hue = hue - 360.f;
+        h = hue < 0.f ? hue + 360.f : hue;
+    }
+    const float h6 = div_rn(h, 60.0f);
+    float m = fmodf(h6, 6.0f);                                      // numpy's mod: the sign of the divisor
+    if (m != 0.f) { if (m < 0.f) m = m + 6.0f; } else m = 0.f;
+    const float sec = floorf(m), f = m - sec;
+    const int sector = ((int)sec) % 6;
+    const float one_s = 1.0f - s, sf = s * f, one_f = 1.0f - f;
+    const float one_sf = 1.0f - sf, s1f = s * one_f;
+    const float one_s1f = 1.0f - s1f;
+    const float pp = v * one_s, q = v * one_sf, t = v * one_s1f;
+    switch (sector) {                                               // (b, g, r) per sector
+        case 0: b = pp; g = t; r = v; break;
+        case 1: b = pp; g = v; r = q; break;
+        case 2: b = t; g = v; r = pp; break;
+        case 3: b = v; g = q; r = pp; break;
+        case 4: b = v; g = pp; r = t; break;
+        default: b = q; g = pp; r = v; break;
+    }
+    if (s == 0.f) { b = v; g = v; r = v; }
+    if (flags & 32) { const float a = prm[7]; b = b * a; g = g * a; r = r * a; }
+    if (flags & 64) {
+        const float src[3] = {b, g, r};
+        const int p0 = (int)prm[8], p1 = (int)prm[9], p2 = (int)prm[10];
+        b = p0 == 0 ? src[0] : (p0 == 1 ? src[1] : src[2]);
+        g = p1 == 0 ? src[0] : (p1 == 1 ? src[1] : src[2]);
+        r = p2 == 0 ? src[0] : (p2 == 1 ? src[1] : src[2]);
+    }
+    c0 = r; c1 = g; c2 = b;                                         // BGR -> RGB
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void preprocess_aug_kernel(const unsigned char *__restrict__ in, const float *__restrict__ prm_all,
+                                                             int Hs, int Ws, double m0, double m1, double m2, double s0, double s1,
+                                                             double s2, int Hp, int Wp, float *__restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+    if (x >= Wp) return;
+    const float *prm = prm_all + (size_t)img * 24;
+    const int H = (int)prm[0], W = (int)prm[1], flags = (int)prm[2];
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if (y < H && x < W) {
+        bool live = true;
+        if (flags & 512) live = x >= (int)prm[13] && x < (int)prm[15] && y >= (int)prm[14] && y < (int)prm[16];
+        int xs = (flags & 256) ? W - 1 - x : x, ys = y;
+        if (flags & 128) { xs -= (int)prm[11]; ys -= (int)prm[12]; }
+        live = live && xs >= 0 && xs < W && ys >= 0 && ys < H;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (live) {
+            const unsigned char *p = in + (((size_t)img * Hs + ys) * Ws + xs) * 3;
+            c0 = (float)p[0]; c1 = (float)p[1]; c2 = (float)p[2];
+            if (flags & 1) aug_colour(c0, c1, c2, prm, flags);
+        }
+        v0 = (float)(((double)c0 - m0) / s0);
+        v1 = (float)(((double)c1 - m1) / s1);
+        v2 = (float)(((double)c2 - m2) / s2);
+    }
+    const size_t plane = (size_t)Hp * Wp, o = (size_t)img * 3 * plane + (size_t)y * Wp + x;
+    out[o] = v0;
+    out[plane + o] = v1;
+    out[2 * plane + o] = v2;
+}
+hipError_t launch_preprocess_aug(const unsigned char *frames, const float *prm, int B, int Hs, int Ws, const double mean[3],
+                                 const double std[3], int Hp, int Wp, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(preprocess_aug_kernel, dim3((Wp + 255) / 256, Hp, B), dim3(256), 0, st, frames, prm, Hs, Ws, mean[0], mean[1],
+                       mean[2], std[0], std[1], std[2], Hp, Wp, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_preprocess(const void *img_hwc, int is_u8, int H, int W, const double mean[3], const double std[3], int Hp,
                              int Wp, float *out_chw, hipStream_t st) {
     dim3 grid((Wp + 255) / 256, Hp);

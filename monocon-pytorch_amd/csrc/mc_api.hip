@@ -986,6 +986,19 @@ int mc_preprocess(mc_handle *h, const void *img_hwc, int dtype, int H, int W, co
     return 0;
 }
 
+int mc_preprocess_augmented(mc_handle *h, const unsigned char *frames_hwc, const float *params, int B, int src_h, int src_w,
+                            const double mean[3], const double std[3], int pad_h, int pad_w, float *out_bchw, void *stream) {
+    if (!h) return -1;
+    if (!frames_hwc || !params || !mean || !std || !out_bchw) return fail(h, "mc_preprocess_augmented: null argument");
+    if (B < 1 || src_h < 1 || src_w < 1 || pad_h < 1 || pad_w < 1 || B > 65535 || pad_h > 65535)
+        return fail(h, "mc_preprocess_augmented: bad shape B=%d %dx%d -> %dx%d", B, src_h, src_w, pad_h, pad_w);
+    for (int c = 0; c < 3; ++c)
+        if (std[c] == 0.0) return fail(h, "mc_preprocess_augmented: std[%d] is zero", c);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_preprocess_aug(frames_hwc, params, B, src_h, src_w, mean, std, pad_h, pad_w, out_bchw, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int mc_bench_mfma_peak(mc_handle *h, int waves_per_simd, int iters, float *tflops) {
     if (!h || !tflops) return fail(h, "mc_bench_mfma_peak: null argument");
     HIPCHK(h, hipSetDevice(h->device));

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from transforms import (Compose, Normalize, Pad, PhotometricDistortion, RandomCrop3D, RandomHorizontalFlip, RandomShift,
+from transforms import (Compose, DeferImage, DeferredImage, Normalize, Pad, PhotometricDistortion, RandomCrop3D, RandomHorizontalFlip, RandomShift,
                         ToTensor)
 from utils.data_classes import KITTICalibration, KITTIMultiObjects
 
@@ -31,18 +31,25 @@ DEFAULT_FILTER_CONFIG = {'min_height': 25, 'min_depth': 2, 'max_depth': 65, 'max
 IMG_MEAN, IMG_STD = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
 
 
-def default_transforms():
-    """the test / validation list (dataset/monocon_dataset.py:38-42)"""
+def default_transforms(device_image: bool = False):
+    """the test / validation list (dataset/monocon_dataset.py:38-42).  ``device_image``: the image work is left to the device
+    (transforms.DeferredImage: the sample carries the raw uint8 frame + 24 parameters for ``mc_preprocess_augmented``)"""
+    if device_image:
+        return [DeferImage(), DeferredImage(size_divisor=32)]
     return [Normalize(mean=IMG_MEAN, std=IMG_STD), Pad(size_divisor=32), ToTensor()]
 
 
-def default_train_transforms(rng=None):
+def default_train_transforms(rng=None, device_image: bool = False):
     """the reference's training list (dataset/monocon_dataset.py:22-35).  ``rng``: one np.random.Generator for all the random
-    decisions (seed it per rank / worker / epoch); None = numpy's global state."""
-    return [PhotometricDistortion(brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, rng=rng),
-            RandomShift(prob=0.5, shift_range=(-32, 32), hide_kpts_in_shift_area=True, rng=rng),
-            RandomHorizontalFlip(prob=0.5, rng=rng),
-            RandomCrop3D(prob=0.5, crop_size=(320, 960), hide_kpts_in_crop_area=True, rng=rng)] + default_transforms()
+    decisions (seed it per rank / worker / epoch); None = numpy's global state.  ``device_image``: the same random decisions,
+    labels and calibration, the pixels left to the device (the float32 colour round trip alone costs a worker ~80 ms per frame)"""
+    aug = [PhotometricDistortion(brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18, rng=rng),
+           RandomShift(prob=0.5, shift_range=(-32, 32), hide_kpts_in_shift_area=True, rng=rng),
+           RandomHorizontalFlip(prob=0.5, rng=rng),
+           RandomCrop3D(prob=0.5, crop_size=(320, 960), hide_kpts_in_crop_area=True, rng=rng)]
+    if device_image:
+        return [DeferImage()] + aug + [DeferredImage(size_divisor=32)]
+    return aug + default_transforms()
 
 
 def _find_imageset(base_root: str, split: str, imageset_dir: Optional[str]) -> Optional[str]:
@@ -97,11 +104,11 @@ class BaseKITTIMono3DDataset(Dataset):
 
 class MonoConDataset(BaseKITTIMono3DDataset):
     def __init__(self, base_root: str, split: str, max_objs: int = 30, transforms=None, filter_configs: Dict[str, Any] = None,
-                 aug_rng=None, **kwargs):
+                 aug_rng=None, device_image: bool = False, **kwargs):
         super().__init__(base_root=base_root, split=split, **kwargs)
         self.max_objs = max_objs
         if transforms is None:          # as the reference: augmentations for 'train' only (monocon_dataset.py:58-63)
-            transforms = default_train_transforms(aug_rng) if split == 'train' else default_transforms()
+            transforms = default_train_transforms(aug_rng, device_image) if split == 'train' else default_transforms(device_image)
         self.transforms = Compose(transforms)
         # One Generator serves every random transform.  A DataLoader with num_workers > 0 COPIES it into each forked
         # worker, which would then all draw the same augmentation sequence (the engine's worker_init_fn only
@@ -179,6 +186,8 @@ class MonoConDataset(BaseKITTIMono3DDataset):
                'calib': [d['calib'] for d in batched]}
         if 'label' in batched[0]:
             out['label'] = {k: torch.cat([d['label'][k] for d in batched], dim=0) for k in batched[0]['label']}
+        if 'img_aug' in batched[0]:          # transforms.DeferredImage: raw frames + the device kernel's parameters
+            out['img_aug'] = torch.stack([d['img_aug'] for d in batched])
         return out
 
     def collect_gt_infos(self, verbose: bool = False) -> List[Dict[str, Any]]:

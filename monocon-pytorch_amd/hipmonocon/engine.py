@@ -352,6 +352,25 @@ class Engine:
                 _lib.check(self.h, rc, "mc_preprocess")
         return out, [(Hp, Wp)] * len(images)
 
+    def preprocess_augmented(self, frames, params, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375)):
+        """the image work of the random train augmentations + Normalize + Pad + ToTensor for a batch in one launch
+        (mc_preprocess_augmented): ``frames`` (B, Hp, Wp, 3) uint8 -- the decoded frames, zero-padded to the padded size --
+        and ``params`` (B, 24) float32 (transforms.DeferredImage writes them) -> (B, 3, Hp, Wp) float32, bit-identical to the
+        host transforms."""
+        _need_cuda(frames, "frames"); _need_cuda(params, "params")
+        if frames.dim() != 4 or frames.shape[3] != 3 or frames.dtype != torch.uint8 or not frames.is_contiguous():
+            raise _lib.MonoconHipError("preprocess_augmented: frames must be a contiguous (B,H,W,3) uint8 tensor")
+        B, Hp, Wp = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        if tuple(params.shape) != (B, 24) or params.dtype != torch.float32 or not params.is_contiguous():
+            raise _lib.MonoconHipError("preprocess_augmented: params must be a contiguous (B,24) float32 tensor")
+        out = torch.empty((B, 3, Hp, Wp), dtype=torch.float32, device=frames.device)
+        m = (C.c_double * 3)(*[float(v) for v in mean])
+        s = (C.c_double * 3)(*[float(v) for v in std])
+        with torch.cuda.device(out.device):
+            rc = self.lib.mc_preprocess_augmented(self.h, _ptr(frames), _ptr(params), B, Hp, Wp, m, s, Hp, Wp, _ptr(out), _stream())
+            _lib.check(self.h, rc, "mc_preprocess_augmented")
+        return out
+
     def set_precision(self, mode):
         """0 = fp32 MFMA, 1 = bf16 MFMA operands (config 3), 2 = fp32 emulated by a 3-way bf16 split, 3 = by a 2-way fp16 split"""
         _lib.check(self.h, self.lib.mc_set_precision(self.h, int(mode)), "mc_set_precision")

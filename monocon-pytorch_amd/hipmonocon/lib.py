@@ -16,7 +16,7 @@ EXPORTS = (
     "mc_create", "mc_destroy", "mc_last_error", "mc_version", "mc_bind_params", "mc_pack_params",
     "mc_forward_infer", "mc_backbone_forward", "mc_neck_forward", "mc_head_forward", "mc_decode", "mc_make_targets", "mc_losses", "mc_losses_backward", "mc_losses_backward_pred", "mc_forward_train", "mc_backward", "mc_train_generation", "mc_head_forward_train", "mc_head_backward", "mc_train_debug_node", "mc_optim_bind", "mc_clip_adamw_step", "mc_op_conv", "mc_op_conv_wgrad", "mc_op_conv_dgrad", "mc_op_stem", "mc_op_maxpool2", "mc_op_deconv4x4",
     "mc_op_nchw_to_nhwc", "mc_op_nhwc_to_nchw", "mc_workspace_bytes", "mc_query_workspace", "mc_forward_cost",
-    "mc_preprocess", "mc_profile_forward", "mc_profile_train", "mc_set_precision", "mc_set_local_maximum_kernel", "mc_set_conv_cfg", "mc_bench_conv", "mc_bench_mfma_peak",
+    "mc_preprocess", "mc_preprocess_augmented", "mc_profile_forward", "mc_profile_train", "mc_set_precision", "mc_set_local_maximum_kernel", "mc_set_conv_cfg", "mc_bench_conv", "mc_bench_mfma_peak",
     "mc_comm_unique_id", "mc_comm_init", "mc_comm_destroy", "mc_comm_set_overlap", "mc_comm_info", "mc_comm_exposed_ms", "mc_allreduce_grads",
     "mc_build_train_plan", "mc_tune_export", "mc_tune_import",
     "mc_rotate_iou_eval", "mc_box3d_overlap", "mc_kitti_image_overlap", "mc_kitti_statistics_part",
@@ -104,6 +104,7 @@ def load():
     lib.mc_bench_mfma_peak.argtypes = [vp, i, i, fp]
     lib.mc_profile_train.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i), vp]
     lib.mc_preprocess.argtypes = [vp, vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, i, vp, vp]
+    lib.mc_preprocess_augmented.argtypes = [vp, vp, vp, i, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), i, i, vp, vp]
     lib.mc_op_conv_dgrad.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, i, i, i, vp, vp]
     lib.mc_comm_unique_id.argtypes = [vp, vp]
     lib.mc_comm_init.argtypes = [vp, i, i, vp]

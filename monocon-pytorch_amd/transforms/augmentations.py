@@ -103,27 +103,52 @@ class PhotometricDistortion(BaseTransform):
         self.hue_delta = hue_delta
         self._draw = _Draw(rng)
 
-    def __call__(self, data_dict: Dict[str, Any]) -> Dict[str, Any]:
+    def draw(self) -> Dict[str, Any]:
+        """the random decisions of one call, in the reference's order (they do not depend on the image): None = not applied"""
         d = self._draw
-        img = data_dict['img'].astype(np.float32)[:, :, ::-1]                 # RGB -> BGR
+        p = {'brightness': None, 'contrast_before': None, 'saturation': None, 'hue': None, 'contrast_after': None, 'permutation': None}
         if d.coin():
-            img = img + np.float32(d.uniform(-self.brightness_delta, self.brightness_delta))
+            p['brightness'] = np.float32(d.uniform(-self.brightness_delta, self.brightness_delta))
         contrast_first = d.coin()
         if contrast_first and d.coin():
-            img = img * np.float32(d.uniform(self.contrast_lower, self.contrast_upper))
+            p['contrast_before'] = np.float32(d.uniform(self.contrast_lower, self.contrast_upper))
+        if d.coin():
+            p['saturation'] = np.float32(d.uniform(self.saturation_lower, self.saturation_upper))
+        if d.coin():
+            p['hue'] = np.float32(d.uniform(-self.hue_delta, self.hue_delta))
+        if not contrast_first and d.coin():
+            p['contrast_after'] = np.float32(d.uniform(self.contrast_lower, self.contrast_upper))
+        if d.coin():
+            p['permutation'] = np.asarray(d.permutation(3))
+        return p
+
+    @staticmethod
+    def apply(img: np.ndarray, p: Dict[str, Any]) -> np.ndarray:
+        img = img.astype(np.float32)[:, :, ::-1]                              # RGB -> BGR
+        if p['brightness'] is not None:
+            img = img + p['brightness']
+        if p['contrast_before'] is not None:
+            img = img * p['contrast_before']
         hsv = bgr_to_hsv(img)
-        if d.coin():
-            hsv[..., 1] = hsv[..., 1] * np.float32(d.uniform(self.saturation_lower, self.saturation_upper))
-        if d.coin():
-            hue = hsv[..., 0] + np.float32(d.uniform(-self.hue_delta, self.hue_delta))
+        if p['saturation'] is not None:
+            hsv[..., 1] = hsv[..., 1] * p['saturation']
+        if p['hue'] is not None:
+            hue = hsv[..., 0] + p['hue']
             hue = np.where(hue > 360, hue - 360, hue)
             hsv[..., 0] = np.where(hue < 0, hue + 360, hue)
         img = hsv_to_bgr(hsv)
-        if not contrast_first and d.coin():
-            img = img * np.float32(d.uniform(self.contrast_lower, self.contrast_upper))
-        if d.coin():
-            img = img[..., d.permutation(3)]
-        data_dict['img'] = np.ascontiguousarray(img[:, :, ::-1])              # BGR -> RGB
+        if p['contrast_after'] is not None:
+            img = img * p['contrast_after']
+        if p['permutation'] is not None:
+            img = img[..., p['permutation']]
+        return np.ascontiguousarray(img[:, :, ::-1])                          # BGR -> RGB
+
+    def __call__(self, data_dict: Dict[str, Any]) -> Dict[str, Any]:
+        p = self.draw()
+        if 'img_ops' in data_dict:                                            # DeferImage: the device does the pixels
+            data_dict['img_ops'].append(('colour', p))
+        else:
+            data_dict['img'] = self.apply(data_dict['img'], p)
         return data_dict
 
 
@@ -174,6 +199,9 @@ class RandomShift(BaseTransform):
         calib.P2[1, 2] += sy
         if hasattr(calib, '_refresh_intrinsics'):
             calib._refresh_intrinsics()
+        if 'img_ops' in data_dict:
+            data_dict['img_ops'].append(('shift', (sx, sy)))
+            return data_dict
         img = data_dict['img']
         canvas = np.zeros_like(img)
         h, w = H - abs(sy), W - abs(sx)
@@ -198,7 +226,10 @@ class RandomHorizontalFlip(BaseTransform):
             return data_dict
         img = data_dict['img']
         w = img.shape[1]
-        data_dict['img'] = img[:, ::-1, :]
+        if 'img_ops' in data_dict:
+            data_dict['img_ops'].append(('flip', True))
+        else:
+            data_dict['img'] = img[:, ::-1, :]
         metas['is_flipped'] = True
         calib = data_dict['calib']
         calib.P2[0, 2] = w - calib.P2[0, 2] - 1
@@ -286,6 +317,9 @@ class _CropBase(BaseTransform):
             vm = label['gt_kpts_valid_mask']
             rows = label['mask'].astype(bool)
             vm[rows] = np.where(inside[rows], vm[rows], 1).astype(vm.dtype)
+        if 'img_ops' in data_dict:
+            data_dict['img_ops'].append(('window', tuple(int(v) for v in frame)))
+            return data_dict
         img = data_dict['img']
         canvas = np.zeros_like(img)
         canvas[frame[1]:frame[3], frame[0]:frame[2], :] = img[frame[1]:frame[3], frame[0]:frame[2], :]
@@ -330,6 +364,8 @@ class Resize3D(BaseTransform):
     def __call__(self, data_dict: Dict[str, Any]) -> Dict[str, Any]:
         if self.target_hw is None:
             return data_dict
+        if data_dict.get('img_ops'):
+            raise NotImplementedError("Resize3D behind a deferred image operation: the device kernel maps whole pixels only")
         import torch
         import torch.nn.functional as F
         img = data_dict['img']
