@@ -193,28 +193,40 @@ def cpu_baseline(sd, height, width, budget_s):
     return out
 
 
-def input_feed_capacity(train_img_per_s_per_gpu, seconds=4.0):
-    """SURVEY 8f-4, one measurement: how fast ONE DataLoader worker produces samples on this host -- PNG decode (PIL) +
-    label file + calibration + filter rules + Normalize / Pad / ToTensor on the mini KITTI tree of tests/golden (real
-    375x1242 frames) -- against what the GPUs consume.  Deterministic transforms only (the random train augmentations
-    are host-side numpy work on top, not part of SURVEY 8's path)."""
+def input_feed_capacity(train_img_per_s_per_gpu, seconds=2.0):
+    """how fast ONE loader worker produces samples on this host, on the mini KITTI tree of tests/golden (real
+    375x1242 frames: PNG decode with PIL, label file, calibration, filter rules, transforms), against what the GPUs consume.
+    Four pipelines: the validation list and the train list (the reference's random augmentations, dataset/monocon_dataset.py:
+    22-35), each with the image work on the host (Normalize / Pad / ToTensor; + the float32 colour round trip, shift, flip,
+    crop for 'train') and with it deferred to the device (transforms.DeferredImage: the worker ships the decoded uint8 frame +
+    24 parameters, mc_preprocess_augmented forms the float32 frame, bit-identical).  The headline fields are the TRAIN list
+    as the engine runs it beside a device (deferred)."""
     mini = os.path.join(REPO, "tests", "golden", "kitti_mini")
     if not os.path.isdir(mini):
         return None
     from dataset.monocon_dataset import MonoConDataset
-    ds = MonoConDataset(mini, "val")
-    ds[0]
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        ds[n % len(ds)]
-        n += 1
-    per_worker = n / (time.perf_counter() - t0)
-    need = lambda g: int(np.ceil(g * train_img_per_s_per_gpu / per_worker))       # noqa: E731
-    return {"per_worker_img_per_s": round(per_worker, 1), "samples": n,
+
+    def rate(split, device_image):
+        ds = MonoConDataset(mini, split, aug_rng=np.random.default_rng(5), device_image=device_image)
+        ds[0]
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            ds[n % len(ds)]
+            n += 1
+        return n / (time.perf_counter() - t0), n
+    legs = {}
+    for split in ("val", "train"):
+        for dev in (False, True):
+            r, n = rate(split, dev)
+            legs["%s_%s" % (split, "device_image" if dev else "host_image")] = {"per_worker_img_per_s": round(r, 1), "samples": n}
+    per_worker = legs["train_device_image"]["per_worker_img_per_s"]
+    need = lambda g, r=per_worker: int(np.ceil(g * train_img_per_s_per_gpu / r))       # noqa: E731
+    return {"per_worker_img_per_s": per_worker, "samples": legs["train_device_image"]["samples"],
             "workers_needed_1gpu": need(1), "workers_needed_8gpu": need(8),
+            "workers_needed_1gpu_host_image": need(1, legs["train_host_image"]["per_worker_img_per_s"]),
+            "legs": legs,
             "host_logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
-            "note": "one process: PIL decode of a 375x1242 PNG + labels + Normalize/Pad/ToTensor (float32 CHW out); the "
-                    "mc_preprocess path (uint8 HWC to the device, normalise on the GPU) leaves only decode + labels on the host"}
+            "note": "one process, samples per second of MonoConDataset.__getitem__ on 375x1242 PNG frames; per_worker_img_per_s / workers_needed_* are the train list with the image work deferred to the device (what the engine runs beside a GPU), workers_needed_1gpu_host_image the same list with the reference's host-side image work"}
 
 
 _T0 = time.perf_counter()

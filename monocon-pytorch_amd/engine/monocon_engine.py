@@ -73,10 +73,14 @@ class MonoconEngine(BaseEngine):
             # the KITTI file dataset (dataset/monocon_dataset.py: PIL decode; the 'train' split runs the reference's random
             # augmentations, transforms/augmentations.py, every other split the deterministic list)
             from dataset.monocon_dataset import MonoConDataset
+            # DATA.DEVICE_AUGMENT (default on beside a device): the samples carry the decoded uint8 frame + 24 parameters and the
+            # detector forms the float32 frame on the device (mc_preprocess_augmented, bit-identical to the host transforms);
+            # a worker then spends its time on the PNG and the labels, not on ~80 ms of float32 colour arithmetic per frame
             dataset = MonoConDataset(base_root=self.cfg.DATA.ROOT,
                                      split=self.cfg.DATA.TRAIN_SPLIT if is_train else self.cfg.DATA.TEST_SPLIT,
                                      max_objs=self.cfg.MODEL.HEAD.MAX_OBJS,
-                                     filter_configs={k.lower(): v for k, v in dict(self.cfg.DATA.FILTER).items()})
+                                     filter_configs={k.lower(): v for k, v in dict(self.cfg.DATA.FILTER).items()},
+                                     device_image=torch.cuda.is_available() and bool(self.cfg.DATA.get('DEVICE_AUGMENT', True)))
         sampler = None
         if self.world > 1 and is_train:
             sampler = DistributedSampler(dataset, num_replicas=self.world, rank=self.rank, shuffle=True, drop_last=True)

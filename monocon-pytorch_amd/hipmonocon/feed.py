@@ -73,7 +73,9 @@ class DevicePrefetcher:
     def _stage(self, batch):
         ok = False
         if self.detector is not None and "label" in batch and isinstance(batch.get("img"), torch.Tensor):
-            ok = _train.labels_ok_on_host(batch["label"], tuple(batch["img"].shape[-2:]), self.num_classes)
+            img = batch["img"]              # (B, 3, Hp, Wp) float32, or transforms.DeferredImage's raw (B, Hp, Wp, 3) uint8 frames
+            pad_hw = tuple(img.shape[1:3]) if "img_aug" in batch else tuple(img.shape[-2:])
+            ok = _train.labels_ok_on_host(batch["label"], pad_hw, self.num_classes)
         with torch.cuda.stream(self.copy_stream):
             dev = _upload(batch, self.device)
             ev = torch.cuda.Event()
@@ -254,8 +256,9 @@ class RingLoader:
             sampler = RandomSampler(dataset, generator=generator) if shuffle else SequentialSampler(dataset)
         self._sampler = sampler
         self.sampler = _EpochGuard(self, sampler) if hasattr(sampler, "set_epoch") else sampler
-        if image_shape is None:
-            image_shape = tuple(dataset[0]["img"].shape)
+        if image_shape is None:                     # one sample tells the frames' shape and type (float32 CHW under the host
+            probe = dataset[0]["img"]               # transforms, uint8 HWC when the image work is deferred to the device)
+            image_shape, image_dtype = tuple(probe.shape), probe.dtype
         self.nslots = prefetch_factor * self.num_workers + self.EXTRA_SLOTS
         self.ring = torch.empty((self.nslots, self.batch_size) + tuple(image_shape), dtype=image_dtype).share_memory_()
         self.ring.zero_()                           # touch every page once, here

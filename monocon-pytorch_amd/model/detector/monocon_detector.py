@@ -42,8 +42,19 @@ class MonoConDetector(nn.Module):
     def _engine(self):
         return self._rt.get(self.state_dict(keep_vars=True))
 
+    def finish_batch(self, data_dict: Dict[str, Any]) -> Dict[str, Any]:
+        """a collated batch of transforms.DeferredImage samples -- raw uint8 frames (B, Hp, Wp, 3) + ``img_aug`` (B, 24) -- gets
+        its float32 (B, 3, Hp, Wp) frames here, in one launch (mc_preprocess_augmented: the train augmentations' image work +
+        Normalize + Pad + ToTensor, bit-identical to the host transforms).  Any other batch passes through."""
+        if 'img_aug' in data_dict:
+            eng = self._rt.engine if self._rt.engine is not None else self._engine()
+            from dataset.monocon_dataset import IMG_MEAN, IMG_STD
+            data_dict['img'] = eng.preprocess_augmented(data_dict['img'].contiguous(), data_dict.pop('img_aug').contiguous(),
+                                                        IMG_MEAN, IMG_STD)
+        return data_dict
+
     def forward(self, data_dict: Dict[str, Any], return_loss: bool = True) -> Tuple[Dict[str, torch.Tensor]]:
-        img = data_dict['img']
+        img = self.finish_batch(data_dict)['img']
         if self.training:
             from hipmonocon.train import forward_train
             pred_dict, loss_dict = forward_train(self, data_dict)
@@ -64,5 +75,5 @@ class MonoConDetector(nn.Module):
         self.load_state_dict(model_dict)
 
     def _extract_feat_from_data_dict(self, data_dict: Dict[str, Any]) -> torch.Tensor:
-        _, feat = self._engine().forward_infer(data_dict['img'].contiguous(), want_feat=True)
+        _, feat = self._engine().forward_infer(self.finish_batch(data_dict)['img'].contiguous(), want_feat=True)
         return feat

@@ -118,3 +118,38 @@ def test_device_augmentation_is_bit_identical_to_the_host_pipeline():
             w = want[lo + k]
             same = torch.equal(got[k].view(torch.int32), w.view(torch.int32))
             assert same, (lo + k, int(params[lo + k][2]), float((got[k] - w).abs().max()), int((got[k] != w).sum()))
+
+
+@pytest.mark.gpu
+def test_detector_steps_on_deferred_batches_as_on_host_batches(golden_sd):
+    """MonoConDetector.forward finishes a collated batch of deferred samples itself (finish_batch -> mc_preprocess_augmented):
+    the train step on it gives the losses and gradients of the step on the host pipeline's batch, bit for bit; the batches
+    come through RingLoader's uint8 ring + DevicePrefetcher on one side, a plain DataLoader on the other"""
+    from torch.utils.data import DataLoader
+    from dataset.monocon_dataset import MonoConDataset
+    from hipmonocon.feed import DevicePrefetcher, RingLoader
+    from model import MonoConDetector
+    res = []
+    for device_image in (False, True):
+        ds = MonoConDataset(MINI, "train", aug_rng=np.random.default_rng(17), device_image=device_image)
+        m = MonoConDetector(34, pretrained_backbone=False)
+        m.load_state_dict(golden_sd, strict=True)
+        m = m.cuda().train()
+        if device_image:
+            ds._aug_rng_worker = 0               # (the test wants the parent's random stream in the worker: no per-worker re-seed)
+            rl = RingLoader(ds, batch_size=2, num_workers=1, collate_fn=ds.collate_fn, image_shape=(384, 1248, 3),
+                            image_dtype=torch.uint8)       # (given: probing a sample would draw from the Generator)
+            assert rl.ring.dtype == torch.uint8 and tuple(rl.ring.shape[1:]) == (2, 384, 1248, 3)
+            batch = next(iter(DevicePrefetcher(rl, "cuda:0", m)))
+            assert batch["img"].dtype == torch.uint8 and tuple(batch["img_aug"].shape) == (2, 24)
+        else:
+            host = next(iter(DataLoader(ds, batch_size=2, collate_fn=ds.collate_fn)))
+            batch = dict(host, img=host["img"].cuda(), label={k: v.cuda() for k, v in host["label"].items()})
+        _, loss = m(batch)
+        assert batch["img"].dtype == torch.float32 and tuple(batch["img"].shape) == (2, 3, 384, 1248) and "img_aug" not in batch
+        sum(loss.values()).backward()
+        res.append(({k: float(v.detach()) for k, v in loss.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
+                    batch["img"].clone()))
+    assert torch.equal(res[0][2], res[1][2])
+    assert res[0][0] == res[1][0]
+    assert all(torch.equal(res[0][1][n], res[1][1][n]) for n in res[0][1])
