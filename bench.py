@@ -193,6 +193,29 @@ def cpu_baseline(sd, height, width, budget_s):
     return out
 
 
+def device_image_leg(engine, B=32, iters=20):
+    """mc_preprocess_augmented on B deferred train samples of the mini tree (every operation drawn), HIP events on the launch
+    stream: the device's share of the train list's image work"""
+    from dataset.monocon_dataset import MonoConDataset
+    mini = os.path.join(REPO, "tests", "golden", "kitti_mini")
+    ds = MonoConDataset(mini, "train", aug_rng=np.random.default_rng(9), device_image=True)
+    samples = [ds[i % len(ds)] for i in range(B)]
+    frames = torch.stack([d["img"] for d in samples]).cuda()
+    params = torch.stack([d["img_aug"] for d in samples]).cuda()
+    for _ in range(3):
+        out = engine.preprocess_augmented(frames, params)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = engine.preprocess_augmented(frames, params)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = frames.numel() + out.numel() * 4
+    return {"ms_per_batch": round(ms, 4), "batch": B, "frame": list(frames.shape[1:3]), "gb_per_s": round(nbytes / ms / 1e6, 1),
+            "bytes": "3 B in (uint8 HWC, zero-padded) + 12 B out (float32 CHW) per pixel; includes the allocation of the output batch"}
+
+
 def input_feed_capacity(train_img_per_s_per_gpu, seconds=2.0):
     """how fast ONE loader worker produces samples on this host, on the mini KITTI tree of tests/golden (real
     375x1242 frames: PNG decode with PIL, label file, calibration, filter rules, transforms), against what the GPUs consume.
@@ -799,6 +822,8 @@ def main():
             _phase("input feed capacity (one DataLoader worker on the mini KITTI tree)")
             try:
                 out["input_feed"] = input_feed_capacity(rep["images_per_sec"] / world)
+                if out["input_feed"] is not None:
+                    out["input_feed"]["device_image_kernel"] = device_image_leg(eng)
             except Exception as e:      # noqa: BLE001  (a host-side side figure must not kill the measurement)
                 out["input_feed"] = {"error": str(e)[:200]}
         _phase("done")
