@@ -130,10 +130,10 @@ def test_train_script_with_worker_processes(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("device_augment", (True, False))
-def test_engine_on_the_kitti_file_dataset(tmp_path, device_augment):
-    """MonoconEngine on a KITTI tree (tests/golden/kitti_mini: two real-size frames, 'train' and 'val' splits) with a loader
-    worker: the train split's random augmentations, frames through RingLoader (uint8 frames + mc_preprocess_augmented with
+@pytest.mark.parametrize("device_augment,workers", ((True, 1), (False, 1), (True, 0)))
+def test_engine_on_the_kitti_file_dataset(tmp_path, device_augment, workers):
+    """MonoconEngine on a KITTI tree (tests/golden/kitti_mini: two real-size frames, 'train' and 'val' splits) with and without a
+    loader worker: the train split's random augmentations, frames through RingLoader (uint8 frames + mc_preprocess_augmented with
     DATA.DEVICE_AUGMENT, the default; float32 frames from the host transforms without), one epoch, the AP evaluation of the
     'val' split (reference engine/monocon_engine.py:84-143, dataset/monocon_dataset.py:22-42)"""
     from engine.monocon_engine import MonoconEngine
@@ -141,12 +141,16 @@ def test_engine_on_the_kitti_file_dataset(tmp_path, device_augment):
     cfg = small_cfg(tmp_path, epochs=1)
     cfg.DATA.ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_mini")
     cfg.DATA.BATCH_SIZE = 2
-    cfg.DATA.NUM_WORKERS = 1
+    cfg.DATA.NUM_WORKERS = workers
     cfg.DATA.DEVICE_AUGMENT = device_augment
     eng = MonoconEngine(cfg)
-    assert isinstance(eng.train_loader, RingLoader) and isinstance(eng.test_loader, RingLoader)
-    want = (torch.uint8, (2, 384, 1248, 3)) if device_augment else (torch.float32, (2, 3, 384, 1248))
-    assert (eng.train_loader.ring.dtype, tuple(eng.train_loader.ring.shape[1:])) == want
+    if workers:
+        assert isinstance(eng.train_loader, RingLoader) and isinstance(eng.test_loader, RingLoader)
+        want = (torch.uint8, (2, 384, 1248, 3)) if device_augment else (torch.float32, (2, 3, 384, 1248))
+        assert (eng.train_loader.ring.dtype, tuple(eng.train_loader.ring.shape[1:])) == want
+    else:                                    # no workers: torch's DataLoader in this process, the same deferred samples
+        assert not isinstance(eng.train_loader, RingLoader)
+        assert next(iter(eng.train_loader))["img"].dtype == torch.uint8
     eng.train()
     assert len(eng.entire_losses) == 1 and eng.entire_losses[0] == eng.entire_losses[0]
     ap = eng.evaluate()
