@@ -350,6 +350,10 @@ def compact_line(out, full_path):
         c["modes"] = modes
     if out.get("realistic_loop"):
         c["realistic_loop"] = {"img_s": out["realistic_loop"]["images_per_sec"], "ms": out["realistic_loop"]["ms_per_step"]}
+    if out.get("engine_feed_kitti") and "ms_per_step" in out["engine_feed_kitti"]:
+        k = out["engine_feed_kitti"]
+        c["engine_feed_kitti"] = {"img_s": k["images_per_sec"], "ms": k["ms_per_step"], "resident_ms": k["resident_ms_per_step"],
+                                  "workers": k["workers"]}
     if out.get("engine_feed") and "ms_per_step" in out["engine_feed"]:
         c["engine_feed"] = {"img_s": out["engine_feed"]["images_per_sec"], "ms": out["engine_feed"]["ms_per_step"],
                             "workers": out["engine_feed"]["workers"]}
@@ -589,6 +593,62 @@ def main():
                             "one step ahead on a copy stream, labels checked on the host, loss read back one step late"
                             % (workers, B * 3 * H * W * 4 / 1e6, ring.nslots)}
 
+    def kitti_feed_leg(mode, steps, workers):
+        """engine_feed on REAL frames: the workers decode 375x1242 KITTI PNGs (the two frames of tests/golden/kitti_mini, over and
+        over), parse labels and calibration, draw the train list's random augmentations and move the labels; the frames travel
+        as uint8 through the ring and `mc_preprocess_augmented` forms the float32 batch (3x384x1248: what Pad(32) makes of KITTI
+        frames) in front of the step.  The same loop on ONE resident batch of that shape is timed beside it."""
+        from dataset.monocon_dataset import MonoConDataset, RepeatedDataset
+        from hipmonocon.feed import DeferredScalars, DevicePrefetcher, RingLoader
+        mini = os.path.join(REPO, "tests", "golden", "kitti_mini")
+        if not os.path.isdir(mini):
+            return None
+        m.train().set_precision(mode)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ds = RepeatedDataset(MonoConDataset(mini, "train", aug_rng=np.random.default_rng(31), device_image=True), B * steps)
+
+        def run(feed):
+            losses, got, n = DeferredScalars(), [], 0
+            for batch in feed:
+                opt.zero_grad()
+                _, loss = m(batch)
+                total = sum(v for v in loss.values())
+                total.backward()
+                losses.push(total)
+                opt.step()
+                sch.step()
+                got += losses.ready(1)
+                n += 1
+            return got + losses.ready(0), n
+
+        def timed(make_feed):
+            sync_all()
+            t0 = time.perf_counter()
+            got, n = run(make_feed())
+            sync_all()
+            dt = time.perf_counter() - t0
+            assert n and all(np.isfinite(v) for v in got)
+            return dt / n * 1e3
+
+        host = ds.collate_fn([ds[i] for i in range(B)])
+        first = next(iter(DevicePrefetcher([host], dev, m)))
+        run([first])                                    # builds (and tunes) the train plan of this shape; `first` now holds float frames
+        res_ms = timed(lambda: [dict(first) for _ in range(steps)])
+        ring = RingLoader(ds, B, workers, shuffle=True, collate_fn=ds.collate_fn)
+        try:
+            run(DevicePrefetcher(ring, dev, m))         # starts the workers
+            ms = timed(lambda: DevicePrefetcher(ring, dev, m))
+            pinned, slots, gb = bool(ring.pinned), ring.nslots, ring.ring.numel() / 1e9
+        finally:
+            ring.close()
+        return {"ms_per_step": round(ms, 3), "images_per_sec": round(B * 1e3 / ms, 2), "resident_ms_per_step": round(res_ms, 3),
+                "steps": steps, "workers": workers, "ring_gb": round(gb, 2), "pinned": pinned,
+                "workload": "train step at 3x384x1248 (KITTI frames after Pad(32)), B=%d, fed by the engine's loop from REAL 375x1242 PNG "
+                            "frames: %d fork-server workers decode, parse labels, draw the reference's train augmentations; uint8 "
+                            "frames through a page-locked ring of %d slots, image work + Normalize/Pad/ToTensor on the device "
+                            "(mc_preprocess_augmented); resident_ms_per_step = the same loop on one resident batch of that shape"
+                            % (B, workers, slots)}
+
     def forward_leg(mode, steps):
         m.eval().set_precision(mode)
         eng = m._engine()           # re-binds the (updated) parameters for the eval plan
@@ -684,13 +744,18 @@ def main():
     if args.realistic_steps > 0:
         _phase("realistic loop (fresh labels, H2D of uint8 frames on a second stream, loss.item() per step)")
         real = realistic_leg(headline_mode, args.realistic_steps)
-    feed = None
+    feed = kfeed = None
     if args.feed_steps > 0 and world == 1:
         _phase("engine feed (RingLoader workers -> pinned ring -> copy stream -> step)")
         try:
             feed = engine_feed_leg(headline_mode, args.feed_steps, args.feed_workers)
         except Exception as e:      # noqa: BLE001  (a host without /dev/shm room, ...: reported, the bench line stands)
             feed = {"error": "%s: %s" % (type(e).__name__, e)}
+        _phase("engine feed on real KITTI frames (PNG decode + train augmentations in the workers, image work on the device)")
+        try:
+            kfeed = kitti_feed_leg(headline_mode, args.feed_steps, args.feed_workers)
+        except Exception as e:      # noqa: BLE001
+            kfeed = {"error": "%s: %s" % (type(e).__name__, e)}
     m.set_precision(headline_mode)
     eng = m.eval()._engine()
 
@@ -788,6 +853,8 @@ def main():
             out["realistic_loop"] = real
         if feed is not None:
             out["engine_feed"] = feed
+        if kfeed is not None:
+            out["engine_feed_kitti"] = kfeed
         if dist_on:
             out["multi_gpu"] = {k: head[k] for k in ("per_rank_ms_per_step", "per_rank_exposed_allreduce_ms", "comm") if k in head}
             comm = head.get("comm") or {}

@@ -245,3 +245,18 @@ class MonoConDataset(BaseKITTIMono3DDataset):
             with open(save_path, 'w') as f:
                 json.dump(ap_dict, f)
         return ap_dict
+
+
+class RepeatedDataset(torch.utils.data.Dataset):
+    """``length`` samples out of a shorter dataset, index modulo its length (each access runs the dataset's own __getitem__:
+    decode, labels, transforms).  For timing a feed on a small tree of real frames (bench.py); picklable like its base."""
+
+    def __init__(self, base, length: int):
+        self.base, self.length = base, int(length)
+        self.collate_fn = base.collate_fn
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx: int):
+        return self.base[idx % len(self.base)]
