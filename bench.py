@@ -555,7 +555,7 @@ def main():
         from hipmonocon.feed import DeferredScalars, DevicePrefetcher, RingLoader
         m.train().set_precision(mode)
         ds = PooledSyntheticDataset(B * steps, H, W, pool=8, seed=900)
-        ring = RingLoader(ds, B, workers, shuffle=True, collate_fn=ds.collate_fn)
+        ring = RingLoader(ds, B, workers, shuffle=True, collate_fn=ds.collate_fn, timeout=180)
         try:
             def epoch():
                 losses, got, t_wait = DeferredScalars(), [], 0.0
@@ -634,7 +634,7 @@ def main():
         first = next(iter(DevicePrefetcher([host], dev, m)))
         run([first])                                    # builds (and tunes) the train plan of this shape; `first` now holds float frames
         res_ms = timed(lambda: [dict(first) for _ in range(steps)])
-        ring = RingLoader(ds, B, workers, shuffle=True, collate_fn=ds.collate_fn)
+        ring = RingLoader(ds, B, workers, shuffle=True, collate_fn=ds.collate_fn, timeout=180)
         try:
             run(DevicePrefetcher(ring, dev, m))         # starts the workers
             ms = timed(lambda: DevicePrefetcher(ring, dev, m))

@@ -246,7 +246,7 @@ class RingLoader:
 
     def __init__(self, dataset, batch_size, num_workers, shuffle=False, sampler=None, drop_last=False, collate_fn=None,
                  worker_init_fn=None, prefetch_factor=2, image_shape=None, image_dtype=torch.float32, pin=None, generator=None,
-                 mp_context=None):
+                 mp_context=None, timeout=0):
         from torch.utils.data import BatchSampler, DataLoader, RandomSampler, SequentialSampler
         if num_workers < 1:
             raise ValueError("RingLoader needs worker processes (num_workers >= 1); use a DataLoader without them")
@@ -288,7 +288,7 @@ class RingLoader:
         self._dl = DataLoader(_RingDataset(dataset, self.ring), batch_sampler=self._bs, num_workers=self.num_workers,
                               collate_fn=_RingCollate(self.collate_fn, self.ring), worker_init_fn=worker_init_fn,
                               prefetch_factor=prefetch_factor, multiprocessing_context=mp_context or WORKER_CONTEXT,
-                              persistent_workers=True)
+                              persistent_workers=True, timeout=timeout)       # timeout: seconds to wait for a batch (0 = for ever)
 
     def __len__(self):
         return len(self._bs)
