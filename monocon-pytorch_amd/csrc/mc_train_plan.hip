@@ -246,8 +246,10 @@ struct TB {   // train plan builder
     // gradient +0.03 ms, a conv +0.01 ms per launch) and saves one element-wise pass over the map (2 x its bytes at ~5.3
     // TB/s): worth it for the large maps only.  MONOCON_HIP_LAZY_MIN: elements per image from which a ReLU'd map whose
     // consumers are convolutions is lazy; maps with element-wise consumers only (neck proj -> deconv, project -> residual)
-    // always are.
-    long long lazy_min = [] { const char *e = std::getenv("MONOCON_HIP_LAZY_MIN"); return e ? std::atoll(e) : 983040ll; }();
+    // always are.  The default sits between the 256-channel 24x80 maps (491 520 elements: stored) and the 128-channel maps
+    // of the quarter-resolution level (983 040 at the benchmark's width 1280, 958 464 at KITTI's 1248: lazy): with 983 040
+    // itself a KITTI batch lost those maps and 0.3 ms per step (48.66 -> 48.35 ms at 384x1248, two runs each).
+    long long lazy_min = [] { const char *e = std::getenv("MONOCON_HIP_LAZY_MIN"); return e ? std::atoll(e) : 900000ll; }();
     int n_lazy = 0, n_materialised = 0;
     // a consumer that cannot form a lazy activation on load: store it after all (one element-wise pass appended to the
     // forward at this point of the build -- i.e. before the consumer's own launch -- and the node is an ordinary one from

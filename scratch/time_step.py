@@ -15,10 +15,11 @@ sd = synth.make_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
 m = MonoConDetector(34, pretrained_backbone=False); m.load_state_dict(sd, strict=True)
 m = m.cuda().train().set_precision(mode)
 opt = AdamW(m.parameters(), lr=2.25e-4, weight_decay=1e-5, betas=(0.95, 0.99), max_grad_norm=35.0)
-b = synth.make_batch(500, 8, 384, 1280)
+W = int(os.environ.get("WIDTH", "1280"))
+b = synth.make_batch(500, 8, 384, W)
 bt = {"img": b["img"].repeat(4, 1, 1, 1).cuda().contiguous(),
       "label": {k: v.repeat(4, *([1] * (v.dim() - 1))).cuda().contiguous() for k, v in b["label"].items()},
-      "img_metas": {"pad_shape": [(384, 1280)] * 32}}
+      "img_metas": {"pad_shape": [(384, W)] * 32}}
 def step():
     opt.zero_grad(); _, loss = m(bt); sum(loss.values()).backward(); opt.step()
 for _ in range(3): step()
