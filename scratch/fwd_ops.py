@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "monocon-pytorc
 import numpy as np, torch
 from hipmonocon import synth
 from model import MonoConDetector
-B = int(os.environ.get("TB", "32")); H, W = 384, 1280
+B = int(os.environ.get("TB", "32")); H, W = 384, int(os.environ.get("WIDTH", "1280"))
 stats = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "bn_calib_seed7.npz"))
 sd = synth.make_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
 m = MonoConDetector(34, pretrained_backbone=False); m.load_state_dict(sd); m = m.cuda().eval().set_precision(os.environ.get("PREC", "f16x2"))
