@@ -254,6 +254,8 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     float Y[16];
     __amdgpu_buffer_rsrc_t e_out = make_rsrc(a.out, 0u), e_res = e_out, e_y = e_out, e_z = e_out;
     int e_sout = 0, e_sres = 0, e_patch = 0, e_img = 0, e_szb = 0;
+    bool e_live = true;
+    float tmax = 0.f;                  // max |v| of the tile whose epilogue runs
     const int v_zb = nok ? (4 * g * (a.Cout >> 5) + (ncol >> 5)) * 4 : BUF_OOB;     // bit-packed mask: this lane's word of pixel 4g
     float ssum = 0.f, ssq = 0.f;
     // operands of the rows in flight: requested LEAD K-steps before their row is finished.  Three steps (~400 cycles) cover an
@@ -265,8 +267,11 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     auto epi_setup = [&](const Cursor &c) {
         const int oy0 = c.ty * 4, ox0 = c.tx * 16 + 8 * wp;
         e_img = c.img;
-        e_patch = c.ty * (2 * tiles_per_row) + 2 * c.tx + wp;
-        e_out = make_rsrc(a.out + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
+        e_patch = c.ty * a.ppr + 2 * c.tx + wp;
+        // the second patch of a row's last tile can lie outside the image (widths of an odd number of patches): its stores
+        // meet an empty buffer, its statistics and its max |v| are dropped (wave-uniform: a wave owns a patch)
+        e_live = ox0 < a.Wout;
+        e_out = make_rsrc(a.out + (size_t)c.img * a.o_img, e_live ? (unsigned)a.o_img * 4u : 0u);
         if constexpr (RES) e_res = make_rsrc(a.res + (size_t)c.img * a.r_img, (unsigned)a.r_img * 4u);
         if constexpr (BM) e_y = make_rsrc(a.bm_y + (size_t)c.img * a.o_img, (unsigned)a.o_img * 4u);
         if constexpr (BM && ZMASK) {
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
         }
         e_sout = (oy0 * a.o_row + ox0 * a.o_px) * 4;
         e_sres = (oy0 * a.r_row + ox0 * a.r_px) * 4;
-        ssum = 0.f; ssq = 0.f;
+        ssum = 0.f; ssq = 0.f; tmax = 0.f;
     };
     auto epi_load = [&](int r) {
         if constexpr (RES) rvr[r % RING] = buf_load1(e_res, v_res, e_sres + ((r >> 2) * a.r_row + (r & 3) * a.r_px) * 4);
@@ -314,15 +319,16 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
             ssq += d * d;      // (two roundings: contraction is off, as in conv_epilogue)
         }
         v = fmaxf(v, floor_v);
-        vmax = fmaxf(vmax, fabsf(v));
+        tmax = fmaxf(tmax, fabsf(v));
         e_v = v;
     };
     auto epi_row_b = [&](int r) { buf_store1(e_v, e_out, v_out, e_sout + ((r >> 2) * a.o_row + (r & 3) * a.o_px) * 4); };
     auto epi_finish = [&] {
+        vmax = fmaxf(vmax, e_live ? tmax : 0.f);
         if constexpr (BM || STATS) {
             ssum += __shfl_xor(ssum, 32);
             ssq += __shfl_xor(ssq, 32);
-            if (g == 0 && nok) {
+            if (g == 0 && nok && e_live) {
                 float *dst = a.stats + (((size_t)e_img * a.ppi + e_patch) * a.CoutP + ncol) * 2;
                 dst[0] = ssum;
                 dst[1] = ssq;
@@ -445,11 +451,13 @@ __global__ __launch_bounds__(256, 1) void conv_wres_kernel(const ConvArgs a, con
     if (a.amax_out) amax_update_wave(a.amax_out, vmax);
 }
 
-// eligible: f16x2 arithmetic on fp32 sources, 3x3 stride 1, ONE 64-channel source, dense NHWC output of whole 4x16 tiles
+// eligible: f16x2 arithmetic on fp32 sources, 3x3 stride 1, ONE 64-channel source, dense NHWC output of whole 4x8 patches (a row
+// whose width is an odd number of patches -- KITTI's 312-wide quarter-resolution maps -- ends in a tile whose second patch lies
+// outside the image: it is computed like any other and nothing of it is kept)
 bool conv_wres_ok(const ConvArgs &a, int ks, int stride) {
     if (a.prec != 3 || !a.wpk16 || !a.amax_w || ks != 3 || stride != 1) return false;
     if (a.nsrc != 1 || a.src[0].C != 64 || a.Cin != 64 || !a.amax_in[0]) return false;
-    if (a.CoutP % 64 || a.Hin != a.Hout || a.Win != a.Wout || a.Wout % 16 || a.Hout % 4) return false;
+    if (a.CoutP % 64 || a.Hin != a.Hout || a.Win != a.Wout || a.Wout % 8 || a.Hout % 4) return false;     // whole 4x8 patches
     if ((size_t)a.Hin * a.Win * 64 * 4 >= ((size_t)1 << 31)) return false;       // 32-bit buffer offsets per image
     if (a.bm_y && !a.stats) return false;
     return true;
@@ -474,7 +482,7 @@ hipError_t launch_conv_wres(const ConvArgs &a_in, int ks, int stride, hipStream_
     a.ppi = a.ppr * ((a.Hout + 3) / 4);
     a.chunks = a.ppi;
     if (resolved) *resolved = a;
-    const int tpr = a.Wout / 16, tpi = tpr * (a.Hout / 4), total = a.B * tpi, ngroups = a.CoutP / 64;
+    const int tpr = (a.Wout + 15) / 16, tpi = tpr * (a.Hout / 4), total = a.B * tpi, ngroups = a.CoutP / 64;
     // one workgroup per CU and column group where the work allows (>= 8 tiles each: the weight prologue is ~2 tiles of time)
     // (the CU count of the CURRENT device, remembered per device: handles on different GPUs share this process -- ADVICE r5)
     static std::atomic<int> ncu_of[64];

@@ -42,6 +42,11 @@ CASES = [
     ("many_tiles", 3, 24, 80, 64, False, True, True),       # 90 tiles: several per workgroup, image seams inside a range
     ("head_576", 2, 8, 32, 576, False, False, True),        # nine column groups
     ("cout_96_padded", 1, 8, 16, 96, False, True, True),    # CoutP = 128: the second group is half padding
+    # widths of an odd number of 8-column patches: the last tile of a row has its second patch outside the image
+    ("ragged_one_and_a_half", 1, 8, 24, 64, True, True, True),
+    ("ragged_half_tile", 2, 4, 8, 64, False, True, True),
+    ("ragged_kitti_row", 1, 8, 312, 64, True, True, True),  # the quarter-resolution width of a 1248-wide KITTI frame
+    ("ragged_head_576", 2, 8, 40, 576, False, False, True),
 ]
 
 
@@ -99,10 +104,10 @@ def test_wres_data_gradient_is_bit_identical(eng):
 
 
 def test_wres_ineligible_launches_fall_back(eng):
-    """the flag is a no-op for launches the kernel does not take (two sources, 128 channels, widths that are no multiple of 16)"""
+    """the flag is a no-op for launches the kernel does not take (two sources, 128 channels, widths that are no multiple of 8)"""
     dev = eng.device
     try:
-        for cins, cout, W in (([64, 64], 64, 32), ([128], 128, 32), ([64], 64, 24)):
+        for cins, cout, W in (([64, 64], 64, 32), ([128], 128, 32), ([64], 64, 20)):
             xs = [nhwc(rnd(960, "x%d" % i, (1, c, 8, W))).to(dev) for i, c in enumerate(cins)]
             w = rnd(960, "w", (cout, sum(cins), 3, 3), 0.05).to(dev)
             eng.set_conv_cfg(BASE)
@@ -114,14 +119,15 @@ def test_wres_ineligible_launches_fall_back(eng):
         eng.set_conv_cfg(0)
 
 
-def test_wres_train_step_is_bit_identical_to_the_tiled_kernels():
+@pytest.mark.parametrize("width", (256, 224))
+def test_wres_train_step_is_bit_identical_to_the_tiled_kernels(width):
     """whole train step (train-mode statistics partials, backward-statistics epilogue, all gradients) with the flag forced
-    on every eligible layer vs forced off"""
+    on every eligible layer vs forced off; width 224: 56-wide maps, rows of three and a half tiles"""
     from model import MonoConDetector
     import os
     stats = np.load(os.path.join(os.path.dirname(__file__), "golden", "bn_calib_seed7.npz"))
     sd = synth.make_state_dict(7, bn_stats={k: stats[k] for k in stats.files})
-    batch = synth.make_conditioned_batch(21, 2, 96, 256)
+    batch = synth.make_conditioned_batch(21, 2, 96, width)
     gb = {"img": batch["img"].cuda(), "label": {k: v.cuda() for k, v in batch["label"].items()}, "img_metas": batch["img_metas"]}
     runs = []
     for cfg in (BASE, WRES):
